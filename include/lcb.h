@@ -1,0 +1,162 @@
+/* lcb.h — C ABI of the MI355X-native locally-collinear-block finder (libsibeliaz_amd.so).
+ *
+ * The reference (SibeliaZ-LCB, C++11/OpenMP) has no plugin or FFI surface: its only in-process seam
+ * is BlocksFinder::FindBlocks (blocksfinder.h:453) -> blocksInstance_ (blocksfinder.h:921) ->
+ * GenerateOutput (blocksfinder.h:605) over a JunctionStorage (junctionstorage.h:116-698). This
+ * header is that seam as plain C: opaque handles, plain pointers and sizes, integer return codes
+ * (0 = ok, <0 = error, message via lcb_last_error()), no exceptions and no torch types across
+ * the boundary. Each entry point cites the reference interface it replaces. INTEGRATION.md shows
+ * the binding a reference maintainer would add.
+ *
+ * Threading: one host thread per lcb_device; lcb_graph is immutable after load and may be shared.
+ * The hot path (lcb_process_seeds) runs only on an MI355X; there is no CPU fallback — without a GPU
+ * lcb_device_create fails loudly.
+ */
+#ifndef LCB_H
+#define LCB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCB_OK 0
+#define LCB_ERR (-1)
+
+typedef struct lcb_graph lcb_graph;         /* replaces Sibelia::JunctionStorage (junctionstorage.h:116-698) */
+typedef struct lcb_device lcb_device;       /* tables + `used` bitmap resident in HBM, per-wavefront workspaces */
+typedef struct lcb_committer lcb_committer; /* ordered commit state of ProcessVertex::operator() (blocksfinder.h:372-427) */
+
+typedef struct {
+    int32_t k;             /* sibeliaz.cpp:45-51  (-k, odd) */
+    int32_t min_block;     /* sibeliaz.cpp:61-67  (-m) -> FindBlocks minBlockSize */
+    int32_t max_branch;    /* sibeliaz.cpp:53-59  (-b) -> FindBlocks maxBranchSize */
+    int32_t max_flank;     /* = -b, sibeliaz.cpp:136 */
+    int32_t looking_depth; /* 8, sibeliaz.cpp:137 */
+    int32_t phase_size;    /* 256, blocksfinder.h:519 — part of the semantics */
+} lcb_params;
+
+typedef struct {           /* BlocksFinder::Bundle (blocksfinder.h:182-209) */
+    int32_t vid;           /* signed vertex id */
+    int32_t ch;            /* next character of the seed edge */
+    uint64_t count;
+    uint64_t rank;
+    uint64_t resolve_pos;
+    uint64_t resolve_chr;
+} lcb_seed;
+
+typedef struct {           /* one Path::Instance of a per-seed result (path.h:53-181) */
+    uint32_t chr;
+    uint32_t front_idx;    /* Front().GetIndex() */
+    uint32_t back_idx;     /* Back().GetIndex() */
+    uint32_t positive;     /* Front().IsPositiveStrand() */
+} lcb_instance;
+
+typedef struct {           /* Sibelia::BlockInstance (blocksfinder.h:29-51) */
+    int32_t id;            /* signed block id */
+    uint32_t chr;
+    uint64_t start;
+    uint64_t end;
+} lcb_block;
+
+typedef struct {           /* reference-semantics event counters; only filled in stats mode */
+    uint64_t n_walk;        /* iterations of the look-ahead loop, blocksfinder.h:722-756 */
+    uint64_t n_occ;         /* occurrences visited at path.h:38, :446, :515 */
+    uint64_t n_compat_call; /* calls of Path::Compatible, path.h:380 */
+    uint64_t n_compat_step; /* iterations of its `used` walk, path.h:387-393 */
+    uint64_t n_inst_out;    /* instances in final per-seed results */
+    uint64_t n_vote;        /* MostPopularVertex calls */
+    uint64_t n_push;        /* successful PointPushBack/Front */
+    uint64_t n_process;     /* Process() calls */
+} lcb_counters;
+
+typedef struct {
+    int64_t seeds;          /* bundle_.size() */
+    int64_t blocks_found;   /* blocksFound_ */
+    int64_t failures;       /* failure_ : ordered-commit conflicts that were re-processed (blocksfinder.h:406) */
+    int64_t launches;       /* kernel launches */
+    int64_t big_retries;    /* seeds re-run with global-memory workspaces after an LDS capacity overflow */
+    double kernel_ms;       /* sum of hipEvent-timed kernel durations on the device's stream */
+    double wall_ms;         /* wall time of the phase loop */
+} lcb_stats;
+
+/* Message of the last failing call on this thread. */
+const char* lcb_last_error(void);
+/* Library version string. */
+const char* lcb_version(void);
+
+/* ---- graph: JunctionStorage::Init (junctionstorage.h:572-650), junctionapi.h:80-98, streamfastaparser.cpp:28-92 */
+lcb_graph* lcb_graph_load(const char* junction_file, const char* const* fasta_files, int n_fasta,
+                          int k, int abundance, int threads);
+void lcb_graph_free(lcb_graph* g);
+int64_t lcb_graph_n_chr(const lcb_graph* g);          /* GetChrNumber, junctionstorage.h:522 */
+int64_t lcb_graph_n_pos(const lcb_graph* g);          /* total junction occurrences kept (P) */
+int64_t lcb_graph_n_vertices(const lcb_graph* g);     /* GetVerticesNumber, junctionstorage.h:557 */
+int64_t lcb_graph_chr_len(const lcb_graph* g, int64_t chr);     /* GetChrSequence(chr).size() */
+int64_t lcb_graph_chr_n_pos(const lcb_graph* g, int64_t chr);   /* GetChrVerticesCount, junctionstorage.h:537 */
+const char* lcb_graph_chr_name(const lcb_graph* g, int64_t chr);/* GetChrDescription, junctionstorage.h:532 */
+/* SoA views (flat position index g = chr_start[chr] + idx); valid while the graph lives. */
+const uint64_t* lcb_graph_chr_start(const lcb_graph* g);        /* [n_chr+1] */
+const int32_t* lcb_graph_pos_id(const lcb_graph* g);            /* [n_pos] Position::id,  junctionstorage.h:142 */
+const uint32_t* lcb_graph_pos_pos(const lcb_graph* g);          /* [n_pos] Position::pos, junctionstorage.h:143 */
+
+/* ---- seeds: bundle enumeration + std::sort (blocksfinder.h:461-503,517). *out is malloc'ed; free with lcb_free. */
+int64_t lcb_enumerate_seeds(const lcb_graph* g, int threads, lcb_seed** out);
+void lcb_free(void* p);
+
+/* ---- device: one MI355X. device_ordinal is the HIP device index. */
+lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int device_ordinal);
+void lcb_device_destroy(lcb_device* d);
+/* `used` bits (Position::used, junctionstorage.h:144) live in HBM as a bitmap over g. */
+int lcb_device_reset_used(lcb_device* d);
+/* Set bits [lo, hi) for each of n ranges given as pairs (lo, hi) of flat position indices. */
+int lcb_device_mark_used(lcb_device* d, const uint64_t* ranges, int64_t n);
+/* Replace the bitmap wholesale (n_words = ceil(n_pos / 32)). */
+int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words);
+/* 1: collect lcb_counters in the kernels (slower; used for the roofline's algorithmic bytes). */
+int lcb_device_set_stats_mode(lcb_device* d, int on);
+
+/* THE HOT PATH: ProcessVertex::Process (blocksfinder.h:228-310) for a batch of seeds, each against the
+ * device's current `used` state, one seed per wavefront. offsets has n+1 entries; the instances of seed
+ * i are inst[offsets[i] .. offsets[i+1]). Returns LCB_OK, or LCB_ERR (e.g. inst_cap too small: the needed
+ * capacity is then in offsets[n]). best_score and ctr may be NULL. */
+int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets,
+                      lcb_instance* inst, uint64_t inst_cap, int64_t* best_score, lcb_counters* ctr);
+/* hipEvent-timed duration (ms) and launch count of kernels since the last call (reset on read). */
+int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches);
+
+/* ---- ordered commit: thread-0 section of ProcessVertex::operator() + Finalize (blocksfinder.h:312-332,372-427).
+ * Host-side, usable without a GPU (multi-GPU ranks run it redundantly on all-gathered results). */
+typedef int (*lcb_reprocess_fn)(void* user, const lcb_seed* seed, lcb_instance* out, uint64_t cap, uint64_t* n_out);
+lcb_committer* lcb_committer_create(const lcb_graph* g, const lcb_params* p);
+void lcb_committer_free(lcb_committer* c);
+/* Commits one phase's results in seed order. Conflicting seeds are re-processed through fn against the live
+ * state (fn must first apply lcb_committer_take_marks to its device). */
+int lcb_committer_commit_phase(lcb_committer* c, const lcb_seed* seeds, int64_t n, const uint64_t* offsets,
+                               const lcb_instance* inst, lcb_reprocess_fn fn, void* user);
+/* Ranges (lo, hi pairs over g) marked used since the previous call; returns the number of ranges written
+ * (at most cap) and leaves the rest queued. */
+int64_t lcb_committer_take_marks(lcb_committer* c, uint64_t* ranges, int64_t cap);
+int64_t lcb_committer_n_blocks(const lcb_committer* c);          /* blocksInstance_.size() */
+const lcb_block* lcb_committer_blocks(const lcb_committer* c);   /* pre-trim, commit order */
+int64_t lcb_committer_blocks_found(const lcb_committer* c);
+int64_t lcb_committer_failures(const lcb_committer* c);
+const uint32_t* lcb_committer_used_words(const lcb_committer* c, int64_t* n_words);
+
+/* ---- BlocksFinder::FindBlocks on one GPU (blocksfinder.h:453-530): phase loop, kernel launches, ordered
+ * commit. *blocks is malloc'ed (pre-trim blocksInstance_ in commit order); free with lcb_free. */
+int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
+                    int progress, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
+
+/* ---- GenerateOutput (blocksfinder.h:605-670): trimming, blocks_coords.gff (blocksfinder.cpp:141-174) and,
+ * if gen_seq, the <out_dir>/<i>.tmp chunk files (blocksfinder.h:533-582). */
+int lcb_generate_output(const lcb_graph* g, int64_t min_block, const lcb_block* blocks, int64_t n_blocks,
+                        int64_t blocks_found, const char* out_dir, int gen_seq, int64_t chunks,
+                        int64_t* n_trimmed, double* coverage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

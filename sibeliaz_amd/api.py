@@ -1,0 +1,358 @@
+"""ctypes binding of include/lcb.h. Fails loudly if the library is missing: there is no Python or CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(PKG, "libsibeliaz_amd.so")
+
+
+class LcbError(RuntimeError):
+    pass
+
+
+SEED_DTYPE = np.dtype([("vid", "<i4"), ("ch", "<i4"), ("count", "<u8"), ("rank", "<u8"), ("resolve_pos", "<u8"), ("resolve_chr", "<u8")])
+INSTANCE_DTYPE = np.dtype([("chr", "<u4"), ("front_idx", "<u4"), ("back_idx", "<u4"), ("positive", "<u4")])
+BLOCK_DTYPE = np.dtype([("id", "<i4"), ("chr", "<u4"), ("start", "<u8"), ("end", "<u8")])
+COUNTER_NAMES = ("n_walk", "n_occ", "n_compat_call", "n_compat_step", "n_inst_out", "n_vote", "n_push", "n_process")
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("min_block", C.c_int32), ("max_branch", C.c_int32), ("max_flank", C.c_int32),
+                ("looking_depth", C.c_int32), ("phase_size", C.c_int32)]
+
+    @classmethod
+    def make(cls, k, b=200, m=50):
+        """sibeliaz.cpp:133-138: maxFlankingSize = maxBranchSize = b, lookingDepth = 8; blocksfinder.h:519: phase 256."""
+        return cls(k, m, b, b, 8, 256)
+
+
+class Stats(C.Structure):
+    _fields_ = [("seeds", C.c_int64), ("blocks_found", C.c_int64), ("failures", C.c_int64), ("launches", C.c_int64),
+                ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_NAMES]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
+
+
+REPROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+
+_lib = None
+
+EXPORTS = [
+    "lcb_last_error", "lcb_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
+    "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
+    "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
+    "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
+    "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
+    "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_generate_output",
+]
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise LcbError("%s is missing: build it with `python sibeliaz_amd/build.py lib` (no CPU fallback exists)" % path)
+    L = C.CDLL(path)
+    vp, i64, u64p = C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)
+    L.lcb_last_error.restype = C.c_char_p
+    L.lcb_version.restype = C.c_char_p
+    L.lcb_graph_load.restype = vp
+    L.lcb_graph_load.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lcb_graph_free.argtypes = [vp]
+    for f in ("lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp]
+    for f in ("lcb_graph_chr_len", "lcb_graph_chr_n_pos"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp, i64]
+    L.lcb_graph_chr_name.restype = C.c_char_p
+    L.lcb_graph_chr_name.argtypes = [vp, i64]
+    L.lcb_graph_chr_start.restype = vp
+    L.lcb_graph_chr_start.argtypes = [vp]
+    L.lcb_graph_pos_id.restype = vp
+    L.lcb_graph_pos_id.argtypes = [vp]
+    L.lcb_graph_pos_pos.restype = vp
+    L.lcb_graph_pos_pos.argtypes = [vp]
+    L.lcb_enumerate_seeds.restype = i64
+    L.lcb_enumerate_seeds.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.lcb_free.argtypes = [vp]
+    L.lcb_device_create.restype = vp
+    L.lcb_device_create.argtypes = [vp, C.POINTER(Params), C.c_int]
+    L.lcb_device_destroy.argtypes = [vp]
+    L.lcb_device_reset_used.argtypes = [vp]
+    L.lcb_device_mark_used.argtypes = [vp, vp, i64]
+    L.lcb_device_set_used.argtypes = [vp, vp, i64]
+    L.lcb_device_set_stats_mode.argtypes = [vp, C.c_int]
+    L.lcb_process_seeds.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, C.POINTER(Counters)]
+    L.lcb_device_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.lcb_committer_create.restype = vp
+    L.lcb_committer_create.argtypes = [vp, C.POINTER(Params)]
+    L.lcb_committer_free.argtypes = [vp]
+    L.lcb_committer_commit_phase.argtypes = [vp, vp, i64, vp, vp, REPROCESS_FN, vp]
+    L.lcb_committer_take_marks.restype = i64
+    L.lcb_committer_take_marks.argtypes = [vp, vp, i64]
+    L.lcb_committer_n_blocks.restype = i64
+    L.lcb_committer_n_blocks.argtypes = [vp]
+    L.lcb_committer_blocks.restype = vp
+    L.lcb_committer_blocks.argtypes = [vp]
+    L.lcb_committer_blocks_found.restype = i64
+    L.lcb_committer_blocks_found.argtypes = [vp]
+    L.lcb_committer_failures.restype = i64
+    L.lcb_committer_failures.argtypes = [vp]
+    L.lcb_committer_used_words.restype = vp
+    L.lcb_committer_used_words.argtypes = [vp, C.POINTER(i64)]
+    L.lcb_find_blocks.argtypes = [vp, vp, C.POINTER(Params), vp, i64, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
+    L.lcb_generate_output.argtypes = [vp, i64, vp, i64, i64, C.c_char_p, C.c_int, i64, C.POINTER(i64), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _err(L):
+    return LcbError(L.lcb_last_error().decode("utf-8", "replace"))
+
+
+def _np_from(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class JunctionStorage:
+    """Sibelia::JunctionStorage (junctionstorage.h:653): junction file + FASTA -> SoA tables."""
+
+    def __init__(self, graph_file, fasta_files, k, threads=1, abundance=150):
+        self.L = load_library()
+        if isinstance(fasta_files, str):
+            fasta_files = [fasta_files]
+        arr = (C.c_char_p * len(fasta_files))(*[f.encode() for f in fasta_files])
+        self.h = self.L.lcb_graph_load(graph_file.encode(), arr, len(fasta_files), k, abundance, threads)
+        if not self.h:
+            raise _err(self.L)
+        self.k = k
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcb_graph_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def GetChrNumber(self):
+        return self.L.lcb_graph_n_chr(self.h)
+
+    def GetVerticesNumber(self):
+        return self.L.lcb_graph_n_vertices(self.h)
+
+    def n_positions(self):
+        return self.L.lcb_graph_n_pos(self.h)
+
+    def GetChrDescription(self, c):
+        return self.L.lcb_graph_chr_name(self.h, c).decode()
+
+    def chr_len(self, c):
+        return self.L.lcb_graph_chr_len(self.h, c)
+
+    def chr_start(self):
+        return _np_from(self.L.lcb_graph_chr_start(self.h), self.GetChrNumber() + 1, np.dtype("<u8"))
+
+    def pos_id(self):
+        return _np_from(self.L.lcb_graph_pos_id(self.h), self.n_positions(), np.dtype("<i4"))
+
+    def pos_pos(self):
+        return _np_from(self.L.lcb_graph_pos_pos(self.h), self.n_positions(), np.dtype("<u4"))
+
+    def seeds(self, threads=1):
+        """Bundle enumeration + sort (blocksfinder.h:461-503,517) -> structured array in processing order."""
+        out = C.c_void_p()
+        n = self.L.lcb_enumerate_seeds(self.h, threads, C.byref(out))
+        if n < 0:
+            raise _err(self.L)
+        arr = _np_from(out.value, n, SEED_DTYPE)
+        self.L.lcb_free(out)
+        return arr
+
+
+class Device:
+    """One MI355X holding the tables and the `used` bitmap in HBM."""
+
+    def __init__(self, storage, params, ordinal=0):
+        self.L = load_library()
+        self.storage = storage
+        self.params = params
+        self.h = self.L.lcb_device_create(storage.h, C.byref(params), ordinal)
+        if not self.h:
+            raise _err(self.L)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcb_device_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset_used(self):
+        if self.L.lcb_device_reset_used(self.h):
+            raise _err(self.L)
+
+    def mark_used(self, ranges):
+        r = np.ascontiguousarray(ranges, dtype="<u8").reshape(-1, 2)
+        if len(r) and self.L.lcb_device_mark_used(self.h, r.ctypes.data, len(r)):
+            raise _err(self.L)
+
+    def set_used(self, words):
+        w = np.ascontiguousarray(words, dtype="<u4")
+        if self.L.lcb_device_set_used(self.h, w.ctypes.data, len(w)):
+            raise _err(self.L)
+
+    def set_stats_mode(self, on):
+        self.L.lcb_device_set_stats_mode(self.h, 1 if on else 0)
+
+    def process_seeds(self, seeds, counters=False):
+        """ProcessVertex::Process (blocksfinder.h:228-310) for a batch -> (offsets[n+1], instances, best_score[n], counters)."""
+        s = np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        n = len(s)
+        offsets = np.zeros(n + 1, dtype="<u8")
+        score = np.zeros(n, dtype="<i8")
+        ctr = Counters()
+        cap = max(1024, 64 * n)
+        while True:
+            inst = np.zeros(cap, dtype=INSTANCE_DTYPE)
+            rc = self.L.lcb_process_seeds(self.h, s.ctypes.data, n, offsets.ctypes.data, inst.ctypes.data, cap, score.ctypes.data, C.byref(ctr))
+            if rc == 0:
+                break
+            if int(offsets[n]) > cap:
+                cap = int(offsets[n])
+                ctr = Counters()
+                continue
+            raise _err(self.L)
+        return offsets, inst[: int(offsets[n])], score, (ctr.as_dict() if counters else None)
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_int64()
+        self.L.lcb_device_kernel_time(self.h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
+class Committer:
+    """Ordered commit of per-seed results (blocksfinder.h:312-332,372-427). Host-only."""
+
+    def __init__(self, storage, params):
+        self.L = load_library()
+        self.storage = storage
+        self.h = self.L.lcb_committer_create(storage.h, C.byref(params))
+        if not self.h:
+            raise _err(self.L)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcb_committer_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def commit_phase(self, seeds, offsets, inst, reprocess):
+        """reprocess(seed_record) -> structured INSTANCE array computed against the live state."""
+        s = np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        off = np.ascontiguousarray(offsets, dtype="<u8")
+        ins = np.ascontiguousarray(inst, dtype=INSTANCE_DTYPE)
+        err = []
+
+        def cb(_user, seed_ptr, out_ptr, cap, n_out):
+            try:
+                seed = _np_from(seed_ptr, 1, SEED_DTYPE)
+                res = np.ascontiguousarray(reprocess(seed), dtype=INSTANCE_DTYPE)
+                n_out[0] = len(res)
+                if len(res) <= cap and len(res):
+                    C.memmove(out_ptr, res.ctypes.data, res.nbytes)
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the C return code
+                err.append(e)
+                return -1
+
+        fn = REPROCESS_FN(cb)
+        rc = self.L.lcb_committer_commit_phase(self.h, s.ctypes.data, len(s), off.ctypes.data, ins.ctypes.data if len(ins) else None, fn, None)
+        if err:
+            raise err[0]
+        if rc:
+            raise _err(self.L)
+
+    def take_marks(self):
+        out = []
+        buf = np.zeros((4096, 2), dtype="<u8")
+        while True:
+            n = self.L.lcb_committer_take_marks(self.h, buf.ctypes.data, len(buf))
+            out.append(buf[:n].copy())
+            if n < len(buf):
+                break
+        return np.concatenate(out) if out else np.zeros((0, 2), dtype="<u8")
+
+    def blocks(self):
+        return _np_from(self.L.lcb_committer_blocks(self.h), self.L.lcb_committer_n_blocks(self.h), BLOCK_DTYPE)
+
+    def blocks_found(self):
+        return self.L.lcb_committer_blocks_found(self.h)
+
+    def failures(self):
+        return self.L.lcb_committer_failures(self.h)
+
+    def used_words(self):
+        n = C.c_int64()
+        p = self.L.lcb_committer_used_words(self.h, C.byref(n))
+        return _np_from(p, n.value, np.dtype("<u4"))
+
+
+class BlocksFinder:
+    """Sibelia::BlocksFinder (blocksfinder.h:178): FindBlocks on one GPU, then GenerateOutput."""
+
+    def __init__(self, storage, k):
+        self.L = load_library()
+        self.storage = storage
+        self.k = k
+        self.blocks = None
+        self.stats = None
+        self.params = None
+
+    def FindBlocks(self, minBlockSize, maxBranchSize, maxFlankingSize=None, lookingDepth=8, sampleSize=0, threads=1, device=None,
+                   seeds=None):
+        p = Params(self.k, minBlockSize, maxBranchSize, maxBranchSize if maxFlankingSize is None else maxFlankingSize, lookingDepth, 256)
+        self.params = p
+        own = device is None
+        dev = Device(self.storage, p) if own else device
+        try:
+            s = self.storage.seeds(threads) if seeds is None else np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+            out, n, st = C.c_void_p(), C.c_int64(), Stats()
+            rc = self.L.lcb_find_blocks(self.storage.h, dev.h, C.byref(p), s.ctypes.data, len(s), 0, C.byref(out), C.byref(n), C.byref(st))
+            if rc:
+                raise _err(self.L)
+            self.blocks = _np_from(out.value, n.value, BLOCK_DTYPE)
+            self.L.lcb_free(out)
+            self.stats = {f: getattr(st, f) for f, _ in Stats._fields_}
+        finally:
+            if own:
+                dev.close()
+        return self.blocks
+
+    def GenerateOutput(self, outDir, genSeq=False, chunks=0, blocks=None, blocks_found=None):
+        b = np.ascontiguousarray(self.blocks if blocks is None else blocks, dtype=BLOCK_DTYPE)
+        found = int(np.abs(b["id"]).max()) if blocks_found is None and len(b) else (blocks_found or 0)
+        if blocks_found is None and self.stats is not None and blocks is None:
+            found = self.stats["blocks_found"]
+        nt, cov = C.c_int64(), C.c_double()
+        rc = self.L.lcb_generate_output(self.storage.h, self.params.min_block if self.params else 0, b.ctypes.data if len(b) else None, len(b),
+                                        found, outDir.encode(), 1 if genSeq else 0, chunks, C.byref(nt), C.byref(cov))
+        if rc:
+            raise _err(self.L)
+        return nt.value, cov.value

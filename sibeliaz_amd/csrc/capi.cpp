@@ -1,0 +1,145 @@
+// capi.cpp — the extern "C" surface declared in include/lcb.h: argument checks, exception -> return
+// code translation, thread-local error text. No logic lives here.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lcb_device.h"
+#include "lcb_host.h"
+
+namespace {
+thread_local std::string g_error;
+}
+
+void lcb_set_error(const std::string& msg) { g_error = msg; }
+
+#define LCB_TRY try {
+#define LCB_CATCH(ret)                                          \
+    }                                                           \
+    catch (std::exception & e) { g_error = e.what(); return ret; } \
+    catch (...) { g_error = "unknown error"; return ret; }
+
+extern "C" {
+
+const char* lcb_last_error(void) { return g_error.c_str(); }
+const char* lcb_version(void) { return "sibeliaz_amd 0.1 (gfx950)"; }
+void lcb_free(void* p) { free(p); }
+
+lcb_graph* lcb_graph_load(const char* junction_file, const char* const* fasta_files, int n_fasta, int k, int abundance, int threads)
+{
+    LCB_TRY
+    if (!junction_file || !fasta_files || n_fasta <= 0) throw LcbError("lcb_graph_load: missing input files");
+    if (k <= 0 || (k % 2) == 0) throw LcbError("value of K must be odd");
+    std::vector<std::string> fa(fasta_files, fasta_files + n_fasta);
+    return lcb_graph_load_impl(junction_file, fa, k, abundance, threads);
+    LCB_CATCH(nullptr)
+}
+void lcb_graph_free(lcb_graph* g) { delete g; }
+int64_t lcb_graph_n_chr(const lcb_graph* g) { return g->nChr(); }
+int64_t lcb_graph_n_pos(const lcb_graph* g) { return (int64_t)g->nPos(); }
+int64_t lcb_graph_n_vertices(const lcb_graph* g) { return g->nVertex; }
+int64_t lcb_graph_chr_len(const lcb_graph* g, int64_t chr) { return (int64_t)g->seq[(size_t)chr].size(); }
+int64_t lcb_graph_chr_n_pos(const lcb_graph* g, int64_t chr) { return (int64_t)(g->chrStart[(size_t)chr + 1] - g->chrStart[(size_t)chr]); }
+const char* lcb_graph_chr_name(const lcb_graph* g, int64_t chr) { return g->chrName[(size_t)chr].c_str(); }
+const uint64_t* lcb_graph_chr_start(const lcb_graph* g) { return g->chrStart.data(); }
+const int32_t* lcb_graph_pos_id(const lcb_graph* g) { return g->posId.data(); }
+const uint32_t* lcb_graph_pos_pos(const lcb_graph* g) { return g->posPos.data(); }
+
+int64_t lcb_enumerate_seeds(const lcb_graph* g, int threads, lcb_seed** out)
+{
+    LCB_TRY
+    std::vector<lcb_seed> v;
+    lcb_enumerate_seeds_impl(*g, threads, v);
+    *out = (lcb_seed*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_seed));
+    if (!*out) throw LcbError("out of memory");
+    if (!v.empty()) memcpy(*out, v.data(), v.size() * sizeof(lcb_seed));
+    return (int64_t)v.size();
+    LCB_CATCH(-1)
+}
+
+lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int device_ordinal)
+{
+    LCB_TRY
+    if (!g || !p) throw LcbError("lcb_device_create: null argument");
+    return lcb_device_create_impl(g, p, device_ordinal);
+    LCB_CATCH(nullptr)
+}
+void lcb_device_destroy(lcb_device* d) { lcb_device_destroy_impl(d); }
+int lcb_device_reset_used(lcb_device* d) { LCB_TRY lcb_device_reset_used_impl(d); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_mark_used(lcb_device* d, const uint64_t* ranges, int64_t n) { LCB_TRY lcb_device_mark_used_impl(d, ranges, n); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words) { LCB_TRY lcb_device_set_used_impl(d, words, n_words); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_set_stats_mode(lcb_device* d, int on) { lcb_device_set_stats_impl(d, on != 0); return LCB_OK; }
+int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches) { lcb_device_kernel_time_impl(d, ms, launches); return LCB_OK; }
+
+int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
+                      int64_t* best_score, lcb_counters* ctr)
+{
+    LCB_TRY
+    std::vector<uint64_t> off;
+    std::vector<lcb_instance> res;
+    lcb_device_process_impl(d, seeds, n, off, res, best_score, ctr);
+    memcpy(offsets, off.data(), off.size() * sizeof(uint64_t));
+    if (res.size() > inst_cap) throw LcbError("lcb_process_seeds: inst_cap too small (needed count is in offsets[n])");
+    if (!res.empty()) memcpy(inst, res.data(), res.size() * sizeof(lcb_instance));
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
+lcb_committer* lcb_committer_create(const lcb_graph* g, const lcb_params* p)
+{
+    LCB_TRY
+    return new lcb_committer(g, *p);
+    LCB_CATCH(nullptr)
+}
+void lcb_committer_free(lcb_committer* c) { delete c; }
+int lcb_committer_commit_phase(lcb_committer* c, const lcb_seed* seeds, int64_t n, const uint64_t* offsets, const lcb_instance* inst,
+                               lcb_reprocess_fn fn, void* user)
+{
+    LCB_TRY
+    c->commitPhase(seeds, n, offsets, inst, fn, user);
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+int64_t lcb_committer_take_marks(lcb_committer* c, uint64_t* ranges, int64_t cap)
+{
+    const int64_t have = (int64_t)(c->marks.size() / 2);
+    const int64_t n = have < cap ? have : cap;
+    if (n > 0) memcpy(ranges, c->marks.data(), (size_t)n * 2 * sizeof(uint64_t));
+    c->marks.erase(c->marks.begin(), c->marks.begin() + 2 * n);
+    return n;
+}
+int64_t lcb_committer_n_blocks(const lcb_committer* c) { return (int64_t)c->blocks.size(); }
+const lcb_block* lcb_committer_blocks(const lcb_committer* c) { return c->blocks.data(); }
+int64_t lcb_committer_blocks_found(const lcb_committer* c) { return c->blocksFound; }
+int64_t lcb_committer_failures(const lcb_committer* c) { return c->failures; }
+const uint32_t* lcb_committer_used_words(const lcb_committer* c, int64_t* n_words)
+{
+    if (n_words) *n_words = (int64_t)c->used.size();
+    return c->used.data();
+}
+
+int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds, int progress,
+                    lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
+{
+    LCB_TRY
+    std::vector<lcb_block> v;
+    lcb_find_blocks_impl(g, d, p, seeds, n_seeds, progress != 0, v, stats);
+    *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));
+    if (!*blocks) throw LcbError("out of memory");
+    if (!v.empty()) memcpy(*blocks, v.data(), v.size() * sizeof(lcb_block));
+    *n_blocks = (int64_t)v.size();
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
+int lcb_generate_output(const lcb_graph* g, int64_t min_block, const lcb_block* blocks, int64_t n_blocks, int64_t blocks_found,
+                        const char* out_dir, int gen_seq, int64_t chunks, int64_t* n_trimmed, double* coverage)
+{
+    LCB_TRY
+    lcb_generate_output_impl(*g, min_block, blocks, n_blocks, blocks_found, out_dir ? out_dir : "", gen_seq != 0, chunks, n_trimmed, coverage);
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
+}  // extern "C"

@@ -1,0 +1,490 @@
+// device.hip — HBM residency, workspaces and launches for the gfx950 block-finder kernels, plus the
+// single-GPU phase loop (BlocksFinder::FindBlocks, blocksfinder.h:453-530).
+//
+// Data layout in HBM (one copy per GPU, read-only except `used`):
+//   chrStart u32[C+1] | posId i32[P] | posPos u32[P] | posCh u8[P] | posRevCh u8[P]
+//   occStart u32[V+1] | occG u32[P] | occChr u32[P] | used u32[ceil(P/32)+1]        ~ 18.1 B per occurrence
+// Seeds and results travel through pinned, device-mapped host memory (the kernel reads 8 B per seed
+// and writes a 96 B header + 16 B per result instance), so a launch needs no explicit copies.
+#include <hip/hip_runtime.h>
+
+#include <time.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "lcb_device.h"
+#include "lcb_kernel.h"
+
+#define HIP_CHECK(x)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) throw LcbError(std::string(#x) + " failed: " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <bool BIG, bool STATS>
+__global__ __launch_bounds__(64) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
+                                                         LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap)
+{
+    lcb_process_body<BIG, STATS>(T, P, seeds, nSeeds, W, out, arena, arenaCap);
+}
+
+// Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
+// kernel leaves them empty again after every seed.
+__global__ __launch_bounds__(256) void lcb_init_slots_kernel(uint8_t* base, uint64_t slotBytes, LcbSlotLayout L,
+                                                             uint32_t pathCap, uint32_t voteCap)
+{
+    uint8_t* slot = base + (uint64_t)blockIdx.x * slotBytes;
+    int32_t* pKeys = (int32_t*)(slot + L.pKeys);
+    for (uint32_t i = threadIdx.x; i < pathCap; i += blockDim.x) pKeys[i] = LCB_EMPTY_KEY;
+    int32_t* vKey = (int32_t*)(slot + L.vKey);
+    uint32_t* vCount = (uint32_t*)(slot + L.vCount);
+    unsigned long long* vLast = (unsigned long long*)(slot + L.vLast);
+    for (uint32_t i = threadIdx.x; i < voteCap; i += blockDim.x) { vKey[i] = LCB_EMPTY_KEY; vCount[i] = 0; vLast[i] = 0; }
+}
+
+// MarkUsed over [lo, hi) (junctionstorage.h:285-295): one workgroup per range.
+__global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const uint64_t* ranges, uint32_t n)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint64_t lo = ranges[2 * r], hi = ranges[2 * r + 1];
+    if (hi <= lo) return;
+    const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+    for (uint64_t w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
+        if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+        atomicOr(&used[w], m);
+    }
+}
+
+namespace {
+
+struct WorkSet {
+    uint8_t* base = nullptr;
+    uint64_t slotBytes = 0;
+    uint32_t nSlots = 0, pathCap = 0, bodyCap = 0, bestCap = 0, instCap = 0, voteCap = 0;
+    bool big = false;
+};
+
+uint32_t envU32(const char* name, uint32_t dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+}  // namespace
+
+struct lcb_device_impl {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const lcb_graph* g = nullptr;
+    lcb_params p{};
+    LcbTables T{};
+    LcbKParams KP{};
+    std::vector<void*> owned;
+    uint32_t* dUsed = nullptr;
+    size_t usedWords = 0;
+    uint32_t* dCursor = nullptr;                 // [0] work tickets, [2..3] arena allocator (u64)
+    uint32_t cursorBase = 0;
+    unsigned long long arenaBase = 0;
+    WorkSet small, big;
+    // pinned, device-mapped host buffers
+    LcbKSeed* hSeeds = nullptr;
+    LcbSeedOut* hOut = nullptr;
+    uint4* hArena = nullptr;
+    uint64_t* hRanges = nullptr;
+    uint32_t* hDbg = nullptr;                    // flight recorder (LCB_DEBUG=1): 16 words per workgroup
+    uint32_t dbgSlots = 0;
+    double watchdogS = 0;                        // LCB_WATCHDOG_S: abort a launch that runs longer (0 = wait forever)
+    uint32_t batchCap = 0;
+    unsigned long long arenaCap = 0;
+    uint32_t rangeCap = 0;
+    bool stats = false;
+    double kernelMs = 0;
+    int64_t launches = 0, bigRetries = 0;
+
+    void use() { HIP_CHECK(hipSetDevice(ordinal)); }
+
+    template <class T_>
+    T_* upload(const T_* src, size_t n)
+    {
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, (n ? n : 1) * sizeof(T_)));
+        owned.push_back(d);
+        if (n) HIP_CHECK(hipMemcpy(d, src, n * sizeof(T_), hipMemcpyHostToDevice));
+        return (T_*)d;
+    }
+
+    void allocWork(WorkSet& w)
+    {
+        if (w.base) { HIP_CHECK(hipFree(w.base)); w.base = nullptr; }
+        const LcbSlotLayout L = lcb_slot_layout(w.pathCap, w.bodyCap, w.bestCap, w.big ? w.instCap : 0, w.big ? w.voteCap : 0);
+        w.slotBytes = L.total;
+        HIP_CHECK(hipMalloc((void**)&w.base, (size_t)w.slotBytes * w.nSlots));
+        hipLaunchKernelGGL(lcb_init_slots_kernel, dim3(w.nSlots), dim3(256), 0, stream, w.base, w.slotBytes, L, w.pathCap,
+                           w.big ? w.voteCap : 0u);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void allocArena(unsigned long long cap)
+    {
+        if (hArena) HIP_CHECK(hipHostFree(hArena));
+        arenaCap = cap;
+        HIP_CHECK(hipHostMalloc((void**)&hArena, (size_t)cap * sizeof(uint4), hipHostMallocDefault));
+    }
+
+    // One launch over hSeeds[0..m): returns after the stream has drained.
+    void launch(WorkSet& w, uint32_t m)
+    {
+        LcbWork W;
+        W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap;
+        W.instCap = w.instCap; W.voteCap = w.voteCap;
+        W.cursor = dCursor; W.cursorBase = cursorBase;
+        W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = arenaBase;
+        const uint32_t grid = m < w.nSlots ? m : w.nSlots;
+        W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
+        if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
+        HIP_CHECK(hipEventRecord(ev0, stream));
+        if (w.big) {
+            if (stats) hipLaunchKernelGGL((lcb_process_kernel<true, true>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
+            else hipLaunchKernelGGL((lcb_process_kernel<true, false>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
+        } else {
+            if (stats) hipLaunchKernelGGL((lcb_process_kernel<false, true>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
+            else hipLaunchKernelGGL((lcb_process_kernel<false, false>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(ev1, stream));
+        if (watchdogS > 0) {
+            // bounded wait: a kernel that does not finish is reported with its flight recorder instead of hanging the caller
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const hipError_t q = hipEventQuery(ev1);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) HIP_CHECK(q);
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el > watchdogS) {
+                    fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, w.big ? "big" : "small", grid, el);
+                    if (W.dbg) {
+                        int shown = 0;
+                        for (uint32_t b = 0; b < grid && shown < 8; b++) {
+                            const uint32_t* r = hDbg + 16 * b;
+                            if (r[0] == 2) continue;
+                            shown++;
+                            fprintf(stderr, "  wg %u: state=%u seed=%u stage=%u nInst=%u nRight=%u nLeft=%u ext=%u next=%d g=%u\n", b, r[0], r[1], r[2], r[3], r[4], r[5], r[6], (int)r[7], r[8]);
+                        }
+                    }
+                    fflush(stderr);
+                    throw LcbError("kernel watchdog expired (LCB_WATCHDOG_S)");
+                }
+                if (el > 0.002) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); }
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        kernelMs += ms;
+        launches++;
+        cursorBase += m + grid;                    // every workgroup consumed exactly one ticket past the end
+        for (uint32_t i = 0; i < m; i++) arenaBase += hOut[i].nInst;
+    }
+};
+
+lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw LcbError("no HIP device available: the block-finder hot path runs only on the GPU (there is no CPU fallback)");
+    if (ordinal < 0 || ordinal >= count) throw LcbError("HIP device ordinal out of range");
+    auto* d = new lcb_device_impl();
+    auto* handle = new lcb_device{d};
+    try {
+        d->ordinal = ordinal; d->g = g; d->p = *p;
+        d->use();
+        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&d->ev0));
+        HIP_CHECK(hipEventCreate(&d->ev1));
+        const uint64_t P = g->nPos();
+        std::vector<uint32_t> cs(g->chrStart.begin(), g->chrStart.end());
+        d->T.chrStart = d->upload(cs.data(), cs.size());
+        d->T.posId = d->upload(g->posId.data(), P);
+        d->T.posPos = d->upload(g->posPos.data(), P);
+        d->T.posCh = d->upload(g->posCh.data(), P);
+        d->T.posRevCh = d->upload(g->posRevCh.data(), P);
+        d->T.occStart = d->upload(g->occStart.data(), g->occStart.size());
+        d->T.occG = d->upload(g->occG.data(), P);
+        d->T.occChr = d->upload(g->occChr.data(), P);
+        d->usedWords = (size_t)(P / 32 + 2);
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4));
+        HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
+        d->T.used = d->dUsed;
+        d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
+        d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
+        d->KP.depth = p->looking_depth;
+        HIP_CHECK(hipMalloc((void**)&d->dCursor, 16));
+        HIP_CHECK(hipMemset(d->dCursor, 0, 16));
+        // small (LDS) mode: instances / vote table in LDS, path set + bodies + snapshot in a 1/4-MB global slot
+        d->small.big = false; d->small.nSlots = envU32("LCB_SLOTS", 1024);
+        d->small.pathCap = envU32("LCB_PATH_CAP", 32768); d->small.bodyCap = d->small.pathCap / 2; d->small.bestCap = LCB_IC_SMALL;
+        d->allocWork(d->small);
+        // big (global-memory) mode for seeds that overflow the LDS capacities; grows on demand
+        d->big.big = true; d->big.nSlots = envU32("LCB_BIG_SLOTS", 64);
+        d->big.pathCap = 262144; d->big.bodyCap = 131072; d->big.instCap = 4096; d->big.voteCap = 65536; d->big.bestCap = 4096;
+        d->allocWork(d->big);
+        d->batchCap = envU32("LCB_BATCH", 65536);
+        HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
+        d->allocArena(1u << 20);
+        const char* wd = getenv("LCB_WATCHDOG_S");
+        d->watchdogS = wd && *wd ? atof(wd) : 0;
+        if (envU32("LCB_DEBUG", 0)) {
+            d->dbgSlots = d->small.nSlots > d->big.nSlots ? d->small.nSlots : d->big.nSlots;
+            HIP_CHECK(hipHostMalloc((void**)&d->hDbg, (size_t)d->dbgSlots * 16 * sizeof(uint32_t), hipHostMallocDefault));
+        }
+        d->rangeCap = 65536;
+        HIP_CHECK(hipHostMalloc((void**)&d->hRanges, (size_t)d->rangeCap * 2 * sizeof(uint64_t), hipHostMallocDefault));
+    } catch (...) {
+        lcb_device_destroy_impl(handle);
+        throw;
+    }
+    return handle;
+}
+
+void lcb_device_destroy_impl(lcb_device* h)
+{
+    if (!h) return;
+    lcb_device_impl* d = h->impl;
+    if (d) {
+        (void)hipSetDevice(d->ordinal);
+        if (d->stream) (void)hipStreamSynchronize(d->stream);
+        for (void* p : d->owned) (void)hipFree(p);
+        if (d->dUsed) (void)hipFree(d->dUsed);
+        if (d->dCursor) (void)hipFree(d->dCursor);
+        if (d->small.base) (void)hipFree(d->small.base);
+        if (d->big.base) (void)hipFree(d->big.base);
+        if (d->hSeeds) (void)hipHostFree(d->hSeeds);
+        if (d->hOut) (void)hipHostFree(d->hOut);
+        if (d->hArena) (void)hipHostFree(d->hArena);
+        if (d->hRanges) (void)hipHostFree(d->hRanges);
+        if (d->hDbg) (void)hipHostFree(d->hDbg);
+        if (d->ev0) (void)hipEventDestroy(d->ev0);
+        if (d->ev1) (void)hipEventDestroy(d->ev1);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+        delete d;
+    }
+    delete h;
+}
+
+void lcb_device_reset_used_impl(lcb_device* h)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    HIP_CHECK(hipMemsetAsync(d->dUsed, 0, d->usedWords * 4, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+}
+
+void lcb_device_set_used_impl(lcb_device* h, const uint32_t* words, int64_t nWords)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    if ((size_t)nWords > d->usedWords) throw LcbError("used bitmap has too many words");
+    HIP_CHECK(hipMemcpy(d->dUsed, words, (size_t)nWords * 4, hipMemcpyHostToDevice));
+}
+
+void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    const uint64_t P = d->g->nPos();
+    for (int64_t done = 0; done < n;) {
+        const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
+        for (uint32_t i = 0; i < m; i++) {
+            if (ranges[2 * (done + i) + 1] > P) throw LcbError("used range beyond the position table");
+            d->hRanges[2 * i] = ranges[2 * (done + i)]; d->hRanges[2 * i + 1] = ranges[2 * (done + i) + 1];
+        }
+        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));   // hRanges is reused
+        done += m;
+    }
+}
+
+void lcb_device_set_stats_impl(lcb_device* h, bool on) { h->impl->stats = on; }
+
+void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
+{
+    if (ms) *ms = h->impl->kernelMs;
+    if (launches) *launches = h->impl->launches;
+    h->impl->kernelMs = 0; h->impl->launches = 0;
+}
+
+int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
+
+void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
+                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    offsets.assign((size_t)n + 1, 0);
+    inst.clear();
+    // per-seed results are gathered out of order (retries), then laid out in seed order
+    std::vector<std::vector<lcb_instance>> late;        // results of retried seeds
+    std::vector<int64_t> lateOf((size_t)n, -1);
+    std::vector<uint32_t> cnt((size_t)n, 0);
+    std::vector<lcb_instance> flat;                     // first-pass results in arena order
+    std::vector<uint64_t> flatOff((size_t)n, 0);
+    auto addCtr = [&](const LcbSeedOut& o) {
+        if (!ctr) return;
+        ctr->n_walk += o.ctr[0]; ctr->n_occ += o.ctr[1]; ctr->n_compat_call += o.ctr[2]; ctr->n_compat_step += o.ctr[3];
+        ctr->n_inst_out += o.ctr[4]; ctr->n_vote += o.ctr[5]; ctr->n_push += o.ctr[6]; ctr->n_process += o.ctr[7];
+    };
+    std::vector<int64_t> retry;                         // seeds that need the big workspaces / a bigger arena
+    for (int64_t base = 0; base < n; base += d->batchCap) {
+        const uint32_t m = (uint32_t)((n - base) < (int64_t)d->batchCap ? (n - base) : d->batchCap);
+        for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[base + i].vid; d->hSeeds[i].ch = seeds[base + i].ch; }
+        d->launch(d->small, m);
+        for (uint32_t i = 0; i < m; i++) {
+            const LcbSeedOut& o = d->hOut[i];
+            const int64_t s = base + i;
+            if (o.status == LCB_ST_OK) {
+                cnt[(size_t)s] = o.nInst;
+                flatOff[(size_t)s] = flat.size();
+                for (uint32_t e = 0; e < o.nInst; e++) {
+                    const uint4 r = d->hArena[o.arenaOff + e];
+                    flat.push_back(lcb_instance{r.x, r.y, r.z, r.w});
+                }
+                if (bestScore) bestScore[s] = o.bestScore;
+                addCtr(o);
+            } else if (o.status == LCB_ST_DIST_OVF) {
+                throw LcbError("a path longer than 2^31 bp is not supported");
+            } else retry.push_back(s);
+        }
+    }
+    // retries: big mode, growing the capacities while seeds keep overflowing
+    for (int round = 0; !retry.empty(); round++) {
+        if (round > 12) throw LcbError("a seed keeps overflowing the device workspaces");
+        std::vector<int64_t> again;
+        for (size_t base = 0; base < retry.size(); base += d->batchCap) {
+            const uint32_t m = (uint32_t)((retry.size() - base) < d->batchCap ? (retry.size() - base) : d->batchCap);
+            for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[retry[base + i]].vid; d->hSeeds[i].ch = seeds[retry[base + i]].ch; }
+            d->bigRetries += m;
+            d->launch(d->big, m);
+            for (uint32_t i = 0; i < m; i++) {
+                const LcbSeedOut& o = d->hOut[i];
+                const int64_t s = retry[base + i];
+                if (o.status == LCB_ST_OK) {
+                    cnt[(size_t)s] = o.nInst;
+                    lateOf[(size_t)s] = (int64_t)late.size();
+                    late.emplace_back();
+                    for (uint32_t e = 0; e < o.nInst; e++) {
+                        const uint4 r = d->hArena[o.arenaOff + e];
+                        late.back().push_back(lcb_instance{r.x, r.y, r.z, r.w});
+                    }
+                    if (bestScore) bestScore[s] = o.bestScore;
+                    addCtr(o);
+                } else if (o.status == LCB_ST_DIST_OVF) {
+                    throw LcbError("a path longer than 2^31 bp is not supported");
+                } else again.push_back(s);
+            }
+        }
+        if (!again.empty()) {
+            bool arenaOnly = true;
+            // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
+            (void)arenaOnly;
+            d->allocArena(d->arenaCap * 4);
+            d->big.pathCap *= 2; d->big.bodyCap *= 2; d->big.instCap *= 2; d->big.voteCap *= 2; d->big.bestCap *= 2;
+            d->allocWork(d->big);
+        }
+        retry.swap(again);
+    }
+    uint64_t total = 0;
+    for (int64_t s = 0; s < n; s++) { offsets[(size_t)s] = total; total += cnt[(size_t)s]; }
+    offsets[(size_t)n] = total;
+    inst.resize((size_t)total);
+    for (int64_t s = 0; s < n; s++) {
+        if (!cnt[(size_t)s]) continue;
+        const lcb_instance* src = lateOf[(size_t)s] >= 0 ? late[(size_t)lateOf[(size_t)s]].data() : flat.data() + flatOff[(size_t)s];
+        memcpy(inst.data() + offsets[(size_t)s], src, (size_t)cnt[(size_t)s] * sizeof(lcb_instance));
+    }
+}
+
+namespace {
+
+struct RedoCtx {
+    lcb_device* dev;
+    lcb_committer* com;
+    std::vector<uint64_t> off;
+    std::vector<lcb_instance> inst;
+    std::vector<uint64_t> marks;
+};
+
+void flushMarks(lcb_device* dev, lcb_committer* com, std::vector<uint64_t>& buf)
+{
+    if (com->marks.empty()) return;
+    buf.swap(com->marks);
+    com->marks.clear();
+    lcb_device_mark_used_impl(dev, buf.data(), (int64_t)(buf.size() / 2));
+}
+
+// Re-process of a seed whose speculative result conflicted (blocksfinder.h:406-411): bring the device's
+// `used` bitmap up to the live state, then run the seed again ON THE GPU.
+int redoOnDevice(void* user, const lcb_seed* seed, lcb_instance* out, uint64_t cap, uint64_t* nOut)
+{
+    RedoCtx* c = (RedoCtx*)user;
+    try {
+        flushMarks(c->dev, c->com, c->marks);
+        lcb_device_process_impl(c->dev, seed, 1, c->off, c->inst, nullptr, nullptr);
+        *nOut = c->inst.size();
+        if (c->inst.size() <= cap) memcpy(out, c->inst.data(), c->inst.size() * sizeof(lcb_instance));
+        return 0;
+    } catch (std::exception& e) {
+        lcb_set_error(e.what());
+        return -1;
+    }
+}
+
+}  // namespace
+
+void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
+                          bool progress, std::vector<lcb_block>& blocks, lcb_stats* stats)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    lcb_committer com(g, *p);
+    lcb_device_reset_used_impl(dev);
+    double ms0 = 0; int64_t l0 = 0;
+    lcb_device_kernel_time_impl(dev, &ms0, &l0);
+    const int64_t retries0 = lcb_device_big_retries_impl(dev);
+    RedoCtx ctx{dev, &com, {}, {}, {}};
+    std::vector<uint64_t> offsets;
+    std::vector<lcb_instance> inst;
+    const int64_t phase = p->phase_size > 0 ? p->phase_size : 256;
+    int64_t portion = nSeeds / 50;                                                       // progressPortion_, blocksfinder.h:509-513
+    if (portion == 0) portion = 1;
+    if (progress) std::cout << '[' << std::flush;
+    for (int64_t at = 0; at < nSeeds; at += phase) {
+        const int64_t n = (nSeeds - at) < phase ? (nSeeds - at) : phase;
+        // every seed of the phase sees the `used` bits as of the start of the phase (blocksfinder.h:345-367)
+        lcb_device_process_impl(dev, seeds + at, n, offsets, inst, nullptr, nullptr);
+        if (progress)
+            for (int64_t i = at; i < at + n; i++) if (i % portion == 0) std::cout << '.' << std::flush;
+        com.commitPhase(seeds + at, n, offsets.data(), inst.data(), redoOnDevice, &ctx);
+        flushMarks(dev, &com, ctx.marks);
+    }
+    if (progress) std::cout << ']' << std::endl;
+    blocks = com.blocks;
+    if (stats) {
+        double ms = 0; int64_t l = 0;
+        lcb_device_kernel_time_impl(dev, &ms, &l);
+        stats->seeds = nSeeds; stats->blocks_found = com.blocksFound; stats->failures = com.failures;
+        stats->launches = l; stats->kernel_ms = ms; stats->big_retries = lcb_device_big_retries_impl(dev) - retries0;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+}

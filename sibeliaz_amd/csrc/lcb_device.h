@@ -1,0 +1,31 @@
+// lcb_device.h — one MI355X: tables + `used` bitmap resident in HBM, per-wavefront workspaces,
+// kernel launches (device.hip).
+#ifndef LCB_DEVICE_H
+#define LCB_DEVICE_H
+
+#include <cstdint>
+#include <vector>
+
+#include "lcb_host.h"
+
+struct lcb_device_impl;
+
+struct lcb_device {
+    lcb_device_impl* impl;
+};
+
+lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal);
+void lcb_device_destroy_impl(lcb_device* d);
+void lcb_device_reset_used_impl(lcb_device* d);
+void lcb_device_mark_used_impl(lcb_device* d, const uint64_t* ranges, int64_t n);
+void lcb_device_set_used_impl(lcb_device* d, const uint32_t* words, int64_t nWords);
+void lcb_device_set_stats_impl(lcb_device* d, bool on);
+// Processes seeds[0..n): fills offsets[n+1] and inst (resized), bestScore (optional, n entries), ctr (optional, accumulated).
+void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
+                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr);
+void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
+int64_t lcb_device_big_retries_impl(lcb_device* d);
+void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
+                          bool progress, std::vector<lcb_block>& blocks, lcb_stats* stats);
+
+#endif

@@ -1,0 +1,864 @@
+// lcb_kernel.h — gfx950 device code of the per-seed path-extension / bubble-scoring hot path.
+//
+// One seed (BlocksFinder::Bundle) per 64-lane wavefront; a workgroup is exactly one wavefront.
+// This replaces ProcessVertex::Process (blocksfinder.h:228-310) and everything under it:
+// MostPopularVertex (blocksfinder.h:708-768), ExtendPathForward/Backward (:770-895), Path::Init,
+// PointPushBack/Front + workers, Compatible, Score, Clear (path.h:33-46,380-677) and
+// DistanceKeeper (distancekeeper.h:9-41). It is a new design, not a translation:
+//
+//  * tables are structure-of-arrays over a FLAT position index g = chrStart[chr] + idx, so a
+//    look-ahead walk is a coalesced read of consecutive posId/posPos words (lanes = walk steps);
+//  * the per-chromosome std::multiset<Instance> becomes one key-sorted index array over an
+//    insertion-ordered instance pool (pool order IS allInstance_ order) in LDS;
+//  * the dense per-thread vote array count[2V+1] becomes an LDS hash table filled with
+//    ds atomics; the order-dependent running arg-max of the reference is restated order-free
+//    (max count, then smallest origin of the last contributing instance in list order, then
+//    earliest walk step — SURVEY.md Q7) so all (instance, step) pairs can vote concurrently;
+//  * the dense DistanceKeeper int[2V] becomes a per-wave open-addressing vertex set in global
+//    memory; distances are carried by the instances (an instance's back/front distance IS the
+//    path distance of its end vertex), so no distance lookups remain;
+//  * a push evaluates all occurrences of the pushed vertex lane-parallel against the pre-push
+//    state and resolves the (rare) occurrences that fall into the same gap between two
+//    instances with a closed-form prefix rule that reproduces the sequential semantics;
+//  * Compatible's unbounded `used` walk (path.h:387-393) becomes a masked bitmap range test
+//    evaluated after the distance tests (it is a pure function).
+//
+// All cross-lane operations (__ballot/__shfl/LCB_WAVE_SYNC) sit in wave-uniform control flow.
+// Integer arithmetic only; no MFMA — the work is indexing, not contraction.
+#ifndef LCB_KERNEL_H
+#define LCB_KERNEL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LCB_EMPTY_KEY INT32_MIN
+
+// LDS-resident ("small") capacities; seeds that exceed them are re-run with global-memory
+// workspaces ("big" mode) by the host.
+#define LCB_IC_SMALL 256u    // instances
+#define LCB_VC_SMALL 1024u   // vote-table slots (power of two)
+
+enum LcbStatus : uint32_t {
+    LCB_ST_OK = 0,
+    LCB_ST_INST_OVF = 1,   // instance pool full
+    LCB_ST_VOTE_OVF = 2,   // vote table full
+    LCB_ST_PATH_OVF = 3,   // path vertex set / body full
+    LCB_ST_BEST_OVF = 4,   // result snapshot buffer full
+    LCB_ST_ARENA_OVF = 5,  // batch result arena full
+    LCB_ST_DIST_OVF = 6,   // path distance does not fit 32 bits (unsupported, > 2 Gbp paths)
+};
+
+struct LcbTables {
+    const uint32_t* chrStart;   // [nChr+1]
+    const int32_t* posId;       // [nPos]  Position::id
+    const uint32_t* posPos;     // [nPos]  Position::pos
+    const uint8_t* posCh;       // [nPos]  seq[pos + k]              (JunctionSequentialIterator::GetChar, + strand)
+    const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
+    const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
+    const uint32_t* occG;       // [nPos]  flat position of each occurrence, ascending
+    const uint32_t* occChr;     // [nPos]
+    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx)
+    uint32_t nChr, nVertex, nPos;
+};
+
+struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
+struct LcbKSeed { int32_t vid; int32_t ch; };
+
+struct LcbSeedOut {            // per-seed header written by the kernel
+    uint32_t nInst;
+    uint32_t status;
+    int64_t bestScore;
+    uint64_t arenaOff;
+    uint64_t ctr[8];           // lcb_counters order; only in stats mode
+};
+
+struct LcbWork {               // per-wave global-memory workspace slots
+    uint8_t* base;
+    uint64_t slotBytes;
+    uint32_t pathCap;          // power of two
+    uint32_t bodyCap;
+    uint32_t bestCap;
+    uint32_t instCap;          // big mode only
+    uint32_t voteCap;          // big mode only, power of two
+    uint32_t* cursor;          // work-queue head: monotone ticket counter, never reset ...
+    uint32_t cursorBase;       // ... tickets of this launch are [cursorBase, cursorBase + nSeeds)
+    unsigned long long* arenaCursor;   // monotone result-arena allocator
+    unsigned long long arenaBase;
+    uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
+};
+
+// ---- workspace layout (shared by host and device) -------------------------------------------
+struct LcbSlotLayout {
+    uint64_t pKeys, pSlots, body, best;                       // always
+    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, vTouched;   // big mode
+    uint64_t total;
+};
+__host__ __device__ inline uint64_t lcb_align16(uint64_t x) { return (x + 15) & ~15ull; }
+__host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint32_t bodyCap, uint32_t bestCap,
+                                                         uint32_t instCap, uint32_t voteCap)
+{
+    LcbSlotLayout L;
+    uint64_t o = 0;
+    L.pKeys = o; o = lcb_align16(o + 4ull * pathCap);
+    L.pSlots = o; o = lcb_align16(o + 4ull * (pathCap / 2 + 1));
+    L.body = o; o = lcb_align16(o + 8ull * bodyCap);
+    L.best = o; o = lcb_align16(o + 16ull * bestCap);
+    L.inst = o; o = lcb_align16(o + 10ull * 4 * instCap);
+    L.ordKey = o; o = lcb_align16(o + 2ull * 4 * instCap);
+    L.ordIdx = o; o = lcb_align16(o + 2ull * 4 * instCap);
+    L.good = o; o = lcb_align16(o + 4ull * instCap);
+    L.vKey = o; o = lcb_align16(o + 4ull * voteCap);
+    L.vCount = o; o = lcb_align16(o + 4ull * voteCap);
+    L.vLast = o; o = lcb_align16(o + 8ull * voteCap);
+    L.vTouched = o; o = lcb_align16(o + 4ull * voteCap);
+    L.total = lcb_align16(o);
+    return L;
+}
+
+// ---- wave primitives ---------------------------------------------------------------------------
+// Orders LDS/global accesses between the lanes of the (single) wavefront of the workgroup.
+#define LCB_WAVE_SYNC()                                           \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");    \
+    } while (0)
+
+// Flight recorder: lane 0 stores progress words the host watchdog can read while the kernel is running.
+#define LCB_MARK(S, slot, value)                                                         \
+    do {                                                                                 \
+        if ((S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    } while (0)
+
+#define LCB_FLAG_POS 1u
+#define LCB_FLAG_BACKFIN 2u
+#define LCB_FLAG_FRONTFIN 4u
+
+struct LcbState {
+    LcbTables T;
+    LcbKParams P;
+    uint32_t lane;
+    // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
+    uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iChr, *iLo, *iHi, *iFlags;
+    int32_t *iFrontDist, *iBackDist;
+    uint32_t* ordKey[2];       // instance_ ordered sets flattened: keys (flat compare position) ...
+    uint32_t* ordIdx[2];       // ... and pool indices, double buffered
+    uint32_t* good;            // goodInstance_ (path.h:685), pool indices in append order
+    uint32_t instCap;
+    // vote table
+    int32_t* vKey;
+    uint32_t* vCount;
+    unsigned long long* vLast; // (list ordinal << 32) | step of the last contribution
+    uint32_t* vTouched;
+    uint32_t* vNTouched;       // LDS counter
+    uint32_t voteCap, voteShift;
+    uint32_t* scr;             // LDS scratch, 4 * 64 words
+    // path vertex set + bodies + result snapshot (global workspace)
+    int32_t* pKeys;
+    uint32_t* pSlots;
+    uint32_t pathCap, pathShift;
+    unsigned long long* body;  // right body: (strand << 32) | g of the iterator whose outgoing edge was pushed
+    uint32_t bodyCap;
+    uint4* best;
+    uint32_t bestCap;
+    // wave-uniform scalars
+    uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
+    int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
+    uint32_t* dbg;             // flight recorder of this workgroup (may be null)
+    // per-lane event counters (stats mode)
+    uint64_t cWalk, cOcc, cCompatCall, cCompatStep, cVote, cPush;
+};
+
+__device__ __forceinline__ uint32_t lcb_hash(int32_t vid, uint32_t shift)
+{
+    return ((uint32_t)vid * 2654435761u) >> shift;
+}
+
+__device__ __forceinline__ bool lcb_used_bit(const uint32_t* used, uint32_t g)
+{
+    return (used[g >> 5] >> (g & 31)) & 1u;
+}
+
+// JunctionSequentialIterator::IsUsed (junctionstorage.h:270-283): `used` marks the edge idx -> idx+1.
+__device__ __forceinline__ bool lcb_it_used(const LcbTables& T, uint32_t g, bool positive, uint32_t lo)
+{
+    if (positive) return lcb_used_bit(T.used, g);
+    return g > lo ? lcb_used_bit(T.used, g - 1) : false;
+}
+
+// JunctionSequentialIterator::GetChar (junctionstorage.h:234-243)
+__device__ __forceinline__ uint8_t lcb_it_char(const LcbTables& T, uint32_t g, bool positive)
+{
+    return positive ? T.posCh[g] : T.posRevCh[g];
+}
+
+// Any used bit in [a, b)?  This is the `used` walk of Path::Compatible (path.h:387-393) for both strands:
+// + strand visits bits a..b-1 going up, - strand visits bits b-1..a going down.
+__device__ inline bool lcb_range_any_used(const uint32_t* used, uint32_t a, uint32_t b)
+{
+    if (a >= b) return false;
+    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    if (wa == wb) return (used[wa] & ma & mb) != 0;
+    if (used[wa] & ma) return true;
+    for (uint32_t w = wa + 1; w < wb; w++)
+        if (used[w]) return true;
+    return (used[wb] & mb) != 0;
+}
+
+// Number of iterations the reference's walk makes over [a, b) (stats mode only).
+__device__ inline uint32_t lcb_range_walk_steps(const uint32_t* used, uint32_t a, uint32_t b, bool up)
+{
+    uint32_t steps = 0;
+    if (up) { for (uint32_t g = a; g < b; g++) { steps++; if (lcb_used_bit(used, g)) break; } }
+    else { for (uint32_t g = b; g > a; g--) { steps++; if (lcb_used_bit(used, g - 1)) break; } }
+    return steps;
+}
+
+__device__ __forceinline__ uint32_t lcb_bcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); }
+
+__device__ __forceinline__ int64_t lcb_wave_sum(int64_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), o);
+        v += (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+    return v;
+}
+
+// ---- path vertex set (DistanceKeeper::IsSet / Set / Unset, distancekeeper.h:17-35) --------------
+__device__ inline bool lcb_path_contains(const LcbState& S, int32_t vid)
+{
+    uint32_t h = lcb_hash(vid, S.pathShift);
+    const uint32_t mask = S.pathCap - 1;
+    for (uint32_t probe = 0; probe < S.pathCap; probe++) {      // the set is at most half full; the bound only guards a corrupted table
+        const int32_t k = S.pKeys[h];
+        if (k == vid) return true;
+        if (k == LCB_EMPTY_KEY) return false;
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+
+// Wave-uniform: inserts vid (not present). Lane 0 writes.
+__device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
+{
+    if ((S.nPath + 1) * 2 > S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
+    uint32_t h = lcb_hash(vid, S.pathShift);
+    const uint32_t mask = S.pathCap - 1;
+    uint32_t probe = 0;
+    while (S.pKeys[h] != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; }
+    if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
+    LCB_WAVE_SYNC();               // every lane has finished probing before lane 0 publishes the key
+    if (S.lane == 0) { S.pKeys[h] = vid; S.pSlots[S.nPath] = h; }
+    S.nPath++;
+    LCB_WAVE_SYNC();
+}
+
+// Path::Clear (path.h:650-677): wave-uniform.
+__device__ inline void lcb_path_clear(LcbState& S)
+{
+    for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+    S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0;
+    S.rightFlank = 0; S.leftFlank = 0;
+    LCB_WAVE_SYNC();
+}
+
+// ---- instance helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lcb_absdiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+// Instance::RealLength (path.h:165-168): |front.GetPosition() - back.GetPosition()| (k cancels).
+__device__ __forceinline__ int64_t lcb_real_length(const LcbState& S, uint32_t i)
+{
+    return (int64_t)lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]);
+}
+
+// Rebuilds the ordered index after m inserts of one chunk. The insert list (position in the OLD order,
+// key, pool index) is in scr[0..m), scr[64..64+m), scr[128..128+m), ascending by position then key.
+__device__ inline void lcb_order_merge(LcbState& S, uint32_t m)
+{
+    const uint32_t n = S.nInst - m;     // old element count (nInst already includes the new ones)
+    const uint32_t c = S.cur, d = c ^ 1;
+    for (uint32_t i = S.lane; i < n; i += 64) {
+        uint32_t cnt = 0;
+        for (uint32_t r = 0; r < m; r++) cnt += (S.scr[r] <= i) ? 1u : 0u;
+        S.ordKey[d][i + cnt] = S.ordKey[c][i];
+        S.ordIdx[d][i + cnt] = S.ordIdx[c][i];
+    }
+    if (S.lane < m) {
+        const uint32_t at = S.scr[S.lane] + S.lane;
+        S.ordKey[d][at] = S.scr[64 + S.lane];
+        S.ordIdx[d][at] = S.scr[128 + S.lane];
+    }
+    S.cur = d;
+    LCB_WAVE_SYNC();
+}
+
+// Path::Init (path.h:33-46): one instance per unused occurrence of vid whose next character is ch.
+template <bool STATS>
+__device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
+{
+    const LcbTables& T = S.T;
+    lcb_path_insert(S, vid);          // distanceKeeper_.Set(vid, 0)
+    if (S.status) return;
+    const uint32_t av = (uint32_t)(vid < 0 ? -vid : vid);
+    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
+    for (uint32_t base = o0; base < o1; base += 64) {
+        const uint32_t j = base + S.lane;
+        bool ok = false;
+        uint32_t g = 0, chr = 0, lo = 0, hi = 0, pos = 0;
+        bool positive = false;
+        if (j < o1) {
+            if (STATS) S.cOcc++;
+            g = T.occG[j]; chr = T.occChr[j];
+            lo = T.chrStart[chr]; hi = T.chrStart[chr + 1];
+            positive = (T.posId[g] == vid);
+            pos = T.posPos[g];
+            ok = !lcb_it_used(T, g, positive, lo) && (int32_t)lcb_it_char(T, g, positive) == ch;
+        }
+        const unsigned long long m = __ballot(ok);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (S.nInst + cnt > S.instCap) { S.status = LCB_ST_INST_OVF; return; }
+        if (ok) {
+            const uint32_t i = S.nInst + (uint32_t)__popcll(m & ((1ull << S.lane) - 1));
+            S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
+            S.iFrontDist[i] = 0; S.iBackDist[i] = 0; S.iChr[i] = chr; S.iLo[i] = lo; S.iHi[i] = hi;
+            S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
+            S.ordKey[S.cur][i] = g;   // occurrences ascend in g, so pool order == key order here
+            S.ordIdx[S.cur][i] = i;
+        }
+        S.nInst += cnt;
+    }
+    LCB_WAVE_SYNC();
+}
+
+// ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
+// Returns the chosen vertex (0 = none) and the pool index of the origin instance.
+template <bool STATS>
+__device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
+{
+    const LcbTables& T = S.T;
+    const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
+    const uint32_t nList = useGood ? S.nGood : S.nInst;
+    const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
+    const uint32_t vmask = S.voteCap - 1;
+    bool ovf = false;
+    if (STATS && S.lane == 0) S.cVote++;
+    for (uint32_t e = 0; e < nList; e++) {
+        const uint32_t i = useGood ? S.good[e] : e;
+        const int32_t endDist = forward ? S.iBackDist[i] : S.iFrontDist[i];
+        // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
+        if (endDist != (forward ? S.rightFlank : S.leftFlank)) continue;
+        const bool positive = (S.iFlags[i] & LCB_FLAG_POS) != 0;
+        const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
+        const uint32_t pos0 = forward ? S.iBackPos[i] : S.iFrontPos[i];
+        const uint32_t lo = S.iLo[i], hi = S.iHi[i];
+        const uint32_t weight = lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]) + 1u;   // blocksfinder.h:719
+        const int64_t dir = (forward == positive) ? 1 : -1;
+        for (uint32_t c = 0;; c++) {
+            const uint32_t d = c * 64 + S.lane + 1;
+            const int64_t gg = (int64_t)g0 + dir * (int64_t)d;
+            bool cond = gg >= (int64_t)lo && gg < (int64_t)hi;                     // it.Valid()
+            int32_t vid = 0;
+            bool stop = false;
+            if (cond) {
+                const uint32_t g = (uint32_t)gg;
+                const uint32_t pos = T.posPos[g];
+                cond = d < (uint32_t)S.P.depth || lcb_absdiff(pos, pos0) <= (uint32_t)S.P.maxBranch;
+                if (cond) {
+                    const int32_t id = T.posId[g];
+                    vid = positive ? id : -id;
+                    stop = lcb_path_contains(S, vid) || (!tryUsed && lcb_it_used(T, g, positive, lo));
+                }
+            }
+            const unsigned long long failM = __ballot(!cond);
+            const unsigned long long stopM = __ballot(stop);
+            const unsigned long long endM = failM | stopM;
+            const uint32_t first = endM ? (uint32_t)(__ffsll((long long)endM) - 1) : 64u;
+            if (STATS) {
+                // loop iterations entered: contributing steps plus the breaking one (not the failed loop test)
+                const bool breaking = stopM && (uint32_t)(__ffsll((long long)stopM) - 1) == first;
+                if (S.lane < first || (S.lane == first && breaking)) S.cWalk++;
+            }
+            if (S.lane < first) {
+                uint32_t h = lcb_hash(vid, S.voteShift);
+                uint32_t probe = 0;
+                for (; probe < S.voteCap; probe++) {
+                    const int32_t old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
+                    if (old == LCB_EMPTY_KEY) {
+                        const uint32_t t = atomicAdd(S.vNTouched, 1u);
+                        if (t < touchedCap) S.vTouched[t] = h; else ovf = true;
+                        break;
+                    }
+                    if (old == vid) break;
+                    h = (h + 1) & vmask;
+                }
+                if (probe == S.voteCap) ovf = true;
+                else {
+                    atomicAdd(&S.vCount[h], weight);
+                    atomicMax(&S.vLast[h], ((unsigned long long)e << 32) | d);
+                }
+            }
+            if (first < 64) break;
+        }
+    }
+    LCB_WAVE_SYNC();
+    uint32_t nTouched = *S.vNTouched;
+    if (__ballot(ovf) || nTouched > touchedCap) { S.status = LCB_ST_VOTE_OVF; if (nTouched > touchedCap) nTouched = touchedCap; }
+    // order-free arg-max: max count; ties -> smallest origin (strand, g) of the last contributing
+    // instance; ties -> earliest step.  key = (positive << 63) | (g0 << 31 >> ...) packed below.
+    uint32_t bestCount = 0, bestSlot = 0xFFFFFFFFu;
+    unsigned long long bestKey = ~0ull;
+    for (uint32_t t = S.lane; t < nTouched; t += 64) {
+        const uint32_t h = S.vTouched[t];
+        const uint32_t cnt = S.vCount[h];
+        const unsigned long long last = S.vLast[h];
+        const uint32_t e = (uint32_t)(last >> 32), d = (uint32_t)last;
+        const uint32_t i = useGood ? S.good[e] : e;
+        const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
+        // JunctionSequentialIterator::operator< (junctionstorage.h:349-362): negative strand first, then chr, idx
+        const unsigned long long key = ((unsigned long long)(S.iFlags[i] & LCB_FLAG_POS) << 62) |
+                                       ((unsigned long long)g0 << 30) | (unsigned long long)(d & 0x3FFFFFFFu);
+        if (cnt > bestCount || (cnt == bestCount && key < bestKey)) { bestCount = cnt; bestKey = key; bestSlot = h; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t oc = (uint32_t)__shfl_xor((int)bestCount, o);
+        const uint32_t os = (uint32_t)__shfl_xor((int)bestSlot, o);
+        const uint32_t klo = (uint32_t)__shfl_xor((int)(uint32_t)bestKey, o);
+        const uint32_t khi = (uint32_t)__shfl_xor((int)(uint32_t)(bestKey >> 32), o);
+        const unsigned long long ok = ((unsigned long long)khi << 32) | klo;
+        if (oc > bestCount || (oc == bestCount && ok < bestKey)) { bestCount = oc; bestKey = ok; bestSlot = os; }
+    }
+    int32_t bestVid = 0;
+    originInst = 0;
+    if (bestSlot != 0xFFFFFFFFu && bestCount > 0) {
+        bestVid = S.vKey[bestSlot];
+        const uint32_t e = (uint32_t)(S.vLast[bestSlot] >> 32);
+        originInst = useGood ? S.good[e] : e;
+    }
+    LCB_WAVE_SYNC();
+    for (uint32_t t = S.lane; t < nTouched; t += 64) {              // blocksfinder.h:761-766
+        const uint32_t h = S.vTouched[t];
+        S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0;
+    }
+    if (S.lane == 0) *S.vNTouched = 0;
+    LCB_WAVE_SYNC();
+    return bestVid;
+}
+
+// ---- a push: PointPushBack / PointPushFront with their workers (path.h:430-602) ------------------
+// Per-occurrence outcomes.
+#define LCB_ACT_NONE 0u
+#define LCB_ACT_SKIP 1u      // Within() the upper-bound instance -> `continue`
+#define LCB_ACT_EXT_P 2u     // extend the predecessor instance
+#define LCB_ACT_EXT_X 3u     // extend the upper-bound instance
+#define LCB_ACT_INSERT 4u    // new single-point instance
+
+// BACK=true:  PointPushBack(e), e = OutgoingEdge of iterator (gIt, itPositive): vertex = end vertex.
+// BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
+// Returns false iff the vertex is already in the path (path.h:571-574,589-592).
+template <bool BACK, bool STATS>
+__device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool record)
+{
+    const LcbTables& T = S.T;
+    // the neighbouring position along the iterator's strand
+    const uint32_t gN = BACK ? (itPositive ? gIt + 1 : gIt - 1) : (itPositive ? gIt - 1 : gIt + 1);
+    const int32_t idN = T.posId[gN], idIt = T.posId[gIt];
+    const int32_t vertex = itPositive ? idN : -idN;                  // pushed vertex
+    const int32_t otherVertex = itPositive ? idIt : -idIt;           // e.GetEndVertex() for a front push
+    if (lcb_path_contains(S, vertex)) return false;
+    const uint32_t length = lcb_absdiff(T.posPos[gN], T.posPos[gIt]);
+    // e.GetChar(): outgoing -> char at gIt, ingoing -> char at the previous position gN (junctionstorage.h:191-227)
+    const int32_t ech = (int32_t)lcb_it_char(T, BACK ? gIt : gN, itPositive);
+    const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
+    if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
+    const int32_t distance = (int32_t)dist64;
+    lcb_path_insert(S, vertex);
+    if (S.status) return false;
+
+    const uint32_t av = (uint32_t)(vertex < 0 ? -vertex : vertex);
+    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
+    const int64_t B = S.P.maxBranch;
+    for (uint32_t base = o0; base < o1; base += 64) {
+        const uint32_t j = base + S.lane;
+        const bool active = j < o1;
+        const uint32_t n = S.nInst;
+        const uint32_t* oKey = S.ordKey[S.cur];
+        const uint32_t* oIdx = S.ordIdx[S.cur];
+        uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
+        uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
+        bool positive = false, usedS = false, usesP = false;
+        if (active) {
+            if (STATS) S.cOcc++;
+            g = T.occG[j]; chr = T.occChr[j];
+            lo = T.chrStart[chr];
+            positive = (T.posId[g] == vertex);                       // JunctionIterator::IsPositiveStrand
+            pos = T.posPos[g];
+            usedS = lcb_it_used(T, g, positive, lo);
+            // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g
+            uint32_t a = 0, b = n;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
+            u = a;
+            const bool hasX = u < n && S.iChr[oIdx[u]] == chr;
+            const bool hasP = u > 0 && S.iChr[oIdx[u - 1]] == chr;
+            bool skip = false;
+            if (hasX) {                                              // Instance::Within (path.h:170-175)
+                const uint32_t x = oIdx[u];
+                const uint32_t f = S.iFrontG[x], bk = S.iBackG[x];
+                skip = g >= (f < bk ? f : bk) && g <= (f < bk ? bk : f);
+            }
+            if (skip) act = LCB_ACT_SKIP;
+            else {
+                usesP = BACK ? positive : !positive;
+                const bool has = usesP ? hasP : hasX;
+                bool compat = false;
+                if (has) {
+                    cand = usesP ? oIdx[u - 1] : oIdx[u];
+                    if (STATS) stCall = 1;
+                    const bool cpos = (S.iFlags[cand] & LCB_FLAG_POS) != 0;
+                    if (cpos == positive) {                          // path.h:382-385
+                        const uint32_t cg = BACK ? S.iBackG[cand] : S.iFrontG[cand];
+                        const uint32_t cp = BACK ? S.iBackPos[cand] : S.iFrontPos[cand];
+                        const int32_t cd = BACK ? S.iBackDist[cand] : S.iFrontDist[cand];
+                        // Compatible(start, end, e): BACK: start = cand.Back(), end = seqIt; FRONT: start = seqIt, end = cand.Front()
+                        const int64_t startPos = BACK ? cp : pos, endPos = BACK ? pos : cp;
+                        const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
+                        const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
+                        const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
+                        if (STATS) stStep = lcb_range_walk_steps(T.used, ga, gb, positive);
+                        bool okDist = realDiff >= 0;
+                        if (okDist && (realDiff > B || ancestralDiff > B)) {
+                            // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
+                            const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
+                            const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
+                            okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
+                            if (okDist && !BACK) {
+                                const int32_t idE = T.posId[ge];
+                                okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
+                            }
+                        }
+                        compat = okDist && !lcb_range_any_used(T.used, ga, gb);
+                    }
+                }
+                if (compat) {
+                    const bool fin = (S.iFlags[cand] & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
+                    act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
+                } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
+            }
+        }
+        // Occurrences that fall into the same gap (same chromosome, same upper bound u) interact sequentially in the
+        // reference; lanes are ordered by g, so a gap is a contiguous lane segment:
+        //  * after the first EXT_X in the gap every later occurrence is Within() that instance -> SKIP;
+        //  * after the first INSERT / EXT_P in the gap the predecessor of later predecessor-using
+        //    occurrences ends at the pushed vertex -> they take the else branch (insert if unused).
+        const uint32_t uPrev = lcb_bcast(u, S.lane ? S.lane - 1 : 0);
+        const uint32_t chrPrev = lcb_bcast(chr, S.lane ? S.lane - 1 : 0);
+        const bool segStart = active && (S.lane == 0 || u != uPrev || chr != chrPrev);   // a gap belongs to one chromosome's set
+        const unsigned long long startM = __ballot(segStart);
+        const unsigned long long touchM = __ballot(active && (act == LCB_ACT_INSERT || act == LCB_ACT_EXT_P));
+        const unsigned long long extXM = __ballot(active && act == LCB_ACT_EXT_X);
+        if (active) {
+            const unsigned long long below = (1ull << S.lane) - 1;
+            const unsigned long long mineStart = startM & (below | (1ull << S.lane));
+            const uint32_t s0 = 63u - (uint32_t)__clzll((long long)mineStart);   // my segment's first lane
+            const unsigned long long seg = below & ~((1ull << s0) - 1);           // earlier lanes of my segment
+            if (extXM & seg) { act = LCB_ACT_SKIP; stCall = 0; stStep = 0; }    // `continue` before Compatible
+            else if (usesP && act != LCB_ACT_SKIP && (touchM & seg)) act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
+        }
+        if (STATS) {
+            // the reference evaluates Compatible against the instance the latest earlier occurrence of the
+            // gap inserted or extended (it ends at the pushed vertex, so the outcome is the else branch)
+            const unsigned long long finalTouchM = __ballot(active && (act == LCB_ACT_INSERT || act == LCB_ACT_EXT_P));
+            const unsigned long long below = (1ull << S.lane) - 1;
+            const unsigned long long mineStart = startM & (below | (1ull << S.lane));
+            const uint32_t s0 = mineStart ? 63u - (uint32_t)__clzll((long long)mineStart) : 0u;
+            const unsigned long long prior = active ? (finalTouchM & below & ~((1ull << s0) - 1)) : 0ull;
+            const uint32_t t = prior ? 63u - (uint32_t)__clzll((long long)prior) : 0u;
+            const uint32_t gT = lcb_bcast(g, t);
+            const uint32_t posT = lcb_bcast(positive ? 1u : 0u, t);
+            if (active && usesP && prior && !(extXM & below & ~((1ull << s0) - 1)) && act != LCB_ACT_SKIP) {
+                stCall = 1;
+                stStep = (posT != 0) == positive ? lcb_range_walk_steps(T.used, gT, g, positive) : 0u;
+            }
+            S.cCompatCall += stCall; S.cCompatStep += stStep;
+        }
+        // apply
+        const bool ins = active && act == LCB_ACT_INSERT;
+        const bool ext = active && (act == LCB_ACT_EXT_P || act == LCB_ACT_EXT_X);
+        bool becameGood = false;
+        if (ext) {
+            const int64_t before = lcb_real_length(S, cand);
+            if (BACK) {                                              // Instance::ChangeBack (path.h:124-133)
+                S.iBackG[cand] = g; S.iBackPos[cand] = pos; S.iBackDist[cand] = distance;
+                if (positive) S.ordKey[S.cur][u - 1] = g;            // compareIdx_ follows the + strand back
+                if (usedS) S.iFlags[cand] |= LCB_FLAG_BACKFIN;
+            } else {                                                 // Instance::ChangeFront (path.h:113-122)
+                S.iFrontG[cand] = g; S.iFrontPos[cand] = pos; S.iFrontDist[cand] = distance;
+                if (!positive) S.ordKey[S.cur][u - 1] = g;           // compareIdx_ follows the - strand front
+                if (usedS) S.iFlags[cand] |= LCB_FLAG_FRONTFIN;
+            }
+            becameGood = before < (int64_t)S.P.minBlock && lcb_real_length(S, cand) >= (int64_t)S.P.minBlock;
+        }
+        const unsigned long long insM = __ballot(ins);
+        const unsigned long long goodM = __ballot(becameGood);
+        const uint32_t m = (uint32_t)__popcll(insM);
+        if (S.nInst + m > S.instCap) { S.status = LCB_ST_INST_OVF; return true; }
+        if (becameGood) S.good[S.nGood + (uint32_t)__popcll(goodM & ((1ull << S.lane) - 1))] = cand;
+        S.nGood += (uint32_t)__popcll(goodM);
+        if (ins) {
+            const uint32_t r = (uint32_t)__popcll(insM & ((1ull << S.lane) - 1));
+            const uint32_t i = S.nInst + r;
+            S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
+            S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iChr[i] = chr; S.iLo[i] = lo;
+            S.iHi[i] = T.chrStart[chr + 1];
+            S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
+            S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
+        }
+        S.nInst += m;
+        LCB_WAVE_SYNC();
+        if (m) lcb_order_merge(S, m);
+    }
+    if (BACK) {
+        if (record) {
+            if (S.nRight >= S.bodyCap) { S.status = LCB_ST_PATH_OVF; return true; }
+            if (S.lane == 0) S.body[S.nRight] = ((unsigned long long)(itPositive ? 1u : 0u) << 32) | gIt;
+        }
+        S.nRight++;
+        S.rightFlank = distance;
+    } else {
+        S.nLeft++;
+        S.leftFlank = distance;
+    }
+    if (STATS && S.lane == 0) S.cPush++;
+    return true;
+}
+
+// Path::Score (path.h:604-628)
+__device__ inline int64_t lcb_score(const LcbState& S)
+{
+    int64_t sum = 0;
+    bool bad = false;
+    for (uint32_t e = S.lane; e < S.nGood; e += 64) {
+        const uint32_t i = S.good[e];
+        const int64_t rightPenalty = (int64_t)S.rightFlank - S.iBackDist[i];
+        const int64_t leftPenalty = -(int64_t)S.leftFlank + S.iFrontDist[i];
+        if (leftPenalty >= S.P.maxFlank || rightPenalty >= S.P.maxFlank) bad = true;
+        else sum += lcb_real_length(S, i) - (rightPenalty + leftPenalty) * (rightPenalty + leftPenalty);
+    }
+    const bool anyBad = __ballot(bad) != 0;
+    sum = lcb_wave_sum(sum);
+    return anyBad ? -(int64_t)INT32_MAX : sum;
+}
+
+// bestInstance <- goodInstance_ (blocksfinder.h:820-824,883-887)
+__device__ inline void lcb_snapshot(LcbState& S)
+{
+    if (S.nGood > S.bestCap) { S.status = LCB_ST_BEST_OVF; return; }
+    for (uint32_t e = S.lane; e < S.nGood; e += 64) {
+        const uint32_t i = S.good[e];
+        uint4 r;
+        r.x = S.iChr[i]; r.y = S.iFrontG[i] - S.iLo[i]; r.z = S.iBackG[i] - S.iLo[i]; r.w = (S.iFlags[i] & LCB_FLAG_POS);
+        S.best[e] = r;
+    }
+    S.nBest = S.nGood;
+}
+
+// ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
+template <bool FORWARD, bool STATS>
+__device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
+{
+    const LcbTables& T = S.T;
+    uint32_t oi = 0;
+    LCB_MARK(S, 4, S.nRight); LCB_MARK(S, 5, S.nLeft); LCB_MARK(S, 6, 1);
+    int32_t next = lcb_vote<STATS>(S, FORWARD, false, oi);
+    LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
+    if (S.status) return false;
+    if (FORWARD && next == 0) {                                      // blocksfinder.h:782-785 (forward only, Q2)
+        next = lcb_vote<STATS>(S, true, true, oi);
+        if (S.status) return false;
+    }
+    bool success = false;
+    if (next != 0) {
+        const bool positive = (S.iFlags[oi] & LCB_FLAG_POS) != 0;
+        uint32_t g = FORWARD ? S.iBackG[oi] : S.iFrontG[oi];
+        const int dir = (FORWARD == positive) ? 1 : -1;
+        for (;;) {
+            const int32_t id = T.posId[g];
+            if ((positive ? id : -id) == next) break;
+            LCB_MARK(S, 6, 3); LCB_MARK(S, 8, g);
+            success = lcb_push<FORWARD, STATS>(S, g, positive, true);
+            LCB_MARK(S, 6, 4);
+            if (S.status) return false;
+            if (success) {
+                nowScore = lcb_score(S);
+                if (nowScore > bestScore) {
+                    bestScore = nowScore;
+                    if (FORWARD) bestRightSize = S.nRight + 1;
+                    if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
+                }
+            }
+            g = (uint32_t)((int64_t)g + dir);
+        }
+    }
+    return success;
+}
+
+// ProcessVertex::Process (blocksfinder.h:228-310)
+template <bool STATS>
+__device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
+{
+    int64_t score = 0, bestScore = 0;
+    S.nBest = 0; S.status = LCB_ST_OK;
+    LCB_MARK(S, 2, 1);
+    lcb_path_init<STATS>(S, vid, ch);
+    LCB_MARK(S, 2, 2); LCB_MARK(S, 3, S.nInst);
+    uint32_t bestRightSize = 1;
+    const int64_t minRun = 2 * (int64_t)S.P.maxBranch;
+    if (!S.status) {
+        for (;;) {                                                   // blocksfinder.h:255-269
+            bool ret = true, positive = false;
+            const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
+            while ((ret = lcb_extend<true, STATS>(S, bestRightSize, bestScore, score)) &&
+                   ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
+                positive = positive || (score > 0);
+            if (!ret || !positive || S.status) break;
+        }
+    }
+    LCB_MARK(S, 2, 3);
+    if (!S.status) {                                                 // replay, blocksfinder.h:271-284
+        const uint32_t nEdge = bestRightSize - 1;
+        // keep the body list, reset everything else
+        for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+        S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0; S.rightFlank = 0; S.leftFlank = 0;
+        LCB_WAVE_SYNC();
+        lcb_path_init<STATS>(S, vid, ch);
+        for (uint32_t i = 0; i < nEdge && !S.status; i++) {
+            const unsigned long long b = S.body[i];
+            lcb_push<true, STATS>(S, (uint32_t)b, (b >> 32) != 0, false);
+        }
+    }
+    LCB_MARK(S, 2, 4);
+    if (!S.status) {
+        for (;;) {                                                   // blocksfinder.h:292-306 (stray ';' at :297, Q1)
+            bool ret = true;
+            const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
+            while ((ret = lcb_extend<false, STATS>(S, bestRightSize, bestScore, score)) &&
+                   ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
+                ;
+            const bool positive = score > 0;
+            if (!ret || !positive || S.status) break;
+        }
+    }
+    LCB_MARK(S, 2, 5);
+    // Path::Clear (blocksfinder.h:308)
+    for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+    S.nPath = 0;
+    if (S.status == LCB_ST_VOTE_OVF) {
+        // the vote table may hold stale keys after an overflow: wipe it
+        for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
+        if (S.lane == 0) *S.vNTouched = 0;
+    }
+    LCB_WAVE_SYNC();
+    bestScoreOut = bestScore;
+}
+
+// ---- the kernel --------------------------------------------------------------------------------
+template <bool BIG, bool STATS>
+__device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P, const LcbKSeed* seeds, uint32_t nSeeds,
+                                        const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap)
+{
+    constexpr uint32_t IC = BIG ? 1u : LCB_IC_SMALL;
+    constexpr uint32_t VC = BIG ? 1u : LCB_VC_SMALL;
+    __shared__ uint32_t sInst[10 * IC];
+    __shared__ uint32_t sOrdKey[2 * IC];
+    __shared__ uint32_t sOrdIdx[2 * IC];
+    __shared__ uint32_t sGood[IC];
+    __shared__ int32_t sVKey[VC];
+    __shared__ uint32_t sVCount[VC];
+    __shared__ unsigned long long sVLast[VC];
+    __shared__ uint32_t sVTouched[VC];
+    __shared__ uint32_t sScr[4 * 64];
+    __shared__ uint32_t sMisc[4];
+
+    LcbState S;
+    S.T = T; S.P = P;
+    S.lane = threadIdx.x & 63u;
+    uint8_t* slot = W.base + (uint64_t)blockIdx.x * W.slotBytes;
+    const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, BIG ? W.instCap : 0, BIG ? W.voteCap : 0);
+    S.pKeys = (int32_t*)(slot + L.pKeys);
+    S.pSlots = (uint32_t*)(slot + L.pSlots);
+    S.pathCap = W.pathCap; S.pathShift = 32u - (uint32_t)__ffs((int)W.pathCap) + 1u;
+    S.body = (unsigned long long*)(slot + L.body); S.bodyCap = W.bodyCap;
+    S.best = (uint4*)(slot + L.best); S.bestCap = W.bestCap;
+    uint32_t* instBase;
+    if (BIG) {
+        instBase = (uint32_t*)(slot + L.inst); S.instCap = W.instCap;
+        S.ordKey[0] = (uint32_t*)(slot + L.ordKey); S.ordKey[1] = S.ordKey[0] + W.instCap;
+        S.ordIdx[0] = (uint32_t*)(slot + L.ordIdx); S.ordIdx[1] = S.ordIdx[0] + W.instCap;
+        S.good = (uint32_t*)(slot + L.good);
+        S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
+        S.vLast = (unsigned long long*)(slot + L.vLast); S.vTouched = (uint32_t*)(slot + L.vTouched);
+        S.voteCap = W.voteCap;
+    } else {
+        instBase = sInst; S.instCap = IC;
+        S.ordKey[0] = sOrdKey; S.ordKey[1] = sOrdKey + IC;
+        S.ordIdx[0] = sOrdIdx; S.ordIdx[1] = sOrdIdx + IC;
+        S.good = sGood;
+        S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast; S.vTouched = sVTouched;
+        S.voteCap = VC;
+        for (uint32_t h = S.lane; h < VC; h += 64) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
+    }
+    S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
+    S.iFrontG = instBase; S.iBackG = instBase + S.instCap; S.iFrontPos = instBase + 2 * S.instCap;
+    S.iBackPos = instBase + 3 * S.instCap; S.iChr = instBase + 4 * S.instCap; S.iLo = instBase + 5 * S.instCap;
+    S.iHi = instBase + 6 * S.instCap; S.iFlags = instBase + 7 * S.instCap;
+    S.iFrontDist = (int32_t*)(instBase + 8 * S.instCap); S.iBackDist = (int32_t*)(instBase + 9 * S.instCap);
+    S.scr = sScr; S.vNTouched = &sMisc[0];
+    S.dbg = W.dbg ? W.dbg + 16u * blockIdx.x : nullptr;
+    LCB_MARK(S, 0, 1);
+    if (S.lane == 0) sMisc[0] = 0;
+    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0;
+    S.rightFlank = S.leftFlank = 0;
+    LCB_WAVE_SYNC();
+
+    for (;;) {
+        uint32_t s = 0;
+        if (S.lane == 0) s = atomicAdd(W.cursor, 1u) - W.cursorBase;   // every workgroup overshoots by exactly one ticket
+        s = lcb_bcast(s, 0);
+        if (s >= nSeeds) break;
+        LCB_MARK(S, 1, s + 1);
+        S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
+        S.nInst = S.nGood = S.cur = S.nRight = S.nLeft = 0; S.rightFlank = S.leftFlank = 0;
+        int64_t bestScore = 0;
+        lcb_process_seed<STATS>(S, seeds[s].vid, seeds[s].ch, bestScore);
+        const uint32_t n = S.status ? 0u : S.nBest;
+        unsigned long long off = 0;
+        if (n) {
+            uint32_t olo = 0, ohi = 0;
+            if (S.lane == 0) { off = atomicAdd(W.arenaCursor, (unsigned long long)n) - W.arenaBase; olo = (uint32_t)off; ohi = (uint32_t)(off >> 32); }
+            olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
+            off = ((unsigned long long)ohi << 32) | olo;
+            if (off + n > arenaCap) S.status = LCB_ST_ARENA_OVF;
+            else for (uint32_t e = S.lane; e < n; e += 64) arena[off + e] = S.best[e];
+        }
+        uint64_t c[6];
+        if (STATS) {
+            c[0] = (uint64_t)lcb_wave_sum((int64_t)S.cWalk); c[1] = (uint64_t)lcb_wave_sum((int64_t)S.cOcc);
+            c[2] = (uint64_t)lcb_wave_sum((int64_t)S.cCompatCall); c[3] = (uint64_t)lcb_wave_sum((int64_t)S.cCompatStep);
+            c[4] = (uint64_t)lcb_wave_sum((int64_t)S.cVote); c[5] = (uint64_t)lcb_wave_sum((int64_t)S.cPush);
+        }
+        if (S.lane == 0) {
+            LcbSeedOut o;
+            o.nInst = n;   // kept on ARENA_OVF so the host can track the allocator
+            o.status = S.status; o.bestScore = bestScore; o.arenaOff = off;
+            for (int q = 0; q < 8; q++) o.ctr[q] = 0;
+            if (STATS) { o.ctr[0] = c[0]; o.ctr[1] = c[1]; o.ctr[2] = c[2]; o.ctr[3] = c[3]; o.ctr[4] = o.nInst; o.ctr[5] = c[4]; o.ctr[6] = c[5]; o.ctr[7] = 1; }
+            out[s] = o;
+        }
+        LCB_MARK(S, 2, 6);
+    }
+    LCB_MARK(S, 0, 2);
+}
+
+#endif

@@ -1,0 +1,252 @@
+// emu_check — TEST-ONLY: runs the device code of lcb_kernel.h under the wavefront emulator and
+// checks it against the CPU oracle (oracle/lcb_oracle.c), seed by seed and end to end. It also
+// exercises the product's host code (graph.cpp, bundles.cpp, commit.cpp, output.cpp) without a GPU.
+//
+//   emu_check <graph.bin> <fasta> <k> <b> <m> <a> <mode> [outdir]
+//     mode = seeds-init   every seed against an all-unused table
+//            seeds-final  every seed against the oracle's final `used` state
+//            find         full phase loop through the product committer + GFF through output.cpp
+//            big          like seeds-init but through the global-memory ("big") kernel variant
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "emu_runtime.h"
+#include "lcb_host.h"
+#include "lcb_kernel.h"
+#include "../../oracle/lcb_oracle.h"
+
+extern "C" size_t orc_used_stride(void);
+
+static std::string g_err;
+void lcb_set_error(const std::string& m) { g_err = m; }
+extern "C" const char* lcb_last_error(void) { return g_err.c_str(); }
+
+namespace {
+
+struct Emu {
+    const lcb_graph* g;
+    lcb_params p;
+    std::vector<uint32_t> chrStart32, used;
+    LcbTables T;
+    LcbKParams KP;
+    bool big = false;
+    std::vector<uint8_t> slot;
+    LcbWork W;
+    uint32_t cursor[4] = {0, 0, 0, 0};
+    std::vector<LcbSeedOut> out;
+    std::vector<uint4> arena;
+    lcb_counters ctr{};
+
+    Emu(const lcb_graph* graph, const lcb_params& prm, bool bigMode) : g(graph), p(prm), big(bigMode)
+    {
+        chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
+        used.assign(g->nPos() / 32 + 2, 0);
+        T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
+        T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
+        T.occG = g->occG.data(); T.occChr = g->occChr.data(); T.used = used.data();
+        T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
+        KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
+        W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : LCB_IC_SMALL; W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
+        LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
+        slot.assign(L.total, 0);
+        int32_t* pk = (int32_t*)(slot.data() + L.pKeys);
+        for (uint32_t i = 0; i < W.pathCap; i++) pk[i] = LCB_EMPTY_KEY;
+        if (big) { int32_t* vk = (int32_t*)(slot.data() + L.vKey); for (uint32_t i = 0; i < W.voteCap; i++) vk[i] = LCB_EMPTY_KEY; }
+        W.base = slot.data(); W.slotBytes = L.total;
+        W.dbg = nullptr; W.cursor = &cursor[0]; W.arenaCursor = (unsigned long long*)&cursor[2];
+        arena.resize(1 << 20);
+    }
+
+    // runs the process kernel over seeds with ONE emulated wavefront (the work queue feeds it all seeds)
+    void run(const std::vector<LcbKSeed>& seeds)
+    {
+        out.assign(seeds.size(), LcbSeedOut{});
+        W.cursorBase = cursor[0];
+        W.arenaBase = *W.arenaCursor;
+        const LcbKSeed* sp = seeds.data();
+        const uint32_t n = (uint32_t)seeds.size();
+        if (big) emu_run_wave(0, [&]() { lcb_process_body<true, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size()); });
+        else emu_run_wave(0, [&]() { lcb_process_body<false, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size()); });
+        for (auto& o : out) {
+            ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
+            ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
+        }
+    }
+};
+
+int compareSeed(int64_t idx, const lcb_seed& sd, const LcbSeedOut& o, const uint4* arena, const orc_inst* ref, int64_t nRef, int64_t refScore)
+{
+    bool ok = o.status == 0 && (int64_t)o.nInst == nRef && o.bestScore == refScore;
+    for (int64_t i = 0; ok && i < nRef; i++) {
+        const uint4 r = arena[o.arenaOff + i];
+        ok = r.x == ref[i].chr && r.y == ref[i].front_idx && r.z == ref[i].back_idx && (r.w != 0) == (ref[i].positive != 0);
+    }
+    if (!ok) {
+        fprintf(stderr, "MISMATCH seed %lld vid=%d ch=%c: kernel status=%u n=%u score=%lld | oracle n=%lld score=%lld\n", (long long)idx, sd.vid,
+                (char)sd.ch, o.status, o.nInst, (long long)o.bestScore, (long long)nRef, (long long)refScore);
+        for (int64_t i = 0; i < nRef || i < (int64_t)o.nInst; i++) {
+            if (i < (int64_t)o.nInst && o.status == 0) { const uint4 r = arena[o.arenaOff + i]; fprintf(stderr, "   K %c,%u,%u,%u", r.w ? '+' : '-', r.x, r.y, r.z); }
+            else fprintf(stderr, "   K -");
+            if (i < nRef) fprintf(stderr, "   | O %c,%u,%u,%u\n", ref[i].positive ? '+' : '-', ref[i].chr, ref[i].front_idx, ref[i].back_idx);
+            else fprintf(stderr, "   | O -\n");
+            if (i > 12) break;
+        }
+    }
+    return ok ? 0 : 1;
+}
+
+struct FindCtx { Emu* emu; lcb_committer* com; };
+
+int redoEmu(void* user, const lcb_seed* seed, lcb_instance* outInst, uint64_t cap, uint64_t* nOut)
+{
+    FindCtx* c = (FindCtx*)user;
+    // live state: the committer's bitmap IS the state
+    c->emu->used = c->com->used;
+    c->emu->T.used = c->emu->used.data();
+    c->com->marks.clear();
+    std::vector<LcbKSeed> one{LcbKSeed{seed->vid, seed->ch}};
+    c->emu->run(one);
+    const LcbSeedOut& o = c->emu->out[0];
+    if (o.status) { lcb_set_error("emulated kernel overflow"); return -1; }
+    *nOut = o.nInst;
+    for (uint32_t i = 0; i < o.nInst && i < cap; i++) {
+        const uint4 r = c->emu->arena[o.arenaOff + i];
+        outInst[i] = lcb_instance{r.x, r.y, r.z, r.w};
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 8) { fprintf(stderr, "usage: emu_check graph fasta k b m a mode [outdir]\n"); return 2; }
+    const char* graph = argv[1]; const char* fasta = argv[2];
+    lcb_params p; p.k = atoi(argv[3]); p.max_branch = p.max_flank = atoi(argv[4]); p.min_block = atoi(argv[5]); p.looking_depth = 8; p.phase_size = 256;
+    const int a = atoi(argv[6]);
+    const std::string mode = argv[7];
+    const std::string outDir = argc > 8 ? argv[8] : "/tmp/emu_out";
+    try {
+        lcb_graph* g = lcb_graph_load_impl(graph, {fasta}, p.k, a, 4);
+        std::vector<lcb_seed> seeds;
+        lcb_enumerate_seeds_impl(*g, 4, seeds);
+        char err[512];
+        const char* fa[1] = {fasta};
+        orc_graph* og = orc_load(graph, fa, 1, p.k, a, err, sizeof(err));
+        if (!og) { fprintf(stderr, "oracle load: %s\n", err); return 1; }
+        orc_params op{p.k, p.min_block, p.max_branch, p.max_flank, p.looking_depth};
+        const int64_t S = orc_build_bundles(og);
+        int bad = 0;
+        if (S != (int64_t)seeds.size()) { fprintf(stderr, "seed count differs: %lld vs %zu\n", (long long)S, seeds.size()); bad++; }
+        for (int64_t i = 0; i < S && i < (int64_t)seeds.size(); i++) {
+            int64_t vid; int32_t ch; uint64_t cnt, rank, rp, rc;
+            orc_get_bundle(og, i, &vid, &ch, &cnt, &rank, &rp, &rc);
+            const lcb_seed& s = seeds[i];
+            if (s.vid != vid || s.ch != ch || s.count != cnt || s.rank != rank || s.resolve_pos != rp || s.resolve_chr != rc) {
+                if (bad < 5) fprintf(stderr, "seed %lld differs: product (%d,%d,%llu) oracle (%lld,%d,%llu)\n", (long long)i, s.vid, s.ch,
+                                     (unsigned long long)s.count, (long long)vid, ch, (unsigned long long)cnt);
+                bad++;
+            }
+        }
+        if (bad) { fprintf(stderr, "FAIL: seed lists differ (%d)\n", bad); return 1; }
+        // table parity (flat SoA vs the oracle's per-chromosome arrays)
+        for (int64_t c = 0; c < orc_n_chr(og); c++) {
+            std::vector<int32_t> id(orc_chr_n_pos(og, c)); std::vector<uint32_t> pos(id.size());
+            orc_chr_positions(og, c, id.data(), pos.data());
+            if ((int64_t)(g->chrStart[c + 1] - g->chrStart[c]) != (int64_t)id.size()) { fprintf(stderr, "FAIL: chr %lld size\n", (long long)c); return 1; }
+            for (size_t i = 0; i < id.size(); i++)
+                if (g->posId[g->chrStart[c] + i] != id[i] || g->posPos[g->chrStart[c] + i] != pos[i]) { fprintf(stderr, "FAIL: table differs\n"); return 1; }
+        }
+        Emu emu(g, p, mode == "big");
+        if (mode == "seeds-init" || mode == "seeds-final" || mode == "big") {
+            orc_counters octr; memset(&octr, 0, sizeof(octr));
+            if (mode == "seeds-final") {
+                orc_block* ob = nullptr; orc_stats st;
+                orc_find_blocks(og, &op, &ob, &st, nullptr);
+                orc_free_blocks(ob);
+                const size_t stride = orc_used_stride();
+                for (int64_t c = 0; c < orc_n_chr(og); c++) {
+                    const uint8_t* u = orc_chr_used(og, c);
+                    for (int64_t i = 0; i < orc_chr_n_pos(og, c); i++)
+                        if (u[(size_t)i * stride]) { const uint64_t q = g->chrStart[c] + i; emu.used[q >> 5] |= 1u << (q & 31); }
+                }
+            }
+            if (getenv("EMU_ONLY")) { const lcb_seed one = seeds[atoi(getenv("EMU_ONLY"))]; seeds.assign(1, one); }
+            std::vector<LcbKSeed> ks;
+            for (auto& s : seeds) ks.push_back(LcbKSeed{s.vid, s.ch});
+            emu.run(ks);
+            std::vector<orc_inst> ref(1 << 16);
+            for (size_t i = 0; i < seeds.size(); i++) {
+                int64_t score = 0;
+                const int64_t n = orc_process_seed(og, &op, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &score, &octr);
+                bad += compareSeed((int64_t)i, seeds[i], emu.out[i], emu.arena.data(), ref.data(), n, score);
+                {
+                    static orc_counters prev; static int shown = 0;
+                    const uint64_t dc = octr.n_compat_call - prev.n_compat_call, ds = octr.n_compat_step - prev.n_compat_step;
+                    if ((dc != emu.out[i].ctr[2] || ds != emu.out[i].ctr[3]) && shown < 5 && getenv("EMU_CTR_DEBUG")) {
+                        shown++;
+                        fprintf(stderr, "ctr seed %zu vid=%d ch=%c: kernel ccall=%llu cstep=%llu | oracle ccall=%llu cstep=%llu (occ k=%llu o=%llu)\n", i, seeds[i].vid,
+                                (char)seeds[i].ch, (unsigned long long)emu.out[i].ctr[2], (unsigned long long)emu.out[i].ctr[3], (unsigned long long)dc,
+                                (unsigned long long)ds, (unsigned long long)emu.out[i].ctr[1], (unsigned long long)(octr.n_occ - prev.n_occ));
+                    }
+                    prev = octr;
+                }
+                if (bad > 8) break;
+            }
+            fprintf(stderr, "%s: %zu seeds, %d mismatches, %llu cross-lane ops\n", mode.c_str(), seeds.size(), bad, (unsigned long long)emu_collective_count());
+            fprintf(stderr, "counters kernel: walk=%llu occ=%llu ccall=%llu cstep=%llu inst=%llu vote=%llu push=%llu\n", (unsigned long long)emu.ctr.n_walk,
+                    (unsigned long long)emu.ctr.n_occ, (unsigned long long)emu.ctr.n_compat_call, (unsigned long long)emu.ctr.n_compat_step,
+                    (unsigned long long)emu.ctr.n_inst_out, (unsigned long long)emu.ctr.n_vote, (unsigned long long)emu.ctr.n_push);
+            fprintf(stderr, "counters oracle: walk=%llu occ=%llu ccall=%llu cstep=%llu inst=%llu vote=%llu push=%llu\n", (unsigned long long)octr.n_walk,
+                    (unsigned long long)octr.n_occ, (unsigned long long)octr.n_compat_call, (unsigned long long)octr.n_compat_step,
+                    (unsigned long long)octr.n_inst_out, (unsigned long long)octr.n_vote, (unsigned long long)octr.n_push);
+            if (!bad && (emu.ctr.n_walk != octr.n_walk || emu.ctr.n_occ != octr.n_occ || emu.ctr.n_compat_call != octr.n_compat_call ||
+                         emu.ctr.n_compat_step != octr.n_compat_step || emu.ctr.n_inst_out != octr.n_inst_out)) { fprintf(stderr, "FAIL: event counters differ\n"); bad++; }
+        } else if (mode == "find") {
+            lcb_committer com(g, p);
+            FindCtx ctx{&emu, &com};
+            for (size_t at = 0; at < seeds.size(); at += 256) {
+                const size_t n = seeds.size() - at < 256 ? seeds.size() - at : 256;
+                std::vector<LcbKSeed> ks;
+                for (size_t i = 0; i < n; i++) ks.push_back(LcbKSeed{seeds[at + i].vid, seeds[at + i].ch});
+                emu.used = com.used; emu.T.used = emu.used.data(); com.marks.clear();
+                emu.run(ks);
+                std::vector<uint64_t> off(n + 1, 0);
+                std::vector<lcb_instance> inst;
+                for (size_t i = 0; i < n; i++) {
+                    const LcbSeedOut& o = emu.out[i];
+                    if (o.status) { fprintf(stderr, "FAIL: overflow status %u\n", o.status); return 1; }
+                    off[i] = inst.size();
+                    for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu.arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
+                }
+                off[n] = inst.size();
+                com.commitPhase(seeds.data() + at, (int64_t)n, off.data(), inst.data(), redoEmu, &ctx);
+            }
+            orc_block* ob = nullptr; orc_stats st;
+            const int64_t nb = orc_find_blocks(og, &op, &ob, &st, nullptr);
+            if (nb != (int64_t)com.blocks.size() || st.blocks_found != com.blocksFound || st.failures != com.failures) {
+                fprintf(stderr, "FAIL: blocks %zu/%lld found %lld/%lld failures %lld/%lld\n", com.blocks.size(), (long long)nb, (long long)com.blocksFound,
+                        (long long)st.blocks_found, (long long)com.failures, (long long)st.failures);
+                bad++;
+            }
+            for (int64_t i = 0; i < nb && i < (int64_t)com.blocks.size(); i++)
+                if (ob[i].id != com.blocks[i].id || ob[i].chr != com.blocks[i].chr || ob[i].start != com.blocks[i].start || ob[i].end != com.blocks[i].end) { bad++; }
+            int64_t nTrim = 0; double cov = 0;
+            lcb_generate_output_impl(*g, p.min_block, com.blocks.data(), (int64_t)com.blocks.size(), com.blocksFound, outDir, false, 0, &nTrim, &cov);
+            double ocov = 0;
+            const std::string od2 = outDir + "_oracle";
+            const int64_t ont = orc_generate_output(og, p.min_block, ob, nb, st.blocks_found, od2.c_str(), &ocov, err, sizeof(err));
+            if (ont != nTrim) { fprintf(stderr, "FAIL: trimmed %lld vs %lld\n", (long long)nTrim, (long long)ont); bad++; }
+            fprintf(stderr, "find: %zu seeds, %lld blocks (%lld trimmed), failures %lld, diffs %d\n", seeds.size(), (long long)com.blocksFound, (long long)nTrim,
+                    (long long)com.failures, bad);
+            printf("Blocks found: %lld\nCoverage: %.2f\n", (long long)nTrim, cov);
+        } else { fprintf(stderr, "unknown mode\n"); return 2; }
+        return bad ? 1 : 0;
+    } catch (std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

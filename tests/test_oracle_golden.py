@@ -5,7 +5,7 @@ import hashlib
 import os
 import subprocess
 
-from conftest import ROOT
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def sha(path):
