@@ -80,6 +80,12 @@ typedef struct {
     int64_t big_retries;    /* seeds re-run with global-memory workspaces after an LDS capacity overflow */
     double kernel_ms;       /* sum of hipEvent-timed kernel durations on the device's stream */
     double wall_ms;         /* wall time of the phase loop */
+    int64_t rounds;             /* speculative multi-phase launches */
+    int64_t recompute_launches; /* per-phase launches that recomputed seeds invalidated by earlier commits of the round */
+    int64_t recomputed_seeds;
+    int64_t conflict_launches;  /* batched re-process launches (blocksfinder.h:406-411) */
+    int64_t conflict_seeds;
+    int64_t exchanges;          /* all-gathers (multi-rank) */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -149,6 +155,29 @@ const uint32_t* lcb_committer_used_words(const lcb_committer* c, int64_t* n_word
  * commit. *blocks is malloc'ed (pre-trim blocksInstance_ in commit order); free with lcb_free. */
 int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                     int progress, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
+
+/* ---- the same with hooks: multi-rank operation and/or a caller-supplied per-seed engine.
+ * rank/world + allgather: the round's seeds are dealt round-robin to the ranks, per-seed results and footprints are
+ * all-gathered (the callback gathers a fixed-size buffer: recv holds world * bytes), every rank commits identically.
+ * If dev is NULL the process/mark/reset callbacks stand in for the device (used by the CPU tests of this logic). */
+typedef int (*lcb_allgather_cb)(void* user, const void* send, uint64_t bytes, void* recv);
+typedef int (*lcb_process_cb)(void* user, const lcb_seed* seeds, int64_t n, uint64_t* offsets /* n+1 */, lcb_instance* inst,
+                              uint64_t inst_cap);   /* returns 0, or 1 with the needed capacity in offsets[n] */
+typedef int (*lcb_mark_cb)(void* user, const uint64_t* ranges, int64_t n);
+typedef int (*lcb_reset_cb)(void* user);
+typedef struct {
+    int32_t rank, world;
+    lcb_allgather_cb allgather;
+    void* allgather_user;
+    lcb_process_cb process;     /* only when dev == NULL */
+    lcb_mark_cb mark;
+    lcb_reset_cb reset;
+    void* engine_user;
+    int32_t round_phases;       /* phases per speculative round; 0 = default (LCB_ROUND_PHASES or 64) */
+    int32_t progress;
+} lcb_hooks;
+int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
+                       const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
 
 /* ---- GenerateOutput (blocksfinder.h:605-670): trimming, blocks_coords.gff (blocksfinder.cpp:141-174) and,
  * if gen_seq, the <out_dir>/<i>.tmp chunk files (blocksfinder.h:533-582). */

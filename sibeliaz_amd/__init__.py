@@ -6,4 +6,4 @@ the tests, `bench.py` and the multi-GPU driver; names mirror the reference class
 (JunctionStorage, BlocksFinder).
 """
 from .api import (LcbError, JunctionStorage, Device, Committer, BlocksFinder, Params, load_library, lib_path,  # noqa: F401
-                  SEED_DTYPE, INSTANCE_DTYPE, BLOCK_DTYPE)
+                  SEED_DTYPE, INSTANCE_DTYPE, BLOCK_DTYPE, Hooks)

@@ -33,7 +33,21 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("seeds", C.c_int64), ("blocks_found", C.c_int64), ("failures", C.c_int64), ("launches", C.c_int64),
-                ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double)]
+                ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
+                ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
+                ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64)]
+
+
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+PROCESS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64)
+MARK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+RESET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class Hooks(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allgather", ALLGATHER_CB), ("allgather_user", C.c_void_p),
+                ("process", PROCESS_CB), ("mark", MARK_CB), ("reset", RESET_CB), ("engine_user", C.c_void_p),
+                ("round_phases", C.c_int32), ("progress", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -53,7 +67,8 @@ EXPORTS = [
     "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
     "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
-    "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_generate_output",
+    "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
+    "lcb_generate_output",
 ]
 
 
@@ -114,6 +129,7 @@ def load_library():
     L.lcb_committer_used_words.restype = vp
     L.lcb_committer_used_words.argtypes = [vp, C.POINTER(i64)]
     L.lcb_find_blocks.argtypes = [vp, vp, C.POINTER(Params), vp, i64, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
+    L.lcb_find_blocks_ex.argtypes = [vp, vp, C.POINTER(Params), vp, i64, C.POINTER(Hooks), C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
     L.lcb_generate_output.argtypes = [vp, i64, vp, i64, i64, C.c_char_p, C.c_int, i64, C.POINTER(i64), C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -326,15 +342,18 @@ class BlocksFinder:
         self.params = None
 
     def FindBlocks(self, minBlockSize, maxBranchSize, maxFlankingSize=None, lookingDepth=8, sampleSize=0, threads=1, device=None,
-                   seeds=None):
+                   seeds=None, hooks=None):
+        """hooks: an api.Hooks (multi-rank all-gather and/or callback engine); device may be None only with callback hooks."""
         p = Params(self.k, minBlockSize, maxBranchSize, maxBranchSize if maxFlankingSize is None else maxFlankingSize, lookingDepth, 256)
         self.params = p
-        own = device is None
+        callback_engine = hooks is not None and bool(hooks.process)
+        own = device is None and not callback_engine
         dev = Device(self.storage, p) if own else device
         try:
             s = self.storage.seeds(threads) if seeds is None else np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
             out, n, st = C.c_void_p(), C.c_int64(), Stats()
-            rc = self.L.lcb_find_blocks(self.storage.h, dev.h, C.byref(p), s.ctypes.data, len(s), 0, C.byref(out), C.byref(n), C.byref(st))
+            rc = self.L.lcb_find_blocks_ex(self.storage.h, dev.h if dev is not None else None, C.byref(p), s.ctypes.data, len(s),
+                                           C.byref(hooks) if hooks is not None else None, C.byref(out), C.byref(n), C.byref(st))
             if rc:
                 raise _err(self.L)
             self.blocks = _np_from(out.value, n.value, BLOCK_DTYPE)

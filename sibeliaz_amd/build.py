@@ -21,7 +21,7 @@ BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libsibeliaz_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-LIB_SRC = ["graph.cpp", "bundles.cpp", "commit.cpp", "output.cpp", "capi.cpp", "device.hip"]
+LIB_SRC = ["graph.cpp", "bundles.cpp", "commit.cpp", "engine.cpp", "output.cpp", "capi.cpp", "device.hip"]
 LIB_HDR = ["lcb_host.h", "lcb_kernel.h", "lcb_device.h"]
 
 

@@ -119,12 +119,74 @@ const uint32_t* lcb_committer_used_words(const lcb_committer* c, int64_t* n_word
     return c->used.data();
 }
 
+namespace {
+// A per-seed engine supplied by the caller through C callbacks (no footprints: one all-covering interval per seed, so
+// every speculative result is conservatively re-computed after any commit).
+struct CallbackProcessor : LcbProcessor {
+    const lcb_hooks* h;
+    explicit CallbackProcessor(const lcb_hooks* hooks) : h(hooks) {}
+    void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        off.assign((size_t)n + 1, 0);
+        uint64_t cap = inst.size() < 4096 ? 4096 : inst.size();
+        for (;;) {
+            inst.resize(cap);
+            const int rc = n ? h->process(h->engine_user, seeds, n, off.data(), inst.data(), cap) : 0;
+            if (rc == 0) break;
+            if (rc == 1 && off[(size_t)n] > cap) { cap = off[(size_t)n]; continue; }
+            throw LcbError("process callback failed");
+        }
+        inst.resize(off[(size_t)n]);
+        fpOff.resize((size_t)n + 1);
+        fp.assign((size_t)n, lcb_fp{0u, UINT32_MAX});
+        for (int64_t i = 0; i <= n; i++) fpOff[(size_t)i] = (uint64_t)i;
+    }
+    void mark(const uint64_t* ranges, int64_t n) override { if (h->mark(h->engine_user, ranges, n)) throw LcbError("mark callback failed"); }
+    void reset() override { if (h->reset(h->engine_user)) throw LcbError("reset callback failed"); }
+};
+}  // namespace
+
+int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
+                       const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
+{
+    LCB_TRY
+    LcbEngineConfig cfg;
+    if (hooks) {
+        cfg.rank = hooks->rank; cfg.world = hooks->world > 0 ? hooks->world : 1;
+        cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
+        cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
+    }
+    std::vector<lcb_block> v;
+    if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
+    else {
+        if (!hooks || !hooks->process || !hooks->mark || !hooks->reset) throw LcbError("lcb_find_blocks_ex: no device and no engine callbacks");
+        CallbackProcessor proc(hooks);
+        LcbEngineStats es;
+        lcb_engine_run(g, p, seeds, n_seeds, proc, cfg, v, &es);
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->seeds = n_seeds; stats->blocks_found = es.blocksFound; stats->failures = es.failures; stats->wall_ms = es.wallMs;
+            stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
+            stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
+        }
+    }
+    *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));
+    if (!*blocks) throw LcbError("out of memory");
+    if (!v.empty()) memcpy(*blocks, v.data(), v.size() * sizeof(lcb_block));
+    *n_blocks = (int64_t)v.size();
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
 int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds, int progress,
                     lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
 {
     LCB_TRY
     std::vector<lcb_block> v;
-    lcb_find_blocks_impl(g, d, p, seeds, n_seeds, progress != 0, v, stats);
+    LcbEngineConfig cfg;
+    cfg.progress = progress != 0;
+    lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));
     if (!*blocks) throw LcbError("out of memory");
     if (!v.empty()) memcpy(*blocks, v.data(), v.size() * sizeof(lcb_block));

@@ -52,6 +52,24 @@ void lcb_committer::finalize(const lcb_instance* inst, uint64_t n)              
     }
 }
 
+bool lcb_committer::conflicts(const lcb_instance* r, uint64_t cnt) const                  // blocksfinder.h:377-398
+{
+    for (uint64_t i = 0; i < cnt; i++) {
+        if (!invalidChr[r[i].chr]) continue;
+        const uint64_t base = g->chrStart[r[i].chr];
+        const uint64_t lo = base + (r[i].front_idx < r[i].back_idx ? r[i].front_idx : r[i].back_idx);
+        const uint64_t hi = base + (r[i].front_idx < r[i].back_idx ? r[i].back_idx : r[i].front_idx);
+        if (anyUsed(lo, hi)) return true;
+    }
+    return false;
+}
+
+void lcb_committer::endPhase()                                                           // blocksfinder.h:416
+{
+    for (uint32_t c : invalidList) invalidChr[c] = 0;
+    invalidList.clear();
+}
+
 void lcb_committer::commitPhase(const lcb_seed* seeds, int64_t n, const uint64_t* offsets, const lcb_instance* inst,
                                 lcb_reprocess_fn fn, void* user)
 {
@@ -60,14 +78,7 @@ void lcb_committer::commitPhase(const lcb_seed* seeds, int64_t n, const uint64_t
         const uint64_t cnt = offsets[s + 1] - offsets[s];
         if (cnt <= 1) continue;                                                          // blocksfinder.h:375
         const lcb_instance* r = inst + offsets[s];
-        bool isGood = true;
-        for (uint64_t i = 0; i < cnt && isGood; i++) {                                   // blocksfinder.h:377-398
-            if (!invalidChr[r[i].chr]) continue;
-            const uint64_t base = g->chrStart[r[i].chr];
-            const uint64_t lo = base + (r[i].front_idx < r[i].back_idx ? r[i].front_idx : r[i].back_idx);
-            const uint64_t hi = base + (r[i].front_idx < r[i].back_idx ? r[i].back_idx : r[i].front_idx);
-            if (anyUsed(lo, hi)) isGood = false;
-        }
+        const bool isGood = !conflicts(r, cnt);
         if (isGood) finalize(r, cnt);
         else {                                                                           // blocksfinder.h:404-412
             failures++;
@@ -83,6 +94,5 @@ void lcb_committer::commitPhase(const lcb_seed* seeds, int64_t n, const uint64_t
             if (got > 1) finalize(redo.data(), got);
         }
     }
-    for (uint32_t c : invalidList) invalidChr[c] = 0;                                    // blocksfinder.h:416
-    invalidList.clear();
+    endPhase();
 }

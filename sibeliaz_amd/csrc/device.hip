@@ -16,6 +16,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lcb_device.h"
@@ -27,11 +28,13 @@
         if (e_ != hipSuccess) throw LcbError(std::string(#x) + " failed: " + hipGetErrorString(e_)); \
     } while (0)
 
-template <bool BIG, bool STATS>
+// MODE 0/1/2 = small / medium / big (lcb_kernel.h): where the per-path instance pool and vote table live.
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(64) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
-                                                         LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap)
+                                                         LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
+                                                         uint2* fpArena, unsigned long long fpCap)
 {
-    lcb_process_body<BIG, STATS>(T, P, seeds, nSeeds, W, out, arena, arenaCap);
+    lcb_process_body<MODE, STATS>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -70,7 +73,8 @@ struct WorkSet {
     uint8_t* base = nullptr;
     uint64_t slotBytes = 0;
     uint32_t nSlots = 0, pathCap = 0, bodyCap = 0, bestCap = 0, instCap = 0, voteCap = 0;
-    bool big = false;
+    int mode = 0;          // 0 small, 1 medium, 2 big
+    bool big = false;      // mode == 2: instance pool and vote table in the workspace
 };
 
 uint32_t envU32(const char* name, uint32_t dflt)
@@ -92,22 +96,30 @@ struct lcb_device_impl {
     std::vector<void*> owned;
     uint32_t* dUsed = nullptr;
     size_t usedWords = 0;
-    uint32_t* dCursor = nullptr;                 // [0] work tickets, [2..3] arena allocator (u64)
+    uint32_t* dCursor = nullptr;                 // [0] work tickets, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t cursorBase = 0;
     unsigned long long arenaBase = 0;
-    WorkSet small, big;
+    WorkSet small, medium, big;
     // pinned, device-mapped host buffers
     LcbKSeed* hSeeds = nullptr;
     LcbSeedOut* hOut = nullptr;
     uint4* hArena = nullptr;
+    uint2* hFp = nullptr;                        // footprint arena (pinned)
+    unsigned long long fpCap = 0, fpBase = 0;
     uint64_t* hRanges = nullptr;
     uint32_t* hDbg = nullptr;                    // flight recorder (LCB_DEBUG=1): 16 words per workgroup
     uint32_t dbgSlots = 0;
+    bool seedTrace = false;                      // LCB_TRACE_SEEDS=1: add per-seed profile lines to the launch trace
+    FILE* traceFile = nullptr;                   // LCB_TRACE_LAUNCHES=<file>: one line per launch (seeds, grid, mode, ms)
     double watchdogS = 0;                        // LCB_WATCHDOG_S: abort a launch that runs longer (0 = wait forever)
     uint32_t batchCap = 0;
     unsigned long long arenaCap = 0;
     uint32_t rangeCap = 0;
     bool stats = false;
+    bool wantFp = false;                         // emit footprints (speculative engine)
+    // seeds that overflowed the LDS capacities before: (vid, ch) -> kernel mode to start with next time, so that a
+    // recomputation does not repeat the doomed small-mode attempt
+    std::unordered_map<uint64_t, uint8_t> modeHint;
     double kernelMs = 0;
     int64_t launches = 0, bigRetries = 0;
 
@@ -138,8 +150,10 @@ struct lcb_device_impl {
     void allocArena(unsigned long long cap)
     {
         if (hArena) HIP_CHECK(hipHostFree(hArena));
-        arenaCap = cap;
+        if (hFp) HIP_CHECK(hipHostFree(hFp));
+        arenaCap = cap; fpCap = cap;
         HIP_CHECK(hipHostMalloc((void**)&hArena, (size_t)cap * sizeof(uint4), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&hFp, (size_t)cap * sizeof(uint2), hipHostMallocDefault));
     }
 
     // One launch over hSeeds[0..m): returns after the stream has drained.
@@ -150,17 +164,16 @@ struct lcb_device_impl {
         W.instCap = w.instCap; W.voteCap = w.voteCap;
         W.cursor = dCursor; W.cursorBase = cursorBase;
         W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = arenaBase;
+        W.fpCursor = (unsigned long long*)(dCursor + 4); W.fpBase = fpBase;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         HIP_CHECK(hipEventRecord(ev0, stream));
-        if (w.big) {
-            if (stats) hipLaunchKernelGGL((lcb_process_kernel<true, true>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
-            else hipLaunchKernelGGL((lcb_process_kernel<true, false>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
-        } else {
-            if (stats) hipLaunchKernelGGL((lcb_process_kernel<false, true>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
-            else hipLaunchKernelGGL((lcb_process_kernel<false, false>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap);
-        }
+#define LCB_LAUNCH(MODE, ST) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
+        if (w.mode == 2) { if (stats) LCB_LAUNCH(2, true); else LCB_LAUNCH(2, false); }
+        else if (w.mode == 1) { if (stats) LCB_LAUNCH(1, true); else LCB_LAUNCH(1, false); }
+        else { if (stats) LCB_LAUNCH(0, true); else LCB_LAUNCH(0, false); }
+#undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ev1, stream));
         if (watchdogS > 0) {
@@ -172,7 +185,7 @@ struct lcb_device_impl {
                 if (q != hipErrorNotReady) HIP_CHECK(q);
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (el > watchdogS) {
-                    fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, w.big ? "big" : "small", grid, el);
+                    fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, w.mode == 2 ? "big" : (w.mode == 1 ? "medium" : "small"), grid, el);
                     if (W.dbg) {
                         int shown = 0;
                         for (uint32_t b = 0; b < grid && shown < 8; b++) {
@@ -193,8 +206,17 @@ struct lcb_device_impl {
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         kernelMs += ms;
         launches++;
+        if (traceFile) {
+            fprintf(traceFile, "%lld\t%u\t%u\t%s\t%.4f\n", (long long)launches, m, grid, w.mode == 2 ? "big" : (w.mode == 1 ? "medium" : "small"), ms);
+            if (!stats && seedTrace)          // per-seed profile of the slowest seeds of the launch (ticks are 10 ns)
+                for (uint32_t i = 0; i < m; i++)
+                    if (hOut[i].ctr[0] > 2000) fprintf(traceFile, "#seed\t%lld\t%u\t%d\tst=%u\tn=%u\tticks=%llu\tpush=%llu\tvote=%llu\tprobe=%llu\tinst=%llu\ttv=%llu\ttp=%llu\tts=%llu\n", (long long)launches, i, hSeeds[i].vid,
+                            hOut[i].status, hOut[i].nInst, (unsigned long long)hOut[i].ctr[0], (unsigned long long)hOut[i].ctr[1], (unsigned long long)hOut[i].ctr[2],
+                            (unsigned long long)hOut[i].ctr[3], (unsigned long long)hOut[i].ctr[4], (unsigned long long)hOut[i].ctr[5], (unsigned long long)hOut[i].ctr[6],
+                            (unsigned long long)hOut[i].ctr[7]);
+        }
         cursorBase += m + grid;                    // every workgroup consumed exactly one ticket past the end
-        for (uint32_t i = 0; i < m; i++) arenaBase += hOut[i].nInst;
+        for (uint32_t i = 0; i < m; i++) { arenaBase += hOut[i].nInst; fpBase += hOut[i].nFp; }
     }
 };
 
@@ -220,8 +242,14 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->T.posCh = d->upload(g->posCh.data(), P);
         d->T.posRevCh = d->upload(g->posRevCh.data(), P);
         d->T.occStart = d->upload(g->occStart.data(), g->occStart.size());
-        d->T.occG = d->upload(g->occG.data(), P);
-        d->T.occChr = d->upload(g->occChr.data(), P);
+        {
+            std::vector<uint4> rec((size_t)P);
+            for (uint64_t j = 0; j < P; j++) {
+                const uint32_t q = g->occG[j];
+                rec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]};
+            }
+            d->T.occRec = d->upload(rec.data(), rec.size());
+        }
         d->usedWords = (size_t)(P / 32 + 2);
         HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
@@ -229,24 +257,34 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
-        HIP_CHECK(hipMalloc((void**)&d->dCursor, 16));
-        HIP_CHECK(hipMemset(d->dCursor, 0, 16));
+        HIP_CHECK(hipMalloc((void**)&d->dCursor, 32));
+        HIP_CHECK(hipMemset(d->dCursor, 0, 32));
         // small (LDS) mode: instances / vote table in LDS, path set + bodies + snapshot in a 1/4-MB global slot
-        d->small.big = false; d->small.nSlots = envU32("LCB_SLOTS", 1024);
+        d->small.big = false; d->small.mode = 0; d->small.nSlots = envU32("LCB_SLOTS", 1024);
         d->small.pathCap = envU32("LCB_PATH_CAP", 32768); d->small.bodyCap = d->small.pathCap / 2; d->small.bestCap = LCB_IC_SMALL;
         d->allocWork(d->small);
+        // medium mode: 4x the LDS capacities, one workgroup per CU
+        d->medium.big = false; d->medium.mode = 1; d->medium.nSlots = envU32("LCB_MEDIUM_SLOTS", 256);
+        d->medium.pathCap = d->small.pathCap < 131072 ? 131072 : d->small.pathCap; d->medium.bodyCap = d->medium.pathCap / 2; d->medium.bestCap = LCB_IC_MEDIUM;
+        if (envU32("LCB_FORCE_BIG", 0)) { d->medium.pathCap = d->small.pathCap; d->medium.bodyCap = d->small.bodyCap; }
+        d->allocWork(d->medium);
         // big (global-memory) mode for seeds that overflow the LDS capacities; grows on demand
-        d->big.big = true; d->big.nSlots = envU32("LCB_BIG_SLOTS", 64);
+        d->big.big = true; d->big.mode = 2; d->big.nSlots = envU32("LCB_BIG_SLOTS", 64);
         d->big.pathCap = 262144; d->big.bodyCap = 131072; d->big.instCap = 4096; d->big.voteCap = 65536; d->big.bestCap = 4096;
         d->allocWork(d->big);
         d->batchCap = envU32("LCB_BATCH", 65536);
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         d->allocArena(1u << 20);
+        const char* tf = getenv("LCB_TRACE_LAUNCHES");
+        if (tf && *tf) d->traceFile = fopen(tf, "w");
+        d->seedTrace = envU32("LCB_TRACE_SEEDS", 0) != 0;
         const char* wd = getenv("LCB_WATCHDOG_S");
         d->watchdogS = wd && *wd ? atof(wd) : 0;
         if (envU32("LCB_DEBUG", 0)) {
-            d->dbgSlots = d->small.nSlots > d->big.nSlots ? d->small.nSlots : d->big.nSlots;
+            d->dbgSlots = d->small.nSlots;
+            if (d->medium.nSlots > d->dbgSlots) d->dbgSlots = d->medium.nSlots;
+            if (d->big.nSlots > d->dbgSlots) d->dbgSlots = d->big.nSlots;
             HIP_CHECK(hipHostMalloc((void**)&d->hDbg, (size_t)d->dbgSlots * 16 * sizeof(uint32_t), hipHostMallocDefault));
         }
         d->rangeCap = 65536;
@@ -269,12 +307,15 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->dUsed) (void)hipFree(d->dUsed);
         if (d->dCursor) (void)hipFree(d->dCursor);
         if (d->small.base) (void)hipFree(d->small.base);
+        if (d->medium.base) (void)hipFree(d->medium.base);
         if (d->big.base) (void)hipFree(d->big.base);
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
         if (d->hArena) (void)hipHostFree(d->hArena);
+        if (d->hFp) (void)hipHostFree(d->hFp);
         if (d->hRanges) (void)hipHostFree(d->hRanges);
         if (d->hDbg) (void)hipHostFree(d->hDbg);
+        if (d->traceFile) fclose(d->traceFile);
         if (d->ev0) (void)hipEventDestroy(d->ev0);
         if (d->ev1) (void)hipEventDestroy(d->ev1);
         if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -329,12 +370,21 @@ void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
-                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr)
+                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut)
 {
     lcb_device_impl* d = h->impl;
     d->use();
     offsets.assign((size_t)n + 1, 0);
     inst.clear();
+    d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
+    std::vector<std::vector<lcb_fp>> fps;               // per seed (only when footprints are wanted)
+    if (d->wantFp) fps.resize((size_t)n);
+    auto takeFp = [&](int64_t s, const LcbSeedOut& o) {
+        if (!d->wantFp) return;
+        fps[(size_t)s].resize(o.nFp);
+        for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = d->hFp[o.fpOff + e]; fps[(size_t)s][e] = lcb_fp{r.x, r.y}; }
+    };
     // per-seed results are gathered out of order (retries), then laid out in seed order
     std::vector<std::vector<lcb_instance>> late;        // results of retried seeds
     std::vector<int64_t> lateOf((size_t)n, -1);
@@ -346,14 +396,26 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         ctr->n_walk += o.ctr[0]; ctr->n_occ += o.ctr[1]; ctr->n_compat_call += o.ctr[2]; ctr->n_compat_step += o.ctr[3];
         ctr->n_inst_out += o.ctr[4]; ctr->n_vote += o.ctr[5]; ctr->n_push += o.ctr[6]; ctr->n_process += o.ctr[7];
     };
-    std::vector<int64_t> retry;                         // seeds that need the big workspaces / a bigger arena
-    for (int64_t base = 0; base < n; base += d->batchCap) {
-        const uint32_t m = (uint32_t)((n - base) < (int64_t)d->batchCap ? (n - base) : d->batchCap);
-        for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[base + i].vid; d->hSeeds[i].ch = seeds[base + i].ch; }
+    std::vector<int64_t> retry;                         // seeds that need larger workspaces (medium, then big)
+    std::vector<int64_t> retryBig;                      // seeds known to need the big workspaces
+    auto keyOf = [](const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; };
+    std::vector<int64_t> firstPass;
+    firstPass.reserve((size_t)n);
+    if (d->modeHint.empty()) for (int64_t s = 0; s < n; s++) firstPass.push_back(s);
+    else
+        for (int64_t s = 0; s < n; s++) {
+            auto it = d->modeHint.find(keyOf(seeds[s]));
+            if (it == d->modeHint.end()) firstPass.push_back(s);
+            else if (it->second == 1) retry.push_back(s);
+            else retryBig.push_back(s);
+        }
+    for (size_t base = 0; base < firstPass.size(); base += d->batchCap) {
+        const uint32_t m = (uint32_t)((firstPass.size() - base) < d->batchCap ? (firstPass.size() - base) : d->batchCap);
+        for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[firstPass[base + i]].vid; d->hSeeds[i].ch = seeds[firstPass[base + i]].ch; }
         d->launch(d->small, m);
         for (uint32_t i = 0; i < m; i++) {
             const LcbSeedOut& o = d->hOut[i];
-            const int64_t s = base + i;
+            const int64_t s = firstPass[base + i];
             if (o.status == LCB_ST_OK) {
                 cnt[(size_t)s] = o.nInst;
                 flatOff[(size_t)s] = flat.size();
@@ -362,21 +424,24 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                     flat.push_back(lcb_instance{r.x, r.y, r.z, r.w});
                 }
                 if (bestScore) bestScore[s] = o.bestScore;
+                takeFp(s, o);
                 addCtr(o);
             } else if (o.status == LCB_ST_DIST_OVF) {
                 throw LcbError("a path longer than 2^31 bp is not supported");
-            } else retry.push_back(s);
+            } else { retry.push_back(s); if (o.status != LCB_ST_ARENA_OVF) d->modeHint[keyOf(seeds[s])] = 1; }
         }
     }
-    // retries: big mode, growing the capacities while seeds keep overflowing
-    for (int round = 0; !retry.empty(); round++) {
-        if (round > 12) throw LcbError("a seed keeps overflowing the device workspaces");
+    // retries: medium mode (4x LDS capacities) first, then big mode, growing its capacities while seeds keep overflowing
+    for (int round = 0; !retry.empty() || !retryBig.empty(); round++) {
+        if (round > 13) throw LcbError("a seed keeps overflowing the device workspaces");
+        WorkSet& ws = round == 0 ? d->medium : d->big;
+        if (round == 1) { retry.insert(retry.end(), retryBig.begin(), retryBig.end()); retryBig.clear(); }
         std::vector<int64_t> again;
         for (size_t base = 0; base < retry.size(); base += d->batchCap) {
             const uint32_t m = (uint32_t)((retry.size() - base) < d->batchCap ? (retry.size() - base) : d->batchCap);
             for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[retry[base + i]].vid; d->hSeeds[i].ch = seeds[retry[base + i]].ch; }
-            d->bigRetries += m;
-            d->launch(d->big, m);
+            if (round > 0) d->bigRetries += m;
+            d->launch(ws, m);
             for (uint32_t i = 0; i < m; i++) {
                 const LcbSeedOut& o = d->hOut[i];
                 const int64_t s = retry[base + i];
@@ -389,16 +454,15 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                         late.back().push_back(lcb_instance{r.x, r.y, r.z, r.w});
                     }
                     if (bestScore) bestScore[s] = o.bestScore;
+                    takeFp(s, o);
                     addCtr(o);
                 } else if (o.status == LCB_ST_DIST_OVF) {
                     throw LcbError("a path longer than 2^31 bp is not supported");
-                } else again.push_back(s);
+                } else { again.push_back(s); if (o.status != LCB_ST_ARENA_OVF) d->modeHint[keyOf(seeds[s])] = 2; }
             }
         }
-        if (!again.empty()) {
-            bool arenaOnly = true;
+        if (!again.empty() && round > 0) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
-            (void)arenaOnly;
             d->allocArena(d->arenaCap * 4);
             d->big.pathCap *= 2; d->big.bodyCap *= 2; d->big.instCap *= 2; d->big.voteCap *= 2; d->big.bestCap *= 2;
             d->allocWork(d->big);
@@ -414,77 +478,51 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         const lcb_instance* src = lateOf[(size_t)s] >= 0 ? late[(size_t)lateOf[(size_t)s]].data() : flat.data() + flatOff[(size_t)s];
         memcpy(inst.data() + offsets[(size_t)s], src, (size_t)cnt[(size_t)s] * sizeof(lcb_instance));
     }
+    if (d->wantFp) {
+        fpOffsets->assign((size_t)n + 1, 0);
+        uint64_t tf = 0;
+        for (int64_t s = 0; s < n; s++) { (*fpOffsets)[(size_t)s] = tf; tf += fps[(size_t)s].size(); }
+        (*fpOffsets)[(size_t)n] = tf;
+        fpOut->resize((size_t)tf);
+        for (int64_t s = 0; s < n; s++)
+            if (!fps[(size_t)s].empty()) memcpy(fpOut->data() + (*fpOffsets)[(size_t)s], fps[(size_t)s].data(), fps[(size_t)s].size() * sizeof(lcb_fp));
+    }
+    d->wantFp = false;
 }
 
 namespace {
 
-struct RedoCtx {
+// The product's per-rank engine: the HIP kernels on one MI355X.
+struct DeviceProcessor : LcbProcessor {
     lcb_device* dev;
-    lcb_committer* com;
-    std::vector<uint64_t> off;
-    std::vector<lcb_instance> inst;
-    std::vector<uint64_t> marks;
-};
-
-void flushMarks(lcb_device* dev, lcb_committer* com, std::vector<uint64_t>& buf)
-{
-    if (com->marks.empty()) return;
-    buf.swap(com->marks);
-    com->marks.clear();
-    lcb_device_mark_used_impl(dev, buf.data(), (int64_t)(buf.size() / 2));
-}
-
-// Re-process of a seed whose speculative result conflicted (blocksfinder.h:406-411): bring the device's
-// `used` bitmap up to the live state, then run the seed again ON THE GPU.
-int redoOnDevice(void* user, const lcb_seed* seed, lcb_instance* out, uint64_t cap, uint64_t* nOut)
-{
-    RedoCtx* c = (RedoCtx*)user;
-    try {
-        flushMarks(c->dev, c->com, c->marks);
-        lcb_device_process_impl(c->dev, seed, 1, c->off, c->inst, nullptr, nullptr);
-        *nOut = c->inst.size();
-        if (c->inst.size() <= cap) memcpy(out, c->inst.data(), c->inst.size() * sizeof(lcb_instance));
-        return 0;
-    } catch (std::exception& e) {
-        lcb_set_error(e.what());
-        return -1;
+    explicit DeviceProcessor(lcb_device* d) : dev(d) {}
+    void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp);
     }
-}
+    void mark(const uint64_t* ranges, int64_t n) override { lcb_device_mark_used_impl(dev, ranges, n); }
+    void reset() override { lcb_device_reset_used_impl(dev); }
+};
 
 }  // namespace
 
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
-                          bool progress, std::vector<lcb_block>& blocks, lcb_stats* stats)
+                          const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, lcb_stats* stats)
 {
-    const auto t0 = std::chrono::steady_clock::now();
-    lcb_committer com(g, *p);
-    lcb_device_reset_used_impl(dev);
     double ms0 = 0; int64_t l0 = 0;
     lcb_device_kernel_time_impl(dev, &ms0, &l0);
     const int64_t retries0 = lcb_device_big_retries_impl(dev);
-    RedoCtx ctx{dev, &com, {}, {}, {}};
-    std::vector<uint64_t> offsets;
-    std::vector<lcb_instance> inst;
-    const int64_t phase = p->phase_size > 0 ? p->phase_size : 256;
-    int64_t portion = nSeeds / 50;                                                       // progressPortion_, blocksfinder.h:509-513
-    if (portion == 0) portion = 1;
-    if (progress) std::cout << '[' << std::flush;
-    for (int64_t at = 0; at < nSeeds; at += phase) {
-        const int64_t n = (nSeeds - at) < phase ? (nSeeds - at) : phase;
-        // every seed of the phase sees the `used` bits as of the start of the phase (blocksfinder.h:345-367)
-        lcb_device_process_impl(dev, seeds + at, n, offsets, inst, nullptr, nullptr);
-        if (progress)
-            for (int64_t i = at; i < at + n; i++) if (i % portion == 0) std::cout << '.' << std::flush;
-        com.commitPhase(seeds + at, n, offsets.data(), inst.data(), redoOnDevice, &ctx);
-        flushMarks(dev, &com, ctx.marks);
-    }
-    if (progress) std::cout << ']' << std::endl;
-    blocks = com.blocks;
+    DeviceProcessor proc(dev);
+    LcbEngineStats es;
+    lcb_engine_run(g, p, seeds, nSeeds, proc, cfg, blocks, &es);
     if (stats) {
         double ms = 0; int64_t l = 0;
         lcb_device_kernel_time_impl(dev, &ms, &l);
-        stats->seeds = nSeeds; stats->blocks_found = com.blocksFound; stats->failures = com.failures;
+        stats->seeds = nSeeds; stats->blocks_found = es.blocksFound; stats->failures = es.failures;
         stats->launches = l; stats->kernel_ms = ms; stats->big_retries = lcb_device_big_retries_impl(dev) - retries0;
-        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->wall_ms = es.wallMs;
+        stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
+        stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
     }
 }

@@ -22,10 +22,11 @@ void lcb_device_set_used_impl(lcb_device* d, const uint32_t* words, int64_t nWor
 void lcb_device_set_stats_impl(lcb_device* d, bool on);
 // Processes seeds[0..n): fills offsets[n+1] and inst (resized), bestScore (optional, n entries), ctr (optional, accumulated).
 void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
-                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr);
+                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
+                             std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr);
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
-                          bool progress, std::vector<lcb_block>& blocks, lcb_stats* stats);
+                          const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);
 
 #endif

@@ -54,9 +54,46 @@ struct lcb_committer {
     int64_t blocksFound = 0, failures = 0;
     lcb_committer(const lcb_graph* graph, const lcb_params& prm);
     bool anyUsed(uint64_t lo, uint64_t hi) const;
+    bool conflicts(const lcb_instance* inst, uint64_t n) const;   // the weak check of blocksfinder.h:377-398
     void finalize(const lcb_instance* inst, uint64_t n);
+    void endPhase();                                              // invalidChr_.clear(), blocksfinder.h:416
     void commitPhase(const lcb_seed* seeds, int64_t n, const uint64_t* offsets, const lcb_instance* inst,
                      lcb_reprocess_fn fn, void* user);
 };
+
+// A footprint interval: flat positions [lo, hi] whose `used` bit a per-seed computation read as 0 (lcb_kernel.h).
+struct lcb_fp { uint32_t lo, hi; };
+
+// engine.cpp — the per-rank engine behind the phase loop: something that runs ProcessVertex::Process for a batch of
+// seeds against ITS current `used` state. The product's implementation is the HIP device (device.hip); tests plug in
+// a callback stand-in. Footprints are optional: an implementation that cannot produce them returns one interval
+// [0, UINT32_MAX] per seed, which makes every speculative result conservatively invalid after any commit.
+struct LcbProcessor {
+    virtual ~LcbProcessor() {}
+    virtual void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                         std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) = 0;
+    virtual void mark(const uint64_t* ranges, int64_t n) = 0;
+    virtual void reset() = 0;
+};
+
+// All-gather of a fixed-size buffer across ranks: recv holds world * bytes. Returns 0 on success.
+typedef int (*lcb_allgather_fn)(void* user, const void* send, uint64_t bytes, void* recv);
+
+struct LcbEngineConfig {
+    int rank = 0, world = 1;
+    lcb_allgather_fn allgather = nullptr;
+    void* allgatherUser = nullptr;
+    int roundPhases = 0;      // phases launched speculatively per round (0 = LCB_ROUND_PHASES or the default)
+    bool progress = false;
+};
+
+struct LcbEngineStats {
+    int64_t seeds = 0, blocksFound = 0, failures = 0, rounds = 0, recomputeLaunches = 0, recomputedSeeds = 0, conflictLaunches = 0,
+            conflictSeeds = 0, exchanges = 0;
+    double wallMs = 0;
+};
+
+void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds, LcbProcessor& proc,
+                    const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, LcbEngineStats* stats);
 
 #endif

@@ -33,10 +33,15 @@
 
 #define LCB_EMPTY_KEY INT32_MIN
 
-// LDS-resident ("small") capacities; seeds that exceed them are re-run with global-memory
-// workspaces ("big" mode) by the host.
+// Three kernel variants by where the per-path state lives. Seeds that overflow one are re-run by the host in the next:
+//   mode 0 "small":  instances + vote table in 36 KB of LDS  -> 4 workgroups per CU
+//   mode 1 "medium": 4x the capacities in 146 KB of LDS       -> 1 workgroup per CU
+//   mode 2 "big":    instances + vote table in the global-memory workspace, capacities chosen by the host
 #define LCB_IC_SMALL 256u    // instances
 #define LCB_VC_SMALL 1024u   // vote-table slots (power of two)
+#define LCB_IC_MEDIUM 1024u
+#define LCB_VC_MEDIUM 4096u
+#define LCB_BLOOM_WORDS 1024u  // LDS Bloom filter in front of the path vertex set (32768 bits, 2 hashes)
 
 enum LcbStatus : uint32_t {
     LCB_ST_OK = 0,
@@ -55,8 +60,7 @@ struct LcbTables {
     const uint8_t* posCh;       // [nPos]  seq[pos + k]              (JunctionSequentialIterator::GetChar, + strand)
     const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
     const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
-    const uint32_t* occG;       // [nPos]  flat position of each occurrence, ascending
-    const uint32_t* occChr;     // [nPos]
+    const uint4* occRec;        // [nPos]  per occurrence, ascending in g: {g, chr, Position::pos, Position::id} (one 16-B load)
     const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx)
     uint32_t nChr, nVertex, nPos;
 };
@@ -69,7 +73,10 @@ struct LcbSeedOut {            // per-seed header written by the kernel
     uint32_t status;
     int64_t bestScore;
     uint64_t arenaOff;
-    uint64_t ctr[8];           // lcb_counters order; only in stats mode
+    uint64_t fpOff;            // first footprint interval of this seed in the footprint arena
+    uint32_t nFp;              // number of footprint intervals (= instances ever created)
+    uint32_t pad;
+    uint64_t ctr[8];           // lcb_counters order in stats mode, a cheap profile otherwise
 };
 
 struct LcbWork {               // per-wave global-memory workspace slots
@@ -84,13 +91,15 @@ struct LcbWork {               // per-wave global-memory workspace slots
     uint32_t cursorBase;       // ... tickets of this launch are [cursorBase, cursorBase + nSeeds)
     unsigned long long* arenaCursor;   // monotone result-arena allocator
     unsigned long long arenaBase;
+    unsigned long long* fpCursor;      // monotone footprint-arena allocator
+    unsigned long long fpBase;
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
 };
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
     uint64_t pKeys, pSlots, body, best;                       // always
-    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, vTouched;   // big mode
+    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, vTouched, fp;   // big mode
     uint64_t total;
 };
 __host__ __device__ inline uint64_t lcb_align16(uint64_t x) { return (x + 15) & ~15ull; }
@@ -111,6 +120,7 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.vCount = o; o = lcb_align16(o + 4ull * voteCap);
     L.vLast = o; o = lcb_align16(o + 8ull * voteCap);
     L.vTouched = o; o = lcb_align16(o + 4ull * voteCap);
+    L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
     L.total = lcb_align16(o);
     return L;
 }
@@ -141,9 +151,15 @@ struct LcbState {
     // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
     uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iChr, *iLo, *iHi, *iFlags;
     int32_t *iFrontDist, *iBackDist;
-    uint32_t* ordKey[2];       // instance_ ordered sets flattened: keys (flat compare position) ...
-    uint32_t* ordIdx[2];       // ... and pool indices, double buffered
+    uint32_t* ordKey;          // instance_ ordered sets flattened: keys (flat compare position) ... [2][instCap], half `cur` is live
+    uint32_t* ordIdx;          // ... and pool indices, double buffered the same way
     uint32_t* good;            // goodInstance_ (path.h:685), pool indices in append order
+    // Footprint: per instance ever created, the range of flat positions whose `used` bit was read as 0 and could
+    // have changed the result (its span plus every look-ahead window walked from its ends). A result computed
+    // against an older `used` snapshot is still exact iff no bit inside these ranges has been set since
+    // (bits only go 0 -> 1 and the computation is deterministic). Survives the replay's Clear.
+    uint32_t *fpLo, *fpHi;
+    uint32_t nFp;
     uint32_t instCap;
     // vote table
     int32_t* vKey;
@@ -153,6 +169,7 @@ struct LcbState {
     uint32_t* vNTouched;       // LDS counter
     uint32_t voteCap, voteShift;
     uint32_t* scr;             // LDS scratch, 4 * 64 words
+    uint32_t* bloom;           // LDS Bloom filter over the path vertex set
     // path vertex set + bodies + result snapshot (global workspace)
     int32_t* pKeys;
     uint32_t* pSlots;
@@ -165,6 +182,8 @@ struct LcbState {
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
     uint32_t* dbg;             // flight recorder of this workgroup (may be null)
+    uint32_t pfPush, pfVote, pfMaxProbe, pfMaxInst;   // cheap always-on per-seed profile (wave-uniform)
+    uint64_t pfTVote, pfTPush, pfTScore;              // 10 ns ticks spent in the vote / push / score+snapshot sections
     // per-lane event counters (stats mode)
     uint64_t cWalk, cOcc, cCompatCall, cCompatStep, cVote, cPush;
 };
@@ -228,17 +247,46 @@ __device__ __forceinline__ int64_t lcb_wave_sum(int64_t v)
 }
 
 // ---- path vertex set (DistanceKeeper::IsSet / Set / Unset, distancekeeper.h:17-35) --------------
-__device__ inline bool lcb_path_contains(const LcbState& S, int32_t vid)
+// Exact open-addressing set in the wave's global workspace, fronted by an LDS Bloom filter: the common
+// answer during a look-ahead walk is "not in the path", which the filter gives from LDS without touching
+// global memory; only filter hits probe the exact table.
+__device__ __forceinline__ uint32_t lcb_bloom1(int32_t vid) { return ((uint32_t)vid * 2654435761u) >> 17; }
+__device__ __forceinline__ uint32_t lcb_bloom2(int32_t vid) { return ((uint32_t)vid * 0xC2B2AE35u + 0x27D4EB2Fu) >> 17; }
+
+__device__ __forceinline__ bool lcb_bloom_maybe(const LcbState& S, int32_t vid)
+{
+    const uint32_t a = lcb_bloom1(vid), b = lcb_bloom2(vid);
+    return ((S.bloom[a >> 5] >> (a & 31)) & (S.bloom[b >> 5] >> (b & 31)) & 1u) != 0;
+}
+
+__device__ inline bool lcb_path_probe(const LcbState& S, int32_t vid, uint32_t& probes)
 {
     uint32_t h = lcb_hash(vid, S.pathShift);
     const uint32_t mask = S.pathCap - 1;
     for (uint32_t probe = 0; probe < S.pathCap; probe++) {      // the set is at most half full; the bound only guards a corrupted table
         const int32_t k = S.pKeys[h];
-        if (k == vid) return true;
-        if (k == LCB_EMPTY_KEY) return false;
+        if (k == vid || k == LCB_EMPTY_KEY) { probes = probe; return k == vid; }
         h = (h + 1) & mask;
     }
+    probes = S.pathCap;
     return false;
+}
+
+__device__ __forceinline__ bool lcb_path_contains(const LcbState& S, int32_t vid)
+{
+    if (!lcb_bloom_maybe(S, vid)) return false;
+    uint32_t probes;
+    return lcb_path_probe(S, vid, probes);
+}
+
+// same, also reporting the probe length (profiling); wave-uniform callers only
+__device__ __forceinline__ bool lcb_path_contains_p(LcbState& S, int32_t vid)
+{
+    if (!lcb_bloom_maybe(S, vid)) return false;
+    uint32_t probes = 0;
+    const bool r = lcb_path_probe(S, vid, probes);
+    if (probes > S.pfMaxProbe) S.pfMaxProbe = probes;
+    return r;
 }
 
 // Wave-uniform: inserts vid (not present). Lane 0 writes.
@@ -251,15 +299,21 @@ __device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
     while (S.pKeys[h] != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; }
     if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
     LCB_WAVE_SYNC();               // every lane has finished probing before lane 0 publishes the key
-    if (S.lane == 0) { S.pKeys[h] = vid; S.pSlots[S.nPath] = h; }
+    if (S.lane == 0) {
+        S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
+        const uint32_t a = lcb_bloom1(vid), b = lcb_bloom2(vid);
+        S.bloom[a >> 5] |= 1u << (a & 31);
+        S.bloom[b >> 5] |= 1u << (b & 31);
+    }
     S.nPath++;
     LCB_WAVE_SYNC();
 }
 
-// Path::Clear (path.h:650-677): wave-uniform.
+// Path::Clear (path.h:650-677): wave-uniform. The right-body list is kept (the replay reads it).
 __device__ inline void lcb_path_clear(LcbState& S)
 {
     for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+    if (S.nPath) for (uint32_t i = S.lane; i < LCB_BLOOM_WORDS; i += 64) S.bloom[i] = 0;
     S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0;
     S.rightFlank = 0; S.leftFlank = 0;
     LCB_WAVE_SYNC();
@@ -280,16 +334,18 @@ __device__ inline void lcb_order_merge(LcbState& S, uint32_t m)
 {
     const uint32_t n = S.nInst - m;     // old element count (nInst already includes the new ones)
     const uint32_t c = S.cur, d = c ^ 1;
+    const uint32_t* ck = S.ordKey + c * S.instCap; const uint32_t* ci = S.ordIdx + c * S.instCap;
+    uint32_t* dk = S.ordKey + d * S.instCap; uint32_t* di = S.ordIdx + d * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         uint32_t cnt = 0;
         for (uint32_t r = 0; r < m; r++) cnt += (S.scr[r] <= i) ? 1u : 0u;
-        S.ordKey[d][i + cnt] = S.ordKey[c][i];
-        S.ordIdx[d][i + cnt] = S.ordIdx[c][i];
+        dk[i + cnt] = ck[i];
+        di[i + cnt] = ci[i];
     }
     if (S.lane < m) {
         const uint32_t at = S.scr[S.lane] + S.lane;
-        S.ordKey[d][at] = S.scr[64 + S.lane];
-        S.ordIdx[d][at] = S.scr[128 + S.lane];
+        dk[at] = S.scr[64 + S.lane];
+        di[at] = S.scr[128 + S.lane];
     }
     S.cur = d;
     LCB_WAVE_SYNC();
@@ -311,10 +367,10 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
         bool positive = false;
         if (j < o1) {
             if (STATS) S.cOcc++;
-            g = T.occG[j]; chr = T.occChr[j];
+            const uint4 rec = T.occRec[j];
+            g = rec.x; chr = rec.y; pos = rec.z;
             lo = T.chrStart[chr]; hi = T.chrStart[chr + 1];
-            positive = (T.posId[g] == vid);
-            pos = T.posPos[g];
+            positive = ((int32_t)rec.w == vid);
             ok = !lcb_it_used(T, g, positive, lo) && (int32_t)lcb_it_char(T, g, positive) == ch;
         }
         const unsigned long long m = __ballot(ok);
@@ -325,10 +381,12 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
             S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
             S.iFrontDist[i] = 0; S.iBackDist[i] = 0; S.iChr[i] = chr; S.iLo[i] = lo; S.iHi[i] = hi;
             S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
-            S.ordKey[S.cur][i] = g;   // occurrences ascend in g, so pool order == key order here
-            S.ordIdx[S.cur][i] = i;
+            if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }        // the replay re-creates instance i at the same occurrence
+            S.ordKey[S.cur * S.instCap + i] = g;   // occurrences ascend in g, so pool order == key order here
+            S.ordIdx[S.cur * S.instCap + i] = i;
         }
         S.nInst += cnt;
+        if (S.nInst > S.nFp) S.nFp = S.nInst;
     }
     LCB_WAVE_SYNC();
 }
@@ -345,33 +403,56 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     const uint32_t vmask = S.voteCap - 1;
     bool ovf = false;
     if (STATS && S.lane == 0) S.cVote++;
-    for (uint32_t e = 0; e < nList; e++) {
-        const uint32_t i = useGood ? S.good[e] : e;
-        const int32_t endDist = forward ? S.iBackDist[i] : S.iFrontDist[i];
-        // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
-        if (endDist != (forward ? S.rightFlank : S.leftFlank)) continue;
-        const bool positive = (S.iFlags[i] & LCB_FLAG_POS) != 0;
-        const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
-        const uint32_t pos0 = forward ? S.iBackPos[i] : S.iFrontPos[i];
-        const uint32_t lo = S.iLo[i], hi = S.iHi[i];
-        const uint32_t weight = lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]) + 1u;   // blocksfinder.h:719
-        const int64_t dir = (forward == positive) ? 1 : -1;
+    S.pfVote++;
+    // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717); its look-ahead window is
+    // walked 64 steps per pass, lanes = steps. The three table reads of a pass (pos, id, used word) are independent and
+    // issued together; the first pass of the NEXT voter is issued before the current one is consumed, so its latency
+    // hides behind the LDS work of this one.
+    struct Voter { uint32_t e, i, g0, pos0, lo, hi, weight; int32_t dir; bool positive; };
+    struct Walk { uint32_t g, pos; int32_t id; bool valid, used; };
+    const int32_t flank = forward ? S.rightFlank : S.leftFlank;
+    auto nextVoter = [&](uint32_t e, Voter& v) -> bool {
+        for (; e < nList; e++) {
+            const uint32_t i = useGood ? S.good[e] : e;
+            // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
+            if ((forward ? S.iBackDist[i] : S.iFrontDist[i]) != flank) continue;
+            v.e = e; v.i = i;
+            v.positive = (S.iFlags[i] & LCB_FLAG_POS) != 0;
+            v.g0 = forward ? S.iBackG[i] : S.iFrontG[i];
+            v.pos0 = forward ? S.iBackPos[i] : S.iFrontPos[i];
+            v.lo = S.iLo[i]; v.hi = S.iHi[i];
+            v.weight = lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]) + 1u;            // blocksfinder.h:719
+            v.dir = (forward == v.positive) ? 1 : -1;
+            return true;
+        }
+        return false;
+    };
+    auto issue = [&](const Voter& v, uint32_t c) -> Walk {
+        Walk w;
+        const uint32_t d = c * 64 + S.lane + 1;
+        const int64_t gg = (int64_t)v.g0 + (int64_t)v.dir * (int64_t)d;
+        w.valid = gg >= (int64_t)v.lo && gg < (int64_t)v.hi;                       // it.Valid()
+        w.g = (uint32_t)gg; w.pos = 0; w.id = 0; w.used = false;
+        if (w.valid) {
+            w.pos = T.posPos[w.g];
+            w.id = T.posId[w.g];
+            w.used = lcb_it_used(T, w.g, v.positive, v.lo);
+        }
+        return w;
+    };
+    Voter cur, nxt;
+    Walk wcur, wnxt;
+    bool have = nextVoter(0, cur);
+    if (have) wcur = issue(cur, 0);
+    while (have) {
+        const bool haveNext = nextVoter(cur.e + 1, nxt);
+        if (haveNext) wnxt = issue(nxt, 0);
         for (uint32_t c = 0;; c++) {
+            const Walk w = c == 0 ? wcur : issue(cur, c);
             const uint32_t d = c * 64 + S.lane + 1;
-            const int64_t gg = (int64_t)g0 + dir * (int64_t)d;
-            bool cond = gg >= (int64_t)lo && gg < (int64_t)hi;                     // it.Valid()
-            int32_t vid = 0;
-            bool stop = false;
-            if (cond) {
-                const uint32_t g = (uint32_t)gg;
-                const uint32_t pos = T.posPos[g];
-                cond = d < (uint32_t)S.P.depth || lcb_absdiff(pos, pos0) <= (uint32_t)S.P.maxBranch;
-                if (cond) {
-                    const int32_t id = T.posId[g];
-                    vid = positive ? id : -id;
-                    stop = lcb_path_contains(S, vid) || (!tryUsed && lcb_it_used(T, g, positive, lo));
-                }
-            }
+            const bool cond = w.valid && (d < (uint32_t)S.P.depth || lcb_absdiff(w.pos, cur.pos0) <= (uint32_t)S.P.maxBranch);
+            const int32_t vid = cur.positive ? w.id : -w.id;
+            const bool stop = cond && ((!tryUsed && w.used) || lcb_path_contains(S, vid));
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
             const unsigned long long endM = failM | stopM;
@@ -396,12 +477,22 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
                 }
                 if (probe == S.voteCap) ovf = true;
                 else {
-                    atomicAdd(&S.vCount[h], weight);
-                    atomicMax(&S.vLast[h], ((unsigned long long)e << 32) | d);
+                    atomicAdd(&S.vCount[h], cur.weight);
+                    atomicMax(&S.vLast[h], ((unsigned long long)cur.e << 32) | d);
                 }
             }
-            if (first < 64) break;
+            if (first < 64) {
+                if (!tryUsed && S.lane == 0) {
+                    // steps 1 .. c*64+first-1 read used == 0 (one step of slack keeps the - strand's bit g-1 inside)
+                    const int64_t ext = (int64_t)cur.g0 + (int64_t)cur.dir * (int64_t)(c * 64 + first);
+                    const uint32_t ge = ext < (int64_t)cur.lo ? cur.lo : (ext >= (int64_t)cur.hi ? cur.hi - 1 : (uint32_t)ext);
+                    if (ge < S.fpLo[cur.i]) S.fpLo[cur.i] = ge;
+                    if (ge > S.fpHi[cur.i]) S.fpHi[cur.i] = ge;
+                }
+                break;
+            }
         }
+        have = haveNext; cur = nxt; wcur = wnxt;
     }
     LCB_WAVE_SYNC();
     uint32_t nTouched = *S.vNTouched;
@@ -467,7 +558,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
     const int32_t idN = T.posId[gN], idIt = T.posId[gIt];
     const int32_t vertex = itPositive ? idN : -idN;                  // pushed vertex
     const int32_t otherVertex = itPositive ? idIt : -idIt;           // e.GetEndVertex() for a front push
-    if (lcb_path_contains(S, vertex)) return false;
+    if (lcb_path_contains_p(S, vertex)) return false;
     const uint32_t length = lcb_absdiff(T.posPos[gN], T.posPos[gIt]);
     // e.GetChar(): outgoing -> char at gIt, ingoing -> char at the previous position gN (junctionstorage.h:191-227)
     const int32_t ech = (int32_t)lcb_it_char(T, BACK ? gIt : gN, itPositive);
@@ -484,17 +575,17 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
         const uint32_t j = base + S.lane;
         const bool active = j < o1;
         const uint32_t n = S.nInst;
-        const uint32_t* oKey = S.ordKey[S.cur];
-        const uint32_t* oIdx = S.ordIdx[S.cur];
+        const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
+        const uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         bool positive = false, usedS = false, usesP = false;
         if (active) {
             if (STATS) S.cOcc++;
-            g = T.occG[j]; chr = T.occChr[j];
+            const uint4 rec = T.occRec[j];
+            g = rec.x; chr = rec.y; pos = rec.z;
             lo = T.chrStart[chr];
-            positive = (T.posId[g] == vertex);                       // JunctionIterator::IsPositiveStrand
-            pos = T.posPos[g];
+            positive = ((int32_t)rec.w == vertex);                   // JunctionIterator::IsPositiveStrand
             usedS = lcb_it_used(T, g, positive, lo);
             // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g
             uint32_t a = 0, b = n;
@@ -591,13 +682,15 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
             const int64_t before = lcb_real_length(S, cand);
             if (BACK) {                                              // Instance::ChangeBack (path.h:124-133)
                 S.iBackG[cand] = g; S.iBackPos[cand] = pos; S.iBackDist[cand] = distance;
-                if (positive) S.ordKey[S.cur][u - 1] = g;            // compareIdx_ follows the + strand back
+                if (positive) S.ordKey[S.cur * S.instCap + u - 1] = g;   // compareIdx_ follows the + strand back
                 if (usedS) S.iFlags[cand] |= LCB_FLAG_BACKFIN;
             } else {                                                 // Instance::ChangeFront (path.h:113-122)
                 S.iFrontG[cand] = g; S.iFrontPos[cand] = pos; S.iFrontDist[cand] = distance;
-                if (!positive) S.ordKey[S.cur][u - 1] = g;           // compareIdx_ follows the - strand front
+                if (!positive) S.ordKey[S.cur * S.instCap + u - 1] = g;  // compareIdx_ follows the - strand front
                 if (usedS) S.iFlags[cand] |= LCB_FLAG_FRONTFIN;
             }
+            if (g < S.fpLo[cand]) S.fpLo[cand] = g;
+            if (g > S.fpHi[cand]) S.fpHi[cand] = g;
             becameGood = before < (int64_t)S.P.minBlock && lcb_real_length(S, cand) >= (int64_t)S.P.minBlock;
         }
         const unsigned long long insM = __ballot(ins);
@@ -613,9 +706,11 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
             S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iChr[i] = chr; S.iLo[i] = lo;
             S.iHi[i] = T.chrStart[chr + 1];
             S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
+            if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
         }
         S.nInst += m;
+        if (S.nInst > S.nFp) S.nFp = S.nInst;
         LCB_WAVE_SYNC();
         if (m) lcb_order_merge(S, m);
     }
@@ -631,6 +726,8 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
         S.leftFlank = distance;
     }
     if (STATS && S.lane == 0) S.cPush++;
+    S.pfPush++;
+    if (S.nInst > S.pfMaxInst) S.pfMaxInst = S.nInst;
     return true;
 }
 
@@ -671,6 +768,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
     const LcbTables& T = S.T;
     uint32_t oi = 0;
     LCB_MARK(S, 4, S.nRight); LCB_MARK(S, 5, S.nLeft); LCB_MARK(S, 6, 1);
+    const uint64_t tv0 = wall_clock64();
     int32_t next = lcb_vote<STATS>(S, FORWARD, false, oi);
     LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
     if (S.status) return false;
@@ -678,6 +776,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
         next = lcb_vote<STATS>(S, true, true, oi);
         if (S.status) return false;
     }
+    S.pfTVote += wall_clock64() - tv0;
     bool success = false;
     if (next != 0) {
         const bool positive = (S.iFlags[oi] & LCB_FLAG_POS) != 0;
@@ -687,7 +786,10 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
             const int32_t id = T.posId[g];
             if ((positive ? id : -id) == next) break;
             LCB_MARK(S, 6, 3); LCB_MARK(S, 8, g);
+            const uint64_t tp0 = wall_clock64();
             success = lcb_push<FORWARD, STATS>(S, g, positive, true);
+            const uint64_t tp1 = wall_clock64();
+            S.pfTPush += tp1 - tp0;
             LCB_MARK(S, 6, 4);
             if (S.status) return false;
             if (success) {
@@ -697,6 +799,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
                     if (FORWARD) bestRightSize = S.nRight + 1;
                     if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
                 }
+                S.pfTScore += wall_clock64() - tp1;
             }
             g = (uint32_t)((int64_t)g + dir);
         }
@@ -728,10 +831,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
     LCB_MARK(S, 2, 3);
     if (!S.status) {                                                 // replay, blocksfinder.h:271-284
         const uint32_t nEdge = bestRightSize - 1;
-        // keep the body list, reset everything else
-        for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
-        S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0; S.rightFlank = 0; S.leftFlank = 0;
-        LCB_WAVE_SYNC();
+        lcb_path_clear(S);            // keeps the body list, resets everything else
         lcb_path_init<STATS>(S, vid, ch);
         for (uint32_t i = 0; i < nEdge && !S.status; i++) {
             const unsigned long long b = S.body[i];
@@ -751,9 +851,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         }
     }
     LCB_MARK(S, 2, 5);
-    // Path::Clear (blocksfinder.h:308)
-    for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
-    S.nPath = 0;
+    lcb_path_clear(S);                // Path::Clear (blocksfinder.h:308)
     if (S.status == LCB_ST_VOTE_OVF) {
         // the vote table may hold stale keys after an overflow: wipe it
         for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
@@ -764,20 +862,24 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
-template <bool BIG, bool STATS>
+template <int MODE, bool STATS>
 __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P, const LcbKSeed* seeds, uint32_t nSeeds,
-                                        const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap)
+                                        const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
+                                        uint2* fpArena, unsigned long long fpCap)
 {
-    constexpr uint32_t IC = BIG ? 1u : LCB_IC_SMALL;
-    constexpr uint32_t VC = BIG ? 1u : LCB_VC_SMALL;
+    constexpr bool BIG = MODE == 2;
+    constexpr uint32_t IC = BIG ? 1u : (MODE == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL);
+    constexpr uint32_t VC = BIG ? 1u : (MODE == 1 ? LCB_VC_MEDIUM : LCB_VC_SMALL);
     __shared__ uint32_t sInst[10 * IC];
     __shared__ uint32_t sOrdKey[2 * IC];
     __shared__ uint32_t sOrdIdx[2 * IC];
     __shared__ uint32_t sGood[IC];
+    __shared__ uint32_t sFp[2 * IC];
     __shared__ int32_t sVKey[VC];
     __shared__ uint32_t sVCount[VC];
     __shared__ unsigned long long sVLast[VC];
     __shared__ uint32_t sVTouched[VC];
+    __shared__ uint32_t sBloom[LCB_BLOOM_WORDS];
     __shared__ uint32_t sScr[4 * 64];
     __shared__ uint32_t sMisc[4];
 
@@ -794,21 +896,25 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     uint32_t* instBase;
     if (BIG) {
         instBase = (uint32_t*)(slot + L.inst); S.instCap = W.instCap;
-        S.ordKey[0] = (uint32_t*)(slot + L.ordKey); S.ordKey[1] = S.ordKey[0] + W.instCap;
-        S.ordIdx[0] = (uint32_t*)(slot + L.ordIdx); S.ordIdx[1] = S.ordIdx[0] + W.instCap;
+        S.ordKey = (uint32_t*)(slot + L.ordKey);
+        S.ordIdx = (uint32_t*)(slot + L.ordIdx);
         S.good = (uint32_t*)(slot + L.good);
+        S.fpLo = (uint32_t*)(slot + L.fp); S.fpHi = S.fpLo + W.instCap;
         S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
         S.vLast = (unsigned long long*)(slot + L.vLast); S.vTouched = (uint32_t*)(slot + L.vTouched);
         S.voteCap = W.voteCap;
     } else {
         instBase = sInst; S.instCap = IC;
-        S.ordKey[0] = sOrdKey; S.ordKey[1] = sOrdKey + IC;
-        S.ordIdx[0] = sOrdIdx; S.ordIdx[1] = sOrdIdx + IC;
+        S.ordKey = sOrdKey;
+        S.ordIdx = sOrdIdx;
         S.good = sGood;
+        S.fpLo = sFp; S.fpHi = sFp + IC;
         S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast; S.vTouched = sVTouched;
         S.voteCap = VC;
         for (uint32_t h = S.lane; h < VC; h += 64) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
     }
+    S.bloom = sBloom;
+    for (uint32_t h = S.lane; h < LCB_BLOOM_WORDS; h += 64) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
     S.iFrontG = instBase; S.iBackG = instBase + S.instCap; S.iFrontPos = instBase + 2 * S.instCap;
     S.iBackPos = instBase + 3 * S.instCap; S.iChr = instBase + 4 * S.instCap; S.iLo = instBase + 5 * S.instCap;
@@ -830,8 +936,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         LCB_MARK(S, 1, s + 1);
         S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
         S.nInst = S.nGood = S.cur = S.nRight = S.nLeft = 0; S.rightFlank = S.leftFlank = 0;
+        S.nFp = 0;
         int64_t bestScore = 0;
+        S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0;
+        const uint64_t tick0 = wall_clock64();
         lcb_process_seed<STATS>(S, seeds[s].vid, seeds[s].ch, bestScore);
+        const uint64_t ticks = wall_clock64() - tick0;
         const uint32_t n = S.status ? 0u : S.nBest;
         unsigned long long off = 0;
         if (n) {
@@ -841,6 +951,18 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             off = ((unsigned long long)ohi << 32) | olo;
             if (off + n > arenaCap) S.status = LCB_ST_ARENA_OVF;
             else for (uint32_t e = S.lane; e < n; e += 64) arena[off + e] = S.best[e];
+        }
+        // footprint intervals (one per instance ever created), widened by one position on the low side
+        // because the - strand reads bit g-1
+        const uint32_t nfp = (S.status == LCB_ST_OK && fpArena) ? S.nFp : 0u;
+        unsigned long long fpo = 0;
+        if (nfp) {
+            uint32_t olo = 0, ohi = 0;
+            if (S.lane == 0) { fpo = atomicAdd(W.fpCursor, (unsigned long long)nfp) - W.fpBase; olo = (uint32_t)fpo; ohi = (uint32_t)(fpo >> 32); }
+            olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
+            fpo = ((unsigned long long)ohi << 32) | olo;
+            if (fpo + nfp > fpCap) S.status = LCB_ST_ARENA_OVF;
+            else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpArena[fpo + e] = r; }
         }
         uint64_t c[6];
         if (STATS) {
@@ -852,7 +974,9 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             LcbSeedOut o;
             o.nInst = n;   // kept on ARENA_OVF so the host can track the allocator
             o.status = S.status; o.bestScore = bestScore; o.arenaOff = off;
+            o.fpOff = fpo; o.nFp = nfp; o.pad = 0;
             for (int q = 0; q < 8; q++) o.ctr[q] = 0;
+            if (!STATS) { o.ctr[0] = ticks; o.ctr[1] = S.pfPush; o.ctr[2] = S.pfVote; o.ctr[3] = S.pfMaxProbe; o.ctr[4] = S.pfMaxInst; o.ctr[5] = S.pfTVote; o.ctr[6] = S.pfTPush; o.ctr[7] = S.pfTScore; }
             if (STATS) { o.ctr[0] = c[0]; o.ctr[1] = c[1]; o.ctr[2] = c[2]; o.ctr[3] = c[3]; o.ctr[4] = o.nInst; o.ctr[5] = c[4]; o.ctr[6] = c[5]; o.ctr[7] = 1; }
             out[s] = o;
         }

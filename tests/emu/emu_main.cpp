@@ -32,24 +32,29 @@ struct Emu {
     std::vector<uint32_t> chrStart32, used;
     LcbTables T;
     LcbKParams KP;
+    int mode = 0;
     bool big = false;
+    std::vector<uint4> occRec;
     std::vector<uint8_t> slot;
     LcbWork W;
-    uint32_t cursor[4] = {0, 0, 0, 0};
+    uint32_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint2> fpArena;
     std::vector<LcbSeedOut> out;
     std::vector<uint4> arena;
     lcb_counters ctr{};
 
-    Emu(const lcb_graph* graph, const lcb_params& prm, bool bigMode) : g(graph), p(prm), big(bigMode)
+    Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode == 2)
     {
         chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
         used.assign(g->nPos() / 32 + 2, 0);
         T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
         T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
-        T.occG = g->occG.data(); T.occChr = g->occChr.data(); T.used = used.data();
+        occRec.resize(g->nPos());
+        for (size_t j = 0; j < occRec.size(); j++) { const uint32_t q = g->occG[j]; occRec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]}; }
+        T.occRec = occRec.data(); T.used = used.data();
         T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
-        W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : LCB_IC_SMALL; W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
+        W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : (mode == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL); W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
         LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
         slot.assign(L.total, 0);
         int32_t* pk = (int32_t*)(slot.data() + L.pKeys);
@@ -58,6 +63,8 @@ struct Emu {
         W.base = slot.data(); W.slotBytes = L.total;
         W.dbg = nullptr; W.cursor = &cursor[0]; W.arenaCursor = (unsigned long long*)&cursor[2];
         arena.resize(1 << 20);
+        fpArena.resize(1 << 20);
+        W.fpCursor = (unsigned long long*)&cursor[4];
     }
 
     // runs the process kernel over seeds with ONE emulated wavefront (the work queue feeds it all seeds)
@@ -66,10 +73,12 @@ struct Emu {
         out.assign(seeds.size(), LcbSeedOut{});
         W.cursorBase = cursor[0];
         W.arenaBase = *W.arenaCursor;
+        W.fpBase = *W.fpCursor;
         const LcbKSeed* sp = seeds.data();
         const uint32_t n = (uint32_t)seeds.size();
-        if (big) emu_run_wave(0, [&]() { lcb_process_body<true, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size()); });
-        else emu_run_wave(0, [&]() { lcb_process_body<false, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size()); });
+        if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else emu_run_wave(0, [&]() { lcb_process_body<0, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
         for (auto& o : out) {
             ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
             ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
@@ -96,27 +105,6 @@ int compareSeed(int64_t idx, const lcb_seed& sd, const LcbSeedOut& o, const uint
         }
     }
     return ok ? 0 : 1;
-}
-
-struct FindCtx { Emu* emu; lcb_committer* com; };
-
-int redoEmu(void* user, const lcb_seed* seed, lcb_instance* outInst, uint64_t cap, uint64_t* nOut)
-{
-    FindCtx* c = (FindCtx*)user;
-    // live state: the committer's bitmap IS the state
-    c->emu->used = c->com->used;
-    c->emu->T.used = c->emu->used.data();
-    c->com->marks.clear();
-    std::vector<LcbKSeed> one{LcbKSeed{seed->vid, seed->ch}};
-    c->emu->run(one);
-    const LcbSeedOut& o = c->emu->out[0];
-    if (o.status) { lcb_set_error("emulated kernel overflow"); return -1; }
-    *nOut = o.nInst;
-    for (uint32_t i = 0; i < o.nInst && i < cap; i++) {
-        const uint4 r = c->emu->arena[o.arenaOff + i];
-        outInst[i] = lcb_instance{r.x, r.y, r.z, r.w};
-    }
-    return 0;
 }
 
 }  // namespace
@@ -160,8 +148,8 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < id.size(); i++)
                 if (g->posId[g->chrStart[c] + i] != id[i] || g->posPos[g->chrStart[c] + i] != pos[i]) { fprintf(stderr, "FAIL: table differs\n"); return 1; }
         }
-        Emu emu(g, p, mode == "big");
-        if (mode == "seeds-init" || mode == "seeds-final" || mode == "big") {
+        Emu emu(g, p, mode == "big" ? 2 : (mode == "medium" ? 1 : 0));
+        if (mode == "seeds-init" || mode == "seeds-final" || mode == "big" || mode == "medium") {
             orc_counters octr; memset(&octr, 0, sizeof(octr));
             if (mode == "seeds-final") {
                 orc_block* ob = nullptr; orc_stats st;
@@ -206,42 +194,58 @@ int main(int argc, char** argv)
             if (!bad && (emu.ctr.n_walk != octr.n_walk || emu.ctr.n_occ != octr.n_occ || emu.ctr.n_compat_call != octr.n_compat_call ||
                          emu.ctr.n_compat_step != octr.n_compat_step || emu.ctr.n_inst_out != octr.n_inst_out)) { fprintf(stderr, "FAIL: event counters differ\n"); bad++; }
         } else if (mode == "find") {
-            lcb_committer com(g, p);
-            FindCtx ctx{&emu, &com};
-            for (size_t at = 0; at < seeds.size(); at += 256) {
-                const size_t n = seeds.size() - at < 256 ? seeds.size() - at : 256;
-                std::vector<LcbKSeed> ks;
-                for (size_t i = 0; i < n; i++) ks.push_back(LcbKSeed{seeds[at + i].vid, seeds[at + i].ch});
-                emu.used = com.used; emu.T.used = emu.used.data(); com.marks.clear();
-                emu.run(ks);
-                std::vector<uint64_t> off(n + 1, 0);
-                std::vector<lcb_instance> inst;
-                for (size_t i = 0; i < n; i++) {
-                    const LcbSeedOut& o = emu.out[i];
-                    if (o.status) { fprintf(stderr, "FAIL: overflow status %u\n", o.status); return 1; }
-                    off[i] = inst.size();
-                    for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu.arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
+            // the product's speculative round engine (engine.cpp) over the emulated kernel, for several round sizes
+            struct EmuProcessor : LcbProcessor {
+                Emu* emu;
+                void process(const lcb_seed* sd, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
+                             std::vector<lcb_fp>& fp) override
+                {
+                    std::vector<LcbKSeed> ks;
+                    for (int64_t i = 0; i < n; i++) ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch});
+                    emu->cursor[2] = emu->cursor[3] = emu->cursor[4] = emu->cursor[5] = 0;   // reuse the arenas
+                    if (n) emu->run(ks);
+                    off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
+                    for (int64_t i = 0; i < n; i++) {
+                        const LcbSeedOut& o = emu->out[(size_t)i];
+                        if (o.status) throw LcbError("emulated kernel overflow");
+                        off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
+                        for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
+                        for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
+                    }
+                    off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
                 }
-                off[n] = inst.size();
-                com.commitPhase(seeds.data() + at, (int64_t)n, off.data(), inst.data(), redoEmu, &ctx);
-            }
+                void mark(const uint64_t* r, int64_t n) override
+                {
+                    for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
+                }
+                void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); }
+            };
             orc_block* ob = nullptr; orc_stats st;
             const int64_t nb = orc_find_blocks(og, &op, &ob, &st, nullptr);
-            if (nb != (int64_t)com.blocks.size() || st.blocks_found != com.blocksFound || st.failures != com.failures) {
-                fprintf(stderr, "FAIL: blocks %zu/%lld found %lld/%lld failures %lld/%lld\n", com.blocks.size(), (long long)nb, (long long)com.blocksFound,
-                        (long long)st.blocks_found, (long long)com.failures, (long long)st.failures);
-                bad++;
+            std::vector<lcb_block> blocks;
+            const char* rp = getenv("EMU_ROUNDS");
+            std::vector<int> rounds = rp ? std::vector<int>{atoi(rp)} : std::vector<int>{1, 3, 64};
+            for (int R : rounds) {
+                EmuProcessor proc; proc.emu = &emu;
+                LcbEngineConfig cfg; cfg.roundPhases = R;
+                LcbEngineStats es;
+                lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
+                int diffs = 0;
+                if (nb != (int64_t)blocks.size() || st.blocks_found != es.blocksFound || st.failures != es.failures) diffs++;
+                for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
+                    if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
+                fprintf(stderr, "find R=%d: %zu seeds, blocks %zu/%lld found %lld/%lld failures %lld/%lld rounds %lld recompute %lld launches (%lld seeds) conflict %lld launches (%lld seeds) diffs %d\n",
+                        R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
+                        (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
+                        (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
+                bad += diffs;
             }
-            for (int64_t i = 0; i < nb && i < (int64_t)com.blocks.size(); i++)
-                if (ob[i].id != com.blocks[i].id || ob[i].chr != com.blocks[i].chr || ob[i].start != com.blocks[i].start || ob[i].end != com.blocks[i].end) { bad++; }
             int64_t nTrim = 0; double cov = 0;
-            lcb_generate_output_impl(*g, p.min_block, com.blocks.data(), (int64_t)com.blocks.size(), com.blocksFound, outDir, false, 0, &nTrim, &cov);
+            lcb_generate_output_impl(*g, p.min_block, blocks.data(), (int64_t)blocks.size(), st.blocks_found, outDir, false, 0, &nTrim, &cov);
             double ocov = 0;
             const std::string od2 = outDir + "_oracle";
             const int64_t ont = orc_generate_output(og, p.min_block, ob, nb, st.blocks_found, od2.c_str(), &ocov, err, sizeof(err));
             if (ont != nTrim) { fprintf(stderr, "FAIL: trimmed %lld vs %lld\n", (long long)nTrim, (long long)ont); bad++; }
-            fprintf(stderr, "find: %zu seeds, %lld blocks (%lld trimmed), failures %lld, diffs %d\n", seeds.size(), (long long)com.blocksFound, (long long)nTrim,
-                    (long long)com.failures, bad);
             printf("Blocks found: %lld\nCoverage: %.2f\n", (long long)nTrim, cov);
         } else { fprintf(stderr, "unknown mode\n"); return 2; }
         return bad ? 1 : 0;

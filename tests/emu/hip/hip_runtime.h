@@ -23,6 +23,7 @@
 #define __launch_bounds__(...)
 
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 struct EmuDim3 { uint32_t x, y, z; };
 
 EmuDim3 emu_thread_idx();
@@ -41,6 +42,7 @@ uint64_t emu_collective(int kind, uint64_t value, int arg, const char* file, int
 
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 template <class T_> static inline void __hip_atomic_store(T_* p, T_ v, int, int) { *p = v; }
+static inline uint64_t wall_clock64() { return 0; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
