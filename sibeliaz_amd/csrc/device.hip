@@ -29,12 +29,16 @@
     } while (0)
 
 // MODE 0/1/2 = small / medium / big (lcb_kernel.h): where the per-path instance pool and vote table live.
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(64) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
+// NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest help with the votes (lcb_kernel.h).
+#define LCB_NW_SMALL 4
+#define LCB_NW_MEDIUM 16
+#define LCB_NW_BIG 4
+template <int MODE, bool STATS, int NW>
+__global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
                                                          LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                                          uint2* fpArena, unsigned long long fpCap)
 {
-    lcb_process_body<MODE, STATS>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
+    lcb_process_body<MODE, STATS, NW>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -169,7 +173,8 @@ struct lcb_device_impl {
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         HIP_CHECK(hipEventRecord(ev0, stream));
-#define LCB_LAUNCH(MODE, ST) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST>), dim3(grid), dim3(64), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
+#define LCB_LAUNCH(MODE, ST) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))>), dim3(grid), \
+                                              dim3(64 * (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
         if (w.mode == 2) { if (stats) LCB_LAUNCH(2, true); else LCB_LAUNCH(2, false); }
         else if (w.mode == 1) { if (stats) LCB_LAUNCH(1, true); else LCB_LAUNCH(1, false); }
         else { if (stats) LCB_LAUNCH(0, true); else LCB_LAUNCH(0, false); }

@@ -170,6 +170,9 @@ struct LcbState {
     uint32_t voteCap, voteShift;
     uint32_t* scr;             // LDS scratch, 4 * 64 words
     uint32_t* bloom;           // LDS Bloom filter over the path vertex set
+    uint32_t* mail;            // LDS mailbox to the helper wavefronts (LCB_MAIL_*)
+    unsigned long long* mailWalk;   // stats: walk steps counted by the helpers
+    uint32_t nWaves;           // wavefronts in this workgroup (1 = no helpers)
     // path vertex set + bodies + result snapshot (global workspace)
     int32_t* pKeys;
     uint32_t* pSlots;
@@ -393,26 +396,24 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
 
 // ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
 // Returns the chosen vertex (0 = none) and the pool index of the origin instance.
+// The voter walks of one vote. With helper wavefronts (nWaves > 1) wave w takes list entries e == w (mod nWaves); all
+// waves accumulate into the shared LDS vote table with atomics, so the split needs no merging.
 template <bool STATS>
-__device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
+__device__ inline bool lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
+                                     uint32_t waveId, uint32_t nWaves)
 {
     const LcbTables& T = S.T;
-    const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
-    const uint32_t nList = useGood ? S.nGood : S.nInst;
     const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
     const uint32_t vmask = S.voteCap - 1;
     bool ovf = false;
-    if (STATS && S.lane == 0) S.cVote++;
-    S.pfVote++;
     // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717); its look-ahead window is
     // walked 64 steps per pass, lanes = steps. The three table reads of a pass (pos, id, used word) are independent and
     // issued together; the first pass of the NEXT voter is issued before the current one is consumed, so its latency
     // hides behind the LDS work of this one.
     struct Voter { uint32_t e, i, g0, pos0, lo, hi, weight; int32_t dir; bool positive; };
     struct Walk { uint32_t g, pos; int32_t id; bool valid, used; };
-    const int32_t flank = forward ? S.rightFlank : S.leftFlank;
     auto nextVoter = [&](uint32_t e, Voter& v) -> bool {
-        for (; e < nList; e++) {
+        for (; e < nList; e += nWaves) {
             const uint32_t i = useGood ? S.good[e] : e;
             // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
             if ((forward ? S.iBackDist[i] : S.iFrontDist[i]) != flank) continue;
@@ -442,10 +443,10 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     };
     Voter cur, nxt;
     Walk wcur, wnxt;
-    bool have = nextVoter(0, cur);
+    bool have = nextVoter(waveId, cur);
     if (have) wcur = issue(cur, 0);
     while (have) {
-        const bool haveNext = nextVoter(cur.e + 1, nxt);
+        const bool haveNext = nextVoter(cur.e + nWaves, nxt);
         if (haveNext) wnxt = issue(nxt, 0);
         for (uint32_t c = 0;; c++) {
             const Walk w = c == 0 ? wcur : issue(cur, c);
@@ -494,9 +495,43 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
         }
         have = haveNext; cur = nxt; wcur = wnxt;
     }
+    return __ballot(ovf) != 0;
+}
+
+// Mailbox words through which wave 0 hands a vote to the helper wavefronts of its workgroup.
+enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_OVF, LCB_MAIL_WORDS = 8 };
+enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
+
+template <bool STATS>
+__device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
+{
+    const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
+    const uint32_t nList = useGood ? S.nGood : S.nInst;
+    const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
+    const int32_t flank = forward ? S.rightFlank : S.leftFlank;
+    if (STATS && S.lane == 0) S.cVote++;
+    S.pfVote++;
+    bool ovfAny;
+    if (S.nWaves > 1 && nList >= S.nWaves) {
+        // wake the helper wavefronts: they walk their share of the voters while this wave walks its own
+        if (S.lane == 0) {
+            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u);
+            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_OVF] = 0;
+            S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
+        }
+        __syncthreads();
+        const bool mine = lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, S.nWaves);
+        __syncthreads();
+        ovfAny = mine || S.mail[LCB_MAIL_OVF] != 0;
+        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; }
+        LCB_WAVE_SYNC();
+        if (STATS && S.lane == 0) *S.mailWalk = 0;
+    } else {
+        ovfAny = lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
+    }
     LCB_WAVE_SYNC();
     uint32_t nTouched = *S.vNTouched;
-    if (__ballot(ovf) || nTouched > touchedCap) { S.status = LCB_ST_VOTE_OVF; if (nTouched > touchedCap) nTouched = touchedCap; }
+    if (ovfAny || nTouched > touchedCap) { S.status = LCB_ST_VOTE_OVF; if (nTouched > touchedCap) nTouched = touchedCap; }
     // order-free arg-max: max count; ties -> smallest origin (strand, g) of the last contributing
     // instance; ties -> earliest step.  key = (positive << 63) | (g0 << 31 >> ...) packed below.
     uint32_t bestCount = 0, bestSlot = 0xFFFFFFFFu;
@@ -862,7 +897,8 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
-template <int MODE, bool STATS>
+// NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
+template <int MODE, bool STATS, int NW>
 __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P, const LcbKSeed* seeds, uint32_t nSeeds,
                                         const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                         uint2* fpArena, unsigned long long fpCap)
@@ -882,6 +918,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     __shared__ uint32_t sBloom[LCB_BLOOM_WORDS];
     __shared__ uint32_t sScr[4 * 64];
     __shared__ uint32_t sMisc[4];
+    __shared__ uint32_t sMail[LCB_MAIL_WORDS];
+    __shared__ unsigned long long sMailWalk[1];
 
     LcbState S;
     S.T = T; S.P = P;
@@ -921,12 +959,36 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.iHi = instBase + 6 * S.instCap; S.iFlags = instBase + 7 * S.instCap;
     S.iFrontDist = (int32_t*)(instBase + 8 * S.instCap); S.iBackDist = (int32_t*)(instBase + 9 * S.instCap);
     S.scr = sScr; S.vNTouched = &sMisc[0];
-    S.dbg = W.dbg ? W.dbg + 16u * blockIdx.x : nullptr;
+    S.mail = sMail; S.mailWalk = sMailWalk; S.nWaves = NW;
+    const uint32_t waveId = threadIdx.x >> 6;
+    S.dbg = (W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     LCB_MARK(S, 0, 1);
-    if (S.lane == 0) sMisc[0] = 0;
+    if (S.lane == 0) { sMisc[0] = 0; sMail[LCB_MAIL_CMD] = 0; sMail[LCB_MAIL_OVF] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0;
     S.rightFlank = S.leftFlank = 0;
+    S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
+    S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;
     LCB_WAVE_SYNC();
+    if (NW > 1) {
+        __syncthreads();           // the LDS tables above were initialised (redundantly) by every wave
+        if (waveId != 0) {
+            // helper wavefront: sleeps at the barrier until wave 0 posts a vote, walks its share of the voters
+            for (;;) {
+                __syncthreads();
+                if (S.mail[LCB_MAIL_CMD] == LCB_CMD_EXIT) return;
+                const uint32_t flags = S.mail[LCB_MAIL_FLAGS];
+                S.cWalk = 0;
+                const bool ovf = lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, S.mail[LCB_MAIL_NLIST],
+                                                      (int32_t)S.mail[LCB_MAIL_FLANK], waveId, NW);
+                if (ovf && S.lane == 0) atomicOr(&S.mail[LCB_MAIL_OVF], 1u);
+                if (STATS) {
+                    const unsigned long long w = (unsigned long long)lcb_wave_sum((int64_t)S.cWalk);
+                    if (S.lane == 0 && w) atomicAdd(S.mailWalk, w);
+                }
+                __syncthreads();
+            }
+        }
+    }
 
     for (;;) {
         uint32_t s = 0;
@@ -981,6 +1043,10 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             out[s] = o;
         }
         LCB_MARK(S, 2, 6);
+    }
+    if (NW > 1) {                  // release the helper wavefronts
+        if (S.lane == 0) S.mail[LCB_MAIL_CMD] = LCB_CMD_EXIT;
+        __syncthreads();
     }
     LCB_MARK(S, 0, 2);
 }

@@ -1,10 +1,16 @@
 // emu_runtime.cpp — TEST-ONLY lockstep wavefront emulator (see tests/emu/hip/hip_runtime.h).
-// 64 coroutine lanes per wavefront on one OS thread; x86-64 System V only.
+// A workgroup of nWaves x 64 coroutine lanes on one OS thread; x86-64 System V only.
+//
+// Wave-level cross-lane operations (__ballot/__shfl/wave barrier) complete when all 64 lanes of THAT wave have
+// arrived at the same call site; __syncthreads completes when every live lane of the workgroup has arrived.
+// Scheduling is deliberately maximally skewed: wave 0 runs until it is blocked at a workgroup barrier (or done) before
+// wave 1 gets to run at all, and so on — which is the schedule most likely to expose a missing barrier.
 #include "emu_runtime.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "hip/hip_runtime.h"
 
@@ -34,100 +40,142 @@ emu_switch:
 
 namespace {
 
-constexpr int kLanes = 64;
+constexpr int kWave = 64;
 constexpr size_t kStack = 512 * 1024;
 
 struct Lane {
     void* sp = nullptr;
     char* stack = nullptr;
-    bool done = true;
+    bool done = true, parked = false;
     int kind = 0, arg = 0, line = 0;
     const char* file = nullptr;
     uint64_t value = 0, result = 0;
 };
 
-struct Wave {
-    Lane lane[kLanes];
+struct Block {
+    std::vector<Lane> lane;
     void* schedSp = nullptr;
-    int current = 0;
+    int current = 0, nWaves = 1;
     uint32_t block = 0;
     std::function<void()> body;
     uint64_t collectives = 0;
 };
 
-Wave g_wave;
+Block g_blk;
 
 void laneEntry()
 {
-    g_wave.body();
-    Lane& l = g_wave.lane[g_wave.current];
+    g_blk.body();
+    Lane& l = g_blk.lane[g_blk.current];
     l.done = true;
-    emu_switch(&l.sp, g_wave.schedSp);
+    emu_switch(&l.sp, g_blk.schedSp);
     abort();   // a finished lane is never resumed
+}
+
+// Runs every runnable lane of wave w until it parks or finishes. Returns true if any lane ran.
+bool sweepWave(int w)
+{
+    bool ran = false;
+    for (int i = w * kWave; i < (w + 1) * kWave; i++) {
+        Lane& l = g_blk.lane[i];
+        if (l.done || l.parked) continue;
+        g_blk.current = i;
+        emu_switch(&g_blk.schedSp, l.sp);
+        ran = true;
+    }
+    return ran;
+}
+
+// Completes wave w's pending wave-level operation if all its live lanes are parked at it.
+// Returns: 0 nothing to do, 1 completed an op, 2 the wave is parked at a workgroup barrier, 3 the wave is done.
+int settleWave(int w)
+{
+    int first = -1, live = 0;
+    for (int i = w * kWave; i < (w + 1) * kWave; i++) {
+        Lane& l = g_blk.lane[i];
+        if (l.done) continue;
+        live++;
+        if (!l.parked) return 0;
+        if (first < 0) first = i;
+        else if (l.kind != g_blk.lane[first].kind || l.line != g_blk.lane[first].line || l.file != g_blk.lane[first].file) {
+            fprintf(stderr, "emu: divergent cross-lane operation in wave %d: lane %d at %s:%d (kind %d) vs lane %d at %s:%d (kind %d)\n", w, first,
+                    g_blk.lane[first].file, g_blk.lane[first].line, g_blk.lane[first].kind, i, l.file, l.line, l.kind);
+            abort();
+        }
+    }
+    if (!live) return 3;
+    if (live != kWave) {
+        fprintf(stderr, "emu: wave %d: %d lanes exited before a cross-lane operation at %s:%d\n", w, kWave - live, g_blk.lane[first].file, g_blk.lane[first].line);
+        abort();
+    }
+    const int kind = g_blk.lane[first].kind;
+    if (kind == EMU_BARRIER) return 2;
+    g_blk.collectives++;
+    Lane* L = &g_blk.lane[w * kWave];
+    if (kind == EMU_BALLOT) {
+        uint64_t m = 0;
+        for (int i = 0; i < kWave; i++) if (L[i].value) m |= 1ull << i;
+        for (int i = 0; i < kWave; i++) L[i].result = m;
+    } else if (kind == EMU_SHFL) {
+        for (int i = 0; i < kWave; i++) L[i].result = L[L[i].arg & 63].value;
+    } else {
+        for (int i = 0; i < kWave; i++) L[i].result = 0;
+    }
+    for (int i = 0; i < kWave; i++) L[i].parked = false;
+    return 1;
 }
 
 }  // namespace
 
-EmuDim3 emu_thread_idx() { return EmuDim3{(uint32_t)g_wave.current, 0, 0}; }
-EmuDim3 emu_block_idx() { return EmuDim3{g_wave.block, 0, 0}; }
+EmuDim3 emu_thread_idx() { return EmuDim3{(uint32_t)g_blk.current, 0, 0}; }
+EmuDim3 emu_block_idx() { return EmuDim3{g_blk.block, 0, 0}; }
 
 uint64_t emu_collective(int kind, uint64_t value, int arg, const char* file, int line)
 {
-    Lane& l = g_wave.lane[g_wave.current];
-    l.kind = kind; l.value = value; l.arg = arg; l.file = file; l.line = line;
-    emu_switch(&l.sp, g_wave.schedSp);
+    Lane& l = g_blk.lane[g_blk.current];
+    l.kind = kind; l.value = value; l.arg = arg; l.file = file; l.line = line; l.parked = true;
+    emu_switch(&l.sp, g_blk.schedSp);
     return l.result;
 }
 
-uint64_t emu_collective_count() { return g_wave.collectives; }
+uint64_t emu_collective_count() { return g_blk.collectives; }
 
-void emu_run_wave(uint32_t blockId, const std::function<void()>& body)
+void emu_run_block(uint32_t blockId, int nWaves, const std::function<void()>& body)
 {
-    Wave& w = g_wave;
-    w.body = body; w.block = blockId;
-    for (int i = 0; i < kLanes; i++) {
-        Lane& l = w.lane[i];
+    Block& b = g_blk;
+    b.body = body; b.block = blockId; b.nWaves = nWaves;
+    if ((int)b.lane.size() < nWaves * kWave) b.lane.resize((size_t)nWaves * kWave);
+    for (int i = 0; i < nWaves * kWave; i++) {
+        Lane& l = b.lane[i];
         if (!l.stack) l.stack = (char*)aligned_alloc(64, kStack);
         uint64_t* top = (uint64_t*)(((uintptr_t)(l.stack + kStack) & ~(uintptr_t)15) - 64);
         memset(top, 0, 64);
         top[6] = (uint64_t)(uintptr_t)&laneEntry;    // popped by `ret` after the six callee-saved registers
-        l.sp = top; l.done = false; l.kind = 0;
+        l.sp = top; l.done = false; l.parked = false; l.kind = 0;
     }
     for (;;) {
-        int live = 0;
-        for (int i = 0; i < kLanes; i++) {
-            if (w.lane[i].done) continue;
-            w.current = i;
-            emu_switch(&w.schedSp, w.lane[i].sp);
-            if (!w.lane[i].done) live++;
-        }
-        if (!live) break;
-        // all live lanes are parked at a cross-lane operation: it must be the same one
-        int first = -1;
-        for (int i = 0; i < kLanes; i++) {
-            if (w.lane[i].done) continue;
-            if (first < 0) first = i;
-            else if (w.lane[i].kind != w.lane[first].kind || w.lane[i].line != w.lane[first].line || w.lane[i].file != w.lane[first].file) {
-                fprintf(stderr, "emu: divergent cross-lane operation: lane %d at %s:%d (kind %d) vs lane %d at %s:%d (kind %d)\n", first,
-                        w.lane[first].file, w.lane[first].line, w.lane[first].kind, i, w.lane[i].file, w.lane[i].line, w.lane[i].kind);
-                abort();
+        // run each wave as far as it can go on its own (maximal skew between waves)
+        int atBarrier = 0, done = 0;
+        for (int w = 0; w < nWaves; w++) {
+            for (;;) {
+                sweepWave(w);
+                const int r = settleWave(w);
+                if (r == 1) continue;          // a wave-level op completed: keep running this wave
+                if (r == 2) atBarrier++;
+                if (r == 3) done++;
+                break;                          // 0 cannot happen after a full sweep; 2/3: blocked or finished
             }
         }
-        if (live != kLanes) {
-            // a lane returned from the kernel while others still communicate: the kernels under test never do that
-            fprintf(stderr, "emu: %d lanes exited before a cross-lane operation at %s:%d\n", kLanes - live, w.lane[first].file, w.lane[first].line);
-            abort();
+        if (done == nWaves) break;
+        if (atBarrier + done == nWaves && atBarrier > 0) {
+            // __syncthreads: every live wave has arrived (exited waves no longer take part)
+            b.collectives++;
+            for (int i = 0; i < nWaves * kWave; i++) if (!b.lane[i].done) { b.lane[i].parked = false; b.lane[i].result = 0; }
+            continue;
         }
-        w.collectives++;
-        const int kind = w.lane[first].kind;
-        if (kind == EMU_BALLOT) {
-            uint64_t m = 0;
-            for (int i = 0; i < kLanes; i++) if (w.lane[i].value) m |= 1ull << i;
-            for (int i = 0; i < kLanes; i++) w.lane[i].result = m;
-        } else if (kind == EMU_SHFL) {
-            for (int i = 0; i < kLanes; i++) w.lane[i].result = w.lane[w.lane[i].arg & 63].value;
-        } else {
-            for (int i = 0; i < kLanes; i++) w.lane[i].result = 0;
-        }
+        fprintf(stderr, "emu: deadlock (%d waves at a workgroup barrier, %d done, %d total)\n", atBarrier, done, nWaves);
+        abort();
     }
 }
+
+void emu_run_wave(uint32_t blockId, const std::function<void()>& body) { emu_run_block(blockId, 1, body); }

@@ -31,14 +31,15 @@ EmuDim3 emu_block_idx();
 #define threadIdx (emu_thread_idx())
 #define blockIdx (emu_block_idx())
 
-enum EmuKind { EMU_BALLOT = 1, EMU_SHFL = 2, EMU_SYNC = 3 };
+enum EmuKind { EMU_BALLOT = 1, EMU_SHFL = 2, EMU_SYNC = 3, EMU_BARRIER = 4 };
 uint64_t emu_collective(int kind, uint64_t value, int arg, const char* file, int line);
 
 #define __ballot(p) ((unsigned long long)emu_collective(EMU_BALLOT, (p) ? 1u : 0u, 0, __FILE__, __LINE__))
 #define __shfl(v, src) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)((src) & 63), __FILE__, __LINE__))
-#define __shfl_xor(v, m) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)((emu_thread_idx().x ^ (uint32_t)(m)) & 63), __FILE__, __LINE__))
+#define __shfl_xor(v, m) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)(((emu_thread_idx().x & 63u) ^ (uint32_t)(m)) & 63), __FILE__, __LINE__))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)emu_collective(EMU_SYNC, 0, 0, __FILE__, __LINE__))
+#define __syncthreads() ((void)emu_collective(EMU_BARRIER, 0, 0, __FILE__, __LINE__))
 
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 template <class T_> static inline void __hip_atomic_store(T_* p, T_ v, int, int) { *p = v; }
@@ -53,6 +54,7 @@ static inline int atomicCAS(int* a, int cmp, int val) { int old = *a; if (old ==
 static inline uint32_t atomicAdd(uint32_t* a, uint32_t v) { uint32_t old = *a; *a = old + v; return old; }
 static inline unsigned long long atomicAdd(unsigned long long* a, unsigned long long v) { unsigned long long old = *a; *a = old + v; return old; }
 static inline unsigned long long atomicMax(unsigned long long* a, unsigned long long v) { unsigned long long old = *a; if (v > old) *a = v; return old; }
+static inline unsigned long long atomicAdd(unsigned long long* a, long long v) { unsigned long long old = *a; *a = old + (unsigned long long)v; return old; }
 static inline uint32_t atomicOr(uint32_t* a, uint32_t v) { uint32_t old = *a; *a = old | v; return old; }
 
 #endif
