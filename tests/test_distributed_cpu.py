@@ -1,0 +1,54 @@
+"""world_size-2 test of the multi-rank path on CPU (gloo): the native round engine with seeds dealt across ranks, results
+all-gathered through torch.distributed, identical commit on every rank. A TEST stand-in built on the oracle plays the
+per-rank device; the sharding / gather / commit code is exactly what runs with RCCL on GPUs."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch.distributed as dist
+import sibeliaz_amd
+from sibeliaz_amd import parallel
+from conftest import Case
+from test_host_cpu import OracleProcessor
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+case = Case(%(name)r, %(tmp)r)
+st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
+hooks, keep = parallel.make_hooks(rank, world, processor=OracleProcessor(case, st), round_phases=%(rounds)d)
+finder = sibeliaz_amd.BlocksFinder(st, case.k)
+blocks = finder.FindBlocks(case.m, case.b, hooks=hooks, threads=2)
+got = "".join("%%d\t%%d\t%%d\t%%d\n" %% (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+assert got == case.golden("pretrim.tsv"), "rank %%d: blocks differ from the reference" %% rank
+assert finder.stats["exchanges"] > 0
+print("rank", rank, "ok", finder.stats["rounds"], finder.stats["exchanges"], flush=True)
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("name,rounds", [("inv_k25", 4), ("twogenomes", 64)])
+def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Case
+    Case(name, str(tmp_path))            # unpack the fixture once, before the ranks start
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT, name=name, tmp=str(tmp_path), rounds=rounds))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count(" ok ") == 2

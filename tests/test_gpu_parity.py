@@ -119,6 +119,21 @@ def test_find_blocks_matches_reference(built, case, tmp_path):
     assert blocks.tobytes() == blocks2.tobytes()
 
 
+@pytest.mark.parametrize("fixed,phases", [("1", "1"), ("1", "7"), ("0", "64")])
+def test_round_engine_variants_on_gpu(built, case, fixed, phases, monkeypatch):
+    """Round size must not change the result: one phase per launch (the reference's schedule), a fixed speculative round of
+    7 phases, and the adaptive default all give the reference's block list."""
+    monkeypatch.setenv("LCB_ROUND_FIXED", fixed)
+    monkeypatch.setenv("LCB_ROUND_PHASES", phases)
+    st, p, dev = _setup(case)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"])
+
+
 def test_cli_drop_in(built, case, tmp_path):
     """The sibeliaz-lcb executable with the wrapper's argv (sibeliaz:146) writes the reference's blocks_coords.gff."""
     out = str(tmp_path / "cli")

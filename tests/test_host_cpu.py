@@ -1,0 +1,151 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports everything include/lcb.h declares, the host code (SoA loader,
+seed enumeration, ordered commit, round engine, output) matches the oracle / the reference goldens, and the kernel LOGIC
+passes under the wavefront emulator. No compute call reaches the HIP kernels here."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import sibeliaz_amd
+from sibeliaz_amd import parallel
+from tests.oracle_binding import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = sibeliaz_amd.load_library()
+    header = open(os.path.join(ROOT, "include", "lcb.h")).read()
+    declared = set(re.findall(r"\b(lcb_[a-z0-9_]+)\s*\(", header)) - {"lcb_reprocess_fn", "lcb_allgather_cb", "lcb_process_cb", "lcb_mark_cb", "lcb_reset_cb"}
+    assert declared, "no declarations parsed"
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(sibeliaz_amd.api.EXPORTS) <= declared
+
+
+def test_device_fails_loudly_without_gpu(built, case):
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    with pytest.raises(sibeliaz_amd.LcbError, match="no CPU fallback"):
+        sibeliaz_amd.Device(st, sibeliaz_amd.Params.make(case.k, case.b, case.m))
+
+
+def test_tables_and_seeds_match_oracle(built, case):
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 4, case.a)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    seeds = st.seeds(4)
+    ref = orc.seeds()
+    assert len(seeds) == len(ref)
+    got = [(int(s["vid"]), int(s["ch"]), int(s["count"]), int(s["rank"]), int(s["resolve_pos"]), int(s["resolve_chr"])) for s in seeds]
+    assert got == ref
+    text = "".join("%d\t%d\t%d\t%d\t%d\t%d\n" % t for t in got)
+    assert hashlib.sha256(text.encode()).hexdigest() == case.meta["sha256"]["bundles.tsv"]     # the REAL reference's sorted bundle_
+
+
+def test_loader_errors(built, case, tmp_path):
+    with pytest.raises(sibeliaz_amd.LcbError, match="Can't read the input file"):
+        sibeliaz_amd.JunctionStorage(str(tmp_path / "missing.bin"), [case.fasta], case.k, 1, case.a)
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n")
+    with pytest.raises(sibeliaz_amd.LcbError, match="should start with a '>'"):
+        sibeliaz_amd.JunctionStorage(case.graph, [str(bad)], case.k, 1, case.a)
+    with pytest.raises(sibeliaz_amd.LcbError, match="must be odd"):
+        sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], 16, 1, case.a)
+
+
+def test_output_stage_matches_reference(built, case, tmp_path):
+    """GenerateOutput + GFF writer on the reference's own pre-trim block instances -> the reference's GFF, byte for byte."""
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
+    rows = [tuple(int(x) for x in ln.split("\t")) for ln in case.golden("pretrim.tsv").splitlines()]
+    blocks = np.array(rows, dtype=sibeliaz_amd.BLOCK_DTYPE) if rows else np.zeros(0, dtype=sibeliaz_amd.BLOCK_DTYPE)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    finder.params = sibeliaz_amd.Params.make(case.k, case.b, case.m)
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    finder.GenerateOutput(str(tmp_path / "o"), blocks=blocks, blocks_found=int(summary["blocksFound"]))
+    assert open(str(tmp_path / "o" / "blocks_coords.gff")).read() == case.golden("ref.gff")
+
+
+class OracleProcessor:
+    """TEST stand-in for the device: per-seed results from the CPU oracle (never used by the product)."""
+
+    def __init__(self, case, storage):
+        self.case = case
+        self.orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+        self.chr_start = storage.chr_start()
+        self.stride = self.orc.L.orc_used_stride()
+
+    def process(self, seeds):
+        off = np.zeros(len(seeds) + 1, dtype="<u8")
+        rows = []
+        for i in range(len(seeds)):
+            r, _ = self.orc.process_seed(self.case.k, self.case.b, self.case.m, int(seeds["vid"][i]), int(seeds["ch"][i]))
+            rows += [(c, f, b, 1 if p else 0) for (c, f, b, p) in r]
+            off[i + 1] = len(rows)
+        return off, np.array(rows, dtype=sibeliaz_amd.INSTANCE_DTYPE) if rows else np.zeros(0, dtype=sibeliaz_amd.INSTANCE_DTYPE)
+
+    def mark(self, ranges):
+        for lo, hi in np.asarray(ranges, dtype=np.uint64).reshape(-1, 2):
+            c = int(np.searchsorted(self.chr_start, lo, side="right") - 1)
+            n = self.orc.L.orc_chr_n_pos(self.orc.h, c)
+            raw = (C.c_uint8 * (n * self.stride)).from_address(self.orc.L.orc_chr_used(self.orc.h, c))
+            for q in range(int(lo), int(hi)):
+                raw[(q - int(self.chr_start[c])) * self.stride] = 1
+
+    def reset(self):
+        self.orc.reset_used()
+
+
+@pytest.mark.parametrize("round_phases", [1, 5])
+def test_round_engine_with_callback_processor(built, case, round_phases):
+    """engine.cpp (rounds, invalidation, batched conflicts, ordered commit) driven through lcb_find_blocks_ex with a callback
+    engine: must reproduce the reference's pre-trim block list exactly."""
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
+    hooks, keep = parallel.make_hooks(processor=OracleProcessor(case, st), round_phases=round_phases)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, hooks=hooks, threads=2)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+
+
+def test_cli_usage_errors(built, case, tmp_path):
+    exe = os.path.join(ROOT, "sibeliaz_amd", "bin", "sibeliaz-lcb")
+    r = subprocess.run([exe, case.fasta, "-k", "15"], capture_output=True, text=True)
+    assert r.returncode == 1 and "graph" in r.stderr
+    r = subprocess.run([exe, "--graph", case.graph, case.fasta, "-k", "16"], capture_output=True, text=True)
+    assert r.returncode == 1 and "odd" in r.stderr
+    r = subprocess.run([exe, "--graph", str(tmp_path / "nope.bin"), case.fasta, "-k", "15"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("error: ") and r.stdout.startswith("Loading the graph...")
+
+
+EMU = os.path.join(ROOT, "tests", "emu", "build", "emu_check")
+
+
+@pytest.fixture(scope="session")
+def emu_built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    return EMU
+
+
+@pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64"})])
+def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode, env, tmp_path):
+    """The unmodified device code of lcb_kernel.h on the CPU wavefront emulator (tests/emu) vs the oracle: per-seed results,
+    event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
+    from conftest import Case
+    c = Case(name, case_dir)
+    r = subprocess.run([emu_built, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    if mode == "find":
+        assert open(str(tmp_path / "emu" / "blocks_coords.gff")).read() == c.golden("ref.gff")
