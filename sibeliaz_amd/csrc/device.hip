@@ -333,6 +333,7 @@ void lcb_device_reset_used_impl(lcb_device* h)
 {
     lcb_device_impl* d = h->impl;
     d->use();
+    d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
     HIP_CHECK(hipMemsetAsync(d->dUsed, 0, d->usedWords * 4, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
 }

@@ -573,6 +573,61 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     return bestVid;
 }
 
+// The table reads one push needs about the walked edge, loadable one step ahead of the push itself.
+struct LcbStep { int32_t idIt, idN; uint32_t posIt, posN; int32_t ech; };
+
+template <bool BACK>
+__device__ __forceinline__ LcbStep lcb_load_step(const LcbTables& T, uint32_t gIt, bool itPositive)
+{
+    const uint32_t gN = BACK ? (itPositive ? gIt + 1 : gIt - 1) : (itPositive ? gIt - 1 : gIt + 1);
+    LcbStep st;
+    st.idIt = T.posId[gIt]; st.idN = T.posId[gN]; st.posIt = T.posPos[gIt]; st.posN = T.posPos[gN];
+    // e.GetChar(): outgoing -> char at gIt, ingoing -> char at the previous position gN (junctionstorage.h:191-227)
+    st.ech = (int32_t)lcb_it_char(T, BACK ? gIt : gN, itPositive);
+    return st;
+}
+
+// One occurrence of the pushed vertex: its record plus the three `used` words around it, so that IsUsed and (almost
+// always) the Compatible gap test need no further global loads.
+struct LcbOcc { uint4 rec; uint32_t lo, wbase, uw0, uw1, uw2; };
+
+__device__ __forceinline__ LcbOcc lcb_load_occ(const LcbTables& T, uint32_t j, bool active)
+{
+    LcbOcc o;
+    o.rec = uint4{0u, 0u, 0u, 0u}; o.lo = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
+    if (active) {
+        o.rec = T.occRec[j];
+        o.lo = T.chrStart[o.rec.y];
+        const uint32_t wi = o.rec.x >> 5;
+        o.wbase = wi ? wi - 1 : 0;
+        o.uw0 = T.used[o.wbase]; o.uw1 = T.used[o.wbase + 1]; o.uw2 = T.used[o.wbase + 2];
+    }
+    return o;
+}
+
+__device__ __forceinline__ bool lcb_occ_bit(const LcbOcc& o, uint32_t g)
+{
+    const uint32_t w = (g >> 5) - o.wbase;                // 0..2 for g and g-1
+    const uint32_t word = w == 0 ? o.uw0 : (w == 1 ? o.uw1 : o.uw2);
+    return (word >> (g & 31)) & 1u;
+}
+
+// lcb_range_any_used over [a, b), served from the cached words when the range lies inside them.
+__device__ inline bool lcb_range_any_used_c(const LcbTables& T, const LcbOcc& o, uint32_t a, uint32_t b)
+{
+    if (a >= b) return false;
+    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(T.used, a, b);
+    bool any = false;
+    for (uint32_t w = wa; w <= wb; w++) {
+        uint32_t word = (w - o.wbase) == 0 ? o.uw0 : ((w - o.wbase) == 1 ? o.uw1 : o.uw2);
+        if (w == wa) word &= 0xFFFFFFFFu << (a & 31);
+        if (w == wb) word &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+        any = any || word != 0;
+    }
+    return any;
+}
+
 // ---- a push: PointPushBack / PointPushFront with their workers (path.h:430-602) ------------------
 // Per-occurrence outcomes.
 #define LCB_ACT_NONE 0u
@@ -585,26 +640,25 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
 template <bool BACK, bool STATS>
-__device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool record)
+__device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool record, const LcbStep& st)
 {
     const LcbTables& T = S.T;
-    // the neighbouring position along the iterator's strand
-    const uint32_t gN = BACK ? (itPositive ? gIt + 1 : gIt - 1) : (itPositive ? gIt - 1 : gIt + 1);
-    const int32_t idN = T.posId[gN], idIt = T.posId[gIt];
-    const int32_t vertex = itPositive ? idN : -idN;                  // pushed vertex
-    const int32_t otherVertex = itPositive ? idIt : -idIt;           // e.GetEndVertex() for a front push
+    const int32_t vertex = itPositive ? st.idN : -st.idN;            // pushed vertex
+    const int32_t otherVertex = itPositive ? st.idIt : -st.idIt;     // e.GetEndVertex() for a front push
+    // the CSR lookup is issued before the path-set probe so that the two global round trips overlap
+    const uint32_t av = (uint32_t)(vertex < 0 ? -vertex : vertex);
+    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
     if (lcb_path_contains_p(S, vertex)) return false;
-    const uint32_t length = lcb_absdiff(T.posPos[gN], T.posPos[gIt]);
-    // e.GetChar(): outgoing -> char at gIt, ingoing -> char at the previous position gN (junctionstorage.h:191-227)
-    const int32_t ech = (int32_t)lcb_it_char(T, BACK ? gIt : gN, itPositive);
+    const uint32_t length = lcb_absdiff(st.posN, st.posIt);
+    const int32_t ech = st.ech;
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
     if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
     const int32_t distance = (int32_t)dist64;
+    // first chunk of occurrences: in flight while the vertex is published in the path set
+    LcbOcc occ = lcb_load_occ(T, o0 + S.lane, o0 + S.lane < o1);
     lcb_path_insert(S, vertex);
     if (S.status) return false;
 
-    const uint32_t av = (uint32_t)(vertex < 0 ? -vertex : vertex);
-    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
     const int64_t B = S.P.maxBranch;
     for (uint32_t base = o0; base < o1; base += 64) {
         const uint32_t j = base + S.lane;
@@ -615,13 +669,13 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         bool positive = false, usedS = false, usesP = false;
+        if (base != o0) occ = lcb_load_occ(T, j, active);
         if (active) {
             if (STATS) S.cOcc++;
-            const uint4 rec = T.occRec[j];
-            g = rec.x; chr = rec.y; pos = rec.z;
-            lo = T.chrStart[chr];
-            positive = ((int32_t)rec.w == vertex);                   // JunctionIterator::IsPositiveStrand
-            usedS = lcb_it_used(T, g, positive, lo);
+            g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
+            lo = occ.lo;
+            positive = ((int32_t)occ.rec.w == vertex);               // JunctionIterator::IsPositiveStrand
+            usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
             // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g
             uint32_t a = 0, b = n;
             while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
@@ -664,7 +718,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
                                 okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
                             }
                         }
-                        compat = okDist && !lcb_range_any_used(T.used, ga, gb);
+                        compat = okDist && !lcb_range_any_used_c(T, occ, ga, gb);
                     }
                 }
                 if (compat) {
@@ -817,12 +871,24 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
         const bool positive = (S.iFlags[oi] & LCB_FLAG_POS) != 0;
         uint32_t g = FORWARD ? S.iBackG[oi] : S.iFrontG[oi];
         const int dir = (FORWARD == positive) ? 1 : -1;
+        const uint32_t lo = S.iLo[oi], hi = S.iHi[oi];
+        // the walk from the origin to the chosen vertex reads consecutive positions: keep the position after the next
+        // one in flight, so a push never waits for its own edge data
+        struct At { int32_t id; uint32_t pos; int32_t ch; };
+        auto loadAt = [&](int64_t q) -> At {
+            At a; a.id = 0; a.pos = 0; a.ch = 0;
+            if (q >= (int64_t)lo && q < (int64_t)hi) { a.id = T.posId[q]; a.pos = T.posPos[q]; a.ch = (int32_t)lcb_it_char(T, (uint32_t)q, positive); }
+            return a;
+        };
+        At cur = loadAt(g), nxt = loadAt((int64_t)g + dir);
         for (;;) {
-            const int32_t id = T.posId[g];
-            if ((positive ? id : -id) == next) break;
+            if ((positive ? cur.id : -cur.id) == next) break;
+            const At ahead = loadAt((int64_t)g + 2 * dir);
+            LcbStep st;
+            st.idIt = cur.id; st.idN = nxt.id; st.posIt = cur.pos; st.posN = nxt.pos; st.ech = FORWARD ? cur.ch : nxt.ch;
             LCB_MARK(S, 6, 3); LCB_MARK(S, 8, g);
             const uint64_t tp0 = wall_clock64();
-            success = lcb_push<FORWARD, STATS>(S, g, positive, true);
+            success = lcb_push<FORWARD, STATS>(S, g, positive, true, st);
             const uint64_t tp1 = wall_clock64();
             S.pfTPush += tp1 - tp0;
             LCB_MARK(S, 6, 4);
@@ -837,6 +903,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
                 S.pfTScore += wall_clock64() - tp1;
             }
             g = (uint32_t)((int64_t)g + dir);
+            cur = nxt; nxt = ahead;
         }
     }
     return success;
@@ -870,7 +937,8 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         lcb_path_init<STATS>(S, vid, ch);
         for (uint32_t i = 0; i < nEdge && !S.status; i++) {
             const unsigned long long b = S.body[i];
-            lcb_push<true, STATS>(S, (uint32_t)b, (b >> 32) != 0, false);
+            const LcbStep st = lcb_load_step<true>(S.T, (uint32_t)b, (b >> 32) != 0);
+            lcb_push<true, STATS>(S, (uint32_t)b, (b >> 32) != 0, false, st);
         }
     }
     LCB_MARK(S, 2, 4);
