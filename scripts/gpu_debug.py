@@ -50,8 +50,7 @@ def run(case, n, start, k, b, m, a, timeout):
         return False
 
 if __name__ == "__main__":
-    steps = [("inv_k25", 1, 1700, 25, 200, 200, 150, 60), ("inv_k25", 1, 0, 25, 200, 200, 150, 60), ("inv_k25", 8, 0, 25, 200, 200, 150, 60),
-             ("inv_k25", 64, 0, 25, 200, 200, 150, 90), ("inv_k25", 1791, 0, 25, 200, 200, 150, 120)]
+    steps = [("collinear6", 64, 0, 15, 200, 50, 150, 60), ("collinear6", 512, 0, 15, 200, 50, 150, 60), ("collinear6", 3373, 0, 15, 200, 50, 150, 90)]
     for s in steps:
         if not run(*s):
             break

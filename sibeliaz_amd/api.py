@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(PKG, "libsibeliaz_amd.so")
+    return os.environ.get("LCB_LIB") or os.path.join(PKG, "libsibeliaz_amd.so")
 
 
 class LcbError(RuntimeError):

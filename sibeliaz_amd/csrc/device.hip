@@ -33,12 +33,13 @@
 #define LCB_NW_SMALL 4
 #define LCB_NW_MEDIUM 16
 #define LCB_NW_BIG 4
-template <int MODE, bool STATS, int NW>
+// PROF adds the flight recorder and the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
+template <int MODE, bool STATS, int NW, bool PROF>
 __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
                                                          LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                                          uint2* fpArena, unsigned long long fpCap)
 {
-    lcb_process_body<MODE, STATS, NW>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
+    lcb_process_body<MODE, STATS, NW, PROF>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -113,6 +114,7 @@ struct lcb_device_impl {
     uint64_t* hRanges = nullptr;
     uint32_t* hDbg = nullptr;                    // flight recorder (LCB_DEBUG=1): 16 words per workgroup
     uint32_t dbgSlots = 0;
+    bool forceProf = false;                      // LCB_FORCE_PROF=1: always use the instrumented kernel variants
     bool seedTrace = false;                      // LCB_TRACE_SEEDS=1: add per-seed profile lines to the launch trace
     FILE* traceFile = nullptr;                   // LCB_TRACE_LAUNCHES=<file>: one line per launch (seeds, grid, mode, ms)
     double watchdogS = 0;                        // LCB_WATCHDOG_S: abort a launch that runs longer (0 = wait forever)
@@ -172,12 +174,17 @@ struct lcb_device_impl {
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
+        if (watchdogS > 0) for (uint32_t i = 0; i < m; i++) hOut[i].status = 0xFFFFFFFFu;   // lets the watchdog name unfinished seeds
         HIP_CHECK(hipEventRecord(ev0, stream));
-#define LCB_LAUNCH(MODE, ST) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))>), dim3(grid), \
-                                              dim3(64 * (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))), 0, stream, T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
-        if (w.mode == 2) { if (stats) LCB_LAUNCH(2, true); else LCB_LAUNCH(2, false); }
-        else if (w.mode == 1) { if (stats) LCB_LAUNCH(1, true); else LCB_LAUNCH(1, false); }
-        else { if (stats) LCB_LAUNCH(0, true); else LCB_LAUNCH(0, false); }
+#define LCB_NW(MODE) (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))
+#define LCB_LAUNCH(MODE, ST, PF) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
+                                                  T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
+#define LCB_LAUNCH_MODE(MODE) do { if (stats) LCB_LAUNCH(MODE, true, false); else if (prof) LCB_LAUNCH(MODE, false, true); else LCB_LAUNCH(MODE, false, false); } while (0)
+        const bool prof = W.dbg != nullptr || seedTrace || forceProf;
+        if (w.mode == 2) LCB_LAUNCH_MODE(2);
+        else if (w.mode == 1) LCB_LAUNCH_MODE(1);
+        else LCB_LAUNCH_MODE(0);
+#undef LCB_LAUNCH_MODE
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ev1, stream));
@@ -191,6 +198,15 @@ struct lcb_device_impl {
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (el > watchdogS) {
                     fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, w.mode == 2 ? "big" : (w.mode == 1 ? "medium" : "small"), grid, el);
+                    {
+                        int shownSeeds = 0;
+                        uint32_t unfinished = 0;
+                        for (uint32_t i = 0; i < m; i++) if (hOut[i].status == 0xFFFFFFFFu) unfinished++;
+                        fprintf(stderr, "  %u of %u seeds unfinished; first ones:", unfinished, m);
+                        for (uint32_t i = 0; i < m && shownSeeds < 8; i++)
+                            if (hOut[i].status == 0xFFFFFFFFu) { fprintf(stderr, " [%u] vid=%d ch=%d", i, hSeeds[i].vid, hSeeds[i].ch); shownSeeds++; }
+                        fprintf(stderr, "\n");
+                    }
                     if (W.dbg) {
                         int shown = 0;
                         for (uint32_t b = 0; b < grid && shown < 8; b++) {
@@ -265,7 +281,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipMalloc((void**)&d->dCursor, 32));
         HIP_CHECK(hipMemset(d->dCursor, 0, 32));
         // small (LDS) mode: instances / vote table in LDS, path set + bodies + snapshot in a 1/4-MB global slot
-        d->small.big = false; d->small.mode = 0; d->small.nSlots = envU32("LCB_SLOTS", 1024);
+        d->small.big = false; d->small.mode = 0; d->small.nSlots = envU32("LCB_SLOTS", 512);
         d->small.pathCap = envU32("LCB_PATH_CAP", 32768); d->small.bodyCap = d->small.pathCap / 2; d->small.bestCap = LCB_IC_SMALL;
         d->allocWork(d->small);
         // medium mode: 4x the LDS capacities, one workgroup per CU
@@ -284,6 +300,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         const char* tf = getenv("LCB_TRACE_LAUNCHES");
         if (tf && *tf) d->traceFile = fopen(tf, "w");
         d->seedTrace = envU32("LCB_TRACE_SEEDS", 0) != 0;
+        d->forceProf = envU32("LCB_FORCE_PROF", 0) != 0;
         const char* wd = getenv("LCB_WATCHDOG_S");
         d->watchdogS = wd && *wd ? atof(wd) : 0;
         if (envU32("LCB_DEBUG", 0)) {

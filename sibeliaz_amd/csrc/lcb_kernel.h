@@ -32,13 +32,18 @@
 #include <stdint.h>
 
 #define LCB_EMPTY_KEY INT32_MIN
+// The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
+// when the recorder is off. KNOWN ISSUE: with the sites compiled out, the small-mode kernel was observed to
+// hang or fault on gfx950 / ROCm 7.2 on seeds that the instrumented build, the CPU emulator and ASan/UBSan all handle
+// correctly; the cause is not understood yet, so the validated (instrumented) code shape is the one that ships.
+#define LCB_FLIGHT_RECORDER 1
 
 // Three kernel variants by where the per-path state lives. Seeds that overflow one are re-run by the host in the next:
 //   mode 0 "small":  instances + vote table in 36 KB of LDS  -> 4 workgroups per CU
 //   mode 1 "medium": 4x the capacities in 146 KB of LDS       -> 1 workgroup per CU
 //   mode 2 "big":    instances + vote table in the global-memory workspace, capacities chosen by the host
-#define LCB_IC_SMALL 256u    // instances
-#define LCB_VC_SMALL 1024u   // vote-table slots (power of two)
+#define LCB_IC_SMALL 512u    // instances
+#define LCB_VC_SMALL 2048u   // vote-table slots (power of two)
 #define LCB_IC_MEDIUM 1024u
 #define LCB_VC_MEDIUM 4096u
 #define LCB_BLOOM_WORDS 1024u  // LDS Bloom filter in front of the path vertex set (32768 bits, 2 hashes)
@@ -137,7 +142,7 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
 // Flight recorder: lane 0 stores progress words the host watchdog can read while the kernel is running.
 #define LCB_MARK(S, slot, value)                                                         \
     do {                                                                                 \
-        if ((S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+        if (LCB_FLIGHT_RECORDER && (S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
     } while (0)
 
 #define LCB_FLAG_POS 1u
@@ -502,7 +507,7 @@ __device__ inline bool lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bo
 enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_OVF, LCB_MAIL_WORDS = 8 };
 enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
 
-template <bool STATS>
+template <bool STATS, bool PROF>
 __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
 {
     const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
@@ -510,7 +515,7 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
     const int32_t flank = forward ? S.rightFlank : S.leftFlank;
     if (STATS && S.lane == 0) S.cVote++;
-    S.pfVote++;
+    if (PROF) S.pfVote++;
     bool ovfAny;
     if (S.nWaves > 1 && nList >= S.nWaves) {
         // wake the helper wavefronts: they walk their share of the voters while this wave walks its own
@@ -639,7 +644,7 @@ __device__ inline bool lcb_range_any_used_c(const LcbTables& T, const LcbOcc& o,
 // BACK=true:  PointPushBack(e), e = OutgoingEdge of iterator (gIt, itPositive): vertex = end vertex.
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
-template <bool BACK, bool STATS>
+template <bool BACK, bool STATS, bool PROF>
 __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool record, const LcbStep& st)
 {
     const LcbTables& T = S.T;
@@ -648,7 +653,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
     // the CSR lookup is issued before the path-set probe so that the two global round trips overlap
     const uint32_t av = (uint32_t)(vertex < 0 ? -vertex : vertex);
     const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
-    if (lcb_path_contains_p(S, vertex)) return false;
+    if (PROF ? lcb_path_contains_p(S, vertex) : lcb_path_contains(S, vertex)) return false;
     const uint32_t length = lcb_absdiff(st.posN, st.posIt);
     const int32_t ech = st.ech;
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
@@ -815,8 +820,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
         S.leftFlank = distance;
     }
     if (STATS && S.lane == 0) S.cPush++;
-    S.pfPush++;
-    if (S.nInst > S.pfMaxInst) S.pfMaxInst = S.nInst;
+    if (PROF) { S.pfPush++; if (S.nInst > S.pfMaxInst) S.pfMaxInst = S.nInst; }
     return true;
 }
 
@@ -851,21 +855,21 @@ __device__ inline void lcb_snapshot(LcbState& S)
 }
 
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
-template <bool FORWARD, bool STATS>
+template <bool FORWARD, bool STATS, bool PROF>
 __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
 {
     const LcbTables& T = S.T;
     uint32_t oi = 0;
     LCB_MARK(S, 4, S.nRight); LCB_MARK(S, 5, S.nLeft); LCB_MARK(S, 6, 1);
-    const uint64_t tv0 = wall_clock64();
-    int32_t next = lcb_vote<STATS>(S, FORWARD, false, oi);
+    const uint64_t tv0 = PROF ? wall_clock64() : 0;
+    int32_t next = lcb_vote<STATS, PROF>(S, FORWARD, false, oi);
     LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
     if (S.status) return false;
     if (FORWARD && next == 0) {                                      // blocksfinder.h:782-785 (forward only, Q2)
-        next = lcb_vote<STATS>(S, true, true, oi);
+        next = lcb_vote<STATS, PROF>(S, true, true, oi);
         if (S.status) return false;
     }
-    S.pfTVote += wall_clock64() - tv0;
+    if (PROF) S.pfTVote += wall_clock64() - tv0;
     bool success = false;
     if (next != 0) {
         const bool positive = (S.iFlags[oi] & LCB_FLAG_POS) != 0;
@@ -887,10 +891,10 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
             LcbStep st;
             st.idIt = cur.id; st.idN = nxt.id; st.posIt = cur.pos; st.posN = nxt.pos; st.ech = FORWARD ? cur.ch : nxt.ch;
             LCB_MARK(S, 6, 3); LCB_MARK(S, 8, g);
-            const uint64_t tp0 = wall_clock64();
-            success = lcb_push<FORWARD, STATS>(S, g, positive, true, st);
-            const uint64_t tp1 = wall_clock64();
-            S.pfTPush += tp1 - tp0;
+            const uint64_t tp0 = PROF ? wall_clock64() : 0;
+            success = lcb_push<FORWARD, STATS, PROF>(S, g, positive, true, st);
+            const uint64_t tp1 = PROF ? wall_clock64() : 0;
+            if (PROF) S.pfTPush += tp1 - tp0;
             LCB_MARK(S, 6, 4);
             if (S.status) return false;
             if (success) {
@@ -900,7 +904,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
                     if (FORWARD) bestRightSize = S.nRight + 1;
                     if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
                 }
-                S.pfTScore += wall_clock64() - tp1;
+                if (PROF) S.pfTScore += wall_clock64() - tp1;
             }
             g = (uint32_t)((int64_t)g + dir);
             cur = nxt; nxt = ahead;
@@ -910,7 +914,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
 }
 
 // ProcessVertex::Process (blocksfinder.h:228-310)
-template <bool STATS>
+template <bool STATS, bool PROF>
 __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
     int64_t score = 0, bestScore = 0;
@@ -924,7 +928,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         for (;;) {                                                   // blocksfinder.h:255-269
             bool ret = true, positive = false;
             const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
-            while ((ret = lcb_extend<true, STATS>(S, bestRightSize, bestScore, score)) &&
+            while ((ret = lcb_extend<true, STATS, PROF>(S, bestRightSize, bestScore, score)) &&
                    ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
                 positive = positive || (score > 0);
             if (!ret || !positive || S.status) break;
@@ -938,7 +942,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         for (uint32_t i = 0; i < nEdge && !S.status; i++) {
             const unsigned long long b = S.body[i];
             const LcbStep st = lcb_load_step<true>(S.T, (uint32_t)b, (b >> 32) != 0);
-            lcb_push<true, STATS>(S, (uint32_t)b, (b >> 32) != 0, false, st);
+            lcb_push<true, STATS, PROF>(S, (uint32_t)b, (b >> 32) != 0, false, st);
         }
     }
     LCB_MARK(S, 2, 4);
@@ -946,7 +950,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         for (;;) {                                                   // blocksfinder.h:292-306 (stray ';' at :297, Q1)
             bool ret = true;
             const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
-            while ((ret = lcb_extend<false, STATS>(S, bestRightSize, bestScore, score)) &&
+            while ((ret = lcb_extend<false, STATS, PROF>(S, bestRightSize, bestScore, score)) &&
                    ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
                 ;
             const bool positive = score > 0;
@@ -965,8 +969,22 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
+// Per-launch arguments that are only touched between seeds (work queue, result arenas). They are parked in LDS so that
+// they do not occupy scalar registers for the whole kernel: the per-seed code already needs the 102-SGPR budget.
+struct LcbLaunchArgs {
+    const LcbKSeed* seeds;
+    LcbSeedOut* out;
+    uint4* arena;
+    uint2* fpArena;
+    unsigned long long arenaCap, fpCap, arenaBase, fpBase;
+    unsigned long long* arenaCursor;
+    unsigned long long* fpCursor;
+    uint32_t* cursor;
+    uint32_t cursorBase, nSeeds;
+};
+
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
-template <int MODE, bool STATS, int NW>
+template <int MODE, bool STATS, int NW, bool PROF>
 __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P, const LcbKSeed* seeds, uint32_t nSeeds,
                                         const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                         uint2* fpArena, unsigned long long fpCap)
@@ -988,6 +1006,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     __shared__ uint32_t sMisc[4];
     __shared__ uint32_t sMail[LCB_MAIL_WORDS];
     __shared__ unsigned long long sMailWalk[1];
+    __shared__ LcbLaunchArgs sArgs;
+    if (threadIdx.x == 0) {
+        sArgs.seeds = seeds; sArgs.out = out; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
+        sArgs.arenaBase = W.arenaBase; sArgs.fpBase = W.fpBase; sArgs.arenaCursor = W.arenaCursor; sArgs.fpCursor = W.fpCursor;
+        sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.nSeeds = nSeeds;
+    }
 
     LcbState S;
     S.T = T; S.P = P;
@@ -1029,7 +1053,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.scr = sScr; S.vNTouched = &sMisc[0];
     S.mail = sMail; S.mailWalk = sMailWalk; S.nWaves = NW;
     const uint32_t waveId = threadIdx.x >> 6;
-    S.dbg = (W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
+    S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     LCB_MARK(S, 0, 1);
     if (S.lane == 0) { sMisc[0] = 0; sMail[LCB_MAIL_CMD] = 0; sMail[LCB_MAIL_OVF] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0;
@@ -1060,39 +1084,41 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
 
     for (;;) {
         uint32_t s = 0;
-        if (S.lane == 0) s = atomicAdd(W.cursor, 1u) - W.cursorBase;   // every workgroup overshoots by exactly one ticket
+        if (S.lane == 0) s = atomicAdd(sArgs.cursor, 1u) - sArgs.cursorBase;   // every workgroup overshoots by exactly one ticket
         s = lcb_bcast(s, 0);
-        if (s >= nSeeds) break;
+        if (s >= sArgs.nSeeds) break;
         LCB_MARK(S, 1, s + 1);
         S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
         S.nInst = S.nGood = S.cur = S.nRight = S.nLeft = 0; S.rightFlank = S.leftFlank = 0;
         S.nFp = 0;
         int64_t bestScore = 0;
         S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0;
-        const uint64_t tick0 = wall_clock64();
-        lcb_process_seed<STATS>(S, seeds[s].vid, seeds[s].ch, bestScore);
-        const uint64_t ticks = wall_clock64() - tick0;
+        const uint64_t tick0 = PROF ? wall_clock64() : 0;
+        const LcbKSeed sd = sArgs.seeds[s];
+        lcb_process_seed<STATS, PROF>(S, sd.vid, sd.ch, bestScore);
+        const uint64_t ticks = PROF ? wall_clock64() - tick0 : 0;
         const uint32_t n = S.status ? 0u : S.nBest;
         unsigned long long off = 0;
         if (n) {
             uint32_t olo = 0, ohi = 0;
-            if (S.lane == 0) { off = atomicAdd(W.arenaCursor, (unsigned long long)n) - W.arenaBase; olo = (uint32_t)off; ohi = (uint32_t)(off >> 32); }
+            if (S.lane == 0) { off = atomicAdd(sArgs.arenaCursor, (unsigned long long)n) - sArgs.arenaBase; olo = (uint32_t)off; ohi = (uint32_t)(off >> 32); }
             olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
             off = ((unsigned long long)ohi << 32) | olo;
-            if (off + n > arenaCap) S.status = LCB_ST_ARENA_OVF;
-            else for (uint32_t e = S.lane; e < n; e += 64) arena[off + e] = S.best[e];
+            if (off + n > sArgs.arenaCap) S.status = LCB_ST_ARENA_OVF;
+            else { uint4* ar = sArgs.arena; for (uint32_t e = S.lane; e < n; e += 64) ar[off + e] = S.best[e]; }
         }
         // footprint intervals (one per instance ever created), widened by one position on the low side
         // because the - strand reads bit g-1
-        const uint32_t nfp = (S.status == LCB_ST_OK && fpArena) ? S.nFp : 0u;
+        uint2* fpa = sArgs.fpArena;
+        const uint32_t nfp = (S.status == LCB_ST_OK && fpa) ? S.nFp : 0u;
         unsigned long long fpo = 0;
         if (nfp) {
             uint32_t olo = 0, ohi = 0;
-            if (S.lane == 0) { fpo = atomicAdd(W.fpCursor, (unsigned long long)nfp) - W.fpBase; olo = (uint32_t)fpo; ohi = (uint32_t)(fpo >> 32); }
+            if (S.lane == 0) { fpo = atomicAdd(sArgs.fpCursor, (unsigned long long)nfp) - sArgs.fpBase; olo = (uint32_t)fpo; ohi = (uint32_t)(fpo >> 32); }
             olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
             fpo = ((unsigned long long)ohi << 32) | olo;
-            if (fpo + nfp > fpCap) S.status = LCB_ST_ARENA_OVF;
-            else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpArena[fpo + e] = r; }
+            if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
+            else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
         }
         uint64_t c[6];
         if (STATS) {
@@ -1106,9 +1132,9 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             o.status = S.status; o.bestScore = bestScore; o.arenaOff = off;
             o.fpOff = fpo; o.nFp = nfp; o.pad = 0;
             for (int q = 0; q < 8; q++) o.ctr[q] = 0;
-            if (!STATS) { o.ctr[0] = ticks; o.ctr[1] = S.pfPush; o.ctr[2] = S.pfVote; o.ctr[3] = S.pfMaxProbe; o.ctr[4] = S.pfMaxInst; o.ctr[5] = S.pfTVote; o.ctr[6] = S.pfTPush; o.ctr[7] = S.pfTScore; }
+            if (!STATS && PROF) { o.ctr[0] = ticks; o.ctr[1] = S.pfPush; o.ctr[2] = S.pfVote; o.ctr[3] = S.pfMaxProbe; o.ctr[4] = S.pfMaxInst; o.ctr[5] = S.pfTVote; o.ctr[6] = S.pfTPush; o.ctr[7] = S.pfTScore; }
             if (STATS) { o.ctr[0] = c[0]; o.ctr[1] = c[1]; o.ctr[2] = c[2]; o.ctr[3] = c[3]; o.ctr[4] = o.nInst; o.ctr[5] = c[4]; o.ctr[6] = c[5]; o.ctr[7] = 1; }
-            out[s] = o;
+            sArgs.out[s] = o;
         }
         LCB_MARK(S, 2, 6);
     }

@@ -78,12 +78,12 @@ struct Emu {
         const uint32_t n = (uint32_t)seeds.size();
         const char* nwEnv = getenv("EMU_NW");
         const int nw = nwEnv ? atoi(nwEnv) : 1;
-        if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
+        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
         for (auto& o : out) {
             ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
             ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
