@@ -30,7 +30,7 @@
 
 // MODE 0/1/2 = small / medium / big (lcb_kernel.h): where the per-path instance pool and vote table live.
 // NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest help with the votes (lcb_kernel.h).
-#define LCB_NW_SMALL 4
+#define LCB_NW_SMALL 16
 #define LCB_NW_MEDIUM 16
 #define LCB_NW_BIG 4
 // PROF adds the flight recorder and the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.

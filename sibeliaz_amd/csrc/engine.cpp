@@ -10,7 +10,9 @@
 // computation is a deterministic function of the bits it read, so a speculative result equals the exact one iff no bit
 // inside its footprint (lcb_kernel.h: one position interval per instance ever created) has been set since the round
 // snapshot. While walking the round's phases in order, seeds whose footprint intersects the ranges marked since the
-// snapshot are recomputed — batched per phase, against the exact phase-start state — before that phase is committed.
+// snapshot are recomputed against the exact phase-start state before that phase is committed; the same launch eagerly
+// recomputes the invalidated seeds of the next few phases too, and every result carries the EPOCH (launch) that produced
+// it: it is valid at its phase iff nothing inside its footprint was marked in that epoch or any later one.
 // Conflicting seeds of a phase are re-processed in batches as well: all seeds that currently conflict are launched
 // together against the live state, and each of those results is used at its turn iff nothing inside its footprint was
 // marked in between (otherwise it is launched again). With world > 1 the round's seeds are dealt round-robin to the
@@ -91,6 +93,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     const char* fixedEnv = getenv("LCB_ROUND_FIXED");
     const bool fixedRound = fixedEnv && *fixedEnv && atoi(fixedEnv) != 0;
     int roundPhases = fixedRound ? maxRound : 1;
+    const char* eagerEnv = getenv("LCB_EAGER_PHASES");
+    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 64;
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
 
@@ -104,11 +108,11 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         proc.mark(pending.data(), (int64_t)(pending.size() / 2));
         pending.clear();
     };
-    RangeSet dirty;                                // marked since the round snapshot
+    std::vector<RangeSet> epochMarks;              // epochMarks[e]: ranges marked after launch e of this round and before launch e+1
     RangeSet dirtyBatch;                           // marked since the last conflict batch was launched
     auto takeMarks = [&]() {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
-            dirty.add(com.marks[i], com.marks[i + 1]);
+            epochMarks.back().add(com.marks[i], com.marks[i + 1]);
             dirtyBatch.add(com.marks[i], com.marks[i + 1]);
             pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]);
         }
@@ -124,13 +128,14 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<unsigned char> sendBuf, recvBuf;
     std::vector<int32_t> ovIdx;                     // per seed of the round: index into overrides or -1
     std::vector<Override> overrides;
+    std::vector<uint32_t> epochOf, checkedTo;       // per seed of the round: epoch of its current result / epochs already checked
     std::vector<int32_t> batchIdx;                  // per seed of the phase: conflict-batch result or -1
     std::vector<Override> batch;
 
     for (int64_t pos = 0; pos < nSeeds;) {
         const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
         flush();                                    // processor state == live state at the start of phase `pos`
-        dirty.clear();
+        epochMarks.assign(1, RangeSet());
         st.rounds++;
         // ---- speculative launch of the whole round (this rank's share) -------------------------------------------
         sub.clear();
@@ -179,28 +184,48 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         }
         ovIdx.assign((size_t)nRound, -1);
         overrides.clear();
+        epochOf.assign((size_t)nRound, 0);
+        checkedTo.assign((size_t)nRound, 0);
         const int64_t recomputedBefore = st.recomputedSeeds;
+        // is the current result of seed i still exact, i.e. was nothing inside its footprint marked since its launch?
+        auto stillValid = [&](int64_t i) -> bool {
+            const lcb_fp* f; size_t nf;
+            if (ovIdx[(size_t)i] >= 0) { const Override& o = overrides[(size_t)ovIdx[(size_t)i]]; f = o.fp.data(); nf = o.fp.size(); }
+            else { f = round.fp.data() + round.fpOff[i]; nf = (size_t)(round.fpOff[i + 1] - round.fpOff[i]); }
+            const uint32_t last = (uint32_t)epochMarks.size() - 1;
+            for (uint32_t e = std::max(epochOf[(size_t)i], checkedTo[(size_t)i]); e <= last; e++) {
+                if (epochMarks[e].empty()) continue;
+                for (size_t k = 0; k < nf; k++) if (epochMarks[e].hits(f[k].lo, f[k].hi)) return false;
+            }
+            checkedTo[(size_t)i] = last;            // closed epochs need no second look; the open one is re-checked
+            return true;
+        };
 
         // ---- walk the round's phases in order -----------------------------------------------------------------------
         for (int64_t ph = 0; ph < nRound; ph += phase) {
             const int64_t n = std::min<int64_t>(phase, nRound - ph);
-            // (a) exact phase-start results: recompute what the commits since the snapshot may have changed
-            if (!dirty.empty()) {
-                sub.clear();
+            // (a) exact phase-start results: recompute what earlier commits may have changed. If this phase has such
+            //     seeds, the launch also takes the currently invalid seeds of the next `eager` phases along.
+            {
                 std::vector<int64_t> which;
-                for (int64_t i = ph; i < ph + n; i++) {
-                    bool hit = false;
-                    for (uint64_t f = round.fpOff[i]; f < round.fpOff[i + 1] && !hit; f++) hit = dirty.hits(round.fp[f].lo, round.fp[f].hi);
-                    if (hit) { which.push_back(i); sub.push_back(seeds[pos + i]); }
-                }
+                for (int64_t i = ph; i < ph + n; i++) if (!stillValid(i)) which.push_back(i);
                 if (!which.empty()) {
+                    const int64_t lim = std::min<int64_t>(nRound, ph + n + (int64_t)eagerPhases * phase);
+                    for (int64_t i = ph + n; i < lim; i++) if (!stillValid(i)) which.push_back(i);
+                    sub.clear();
+                    for (int64_t i : which) sub.push_back(seeds[pos + i]);
                     flush();                        // == live state at the start of this phase
                     proc.process(sub.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
                     st.recomputeLaunches++; st.recomputedSeeds += (int64_t)which.size();
+                    epochMarks.emplace_back();      // marks from here on belong to the new epoch
+                    const uint32_t epoch = (uint32_t)epochMarks.size() - 1;
                     for (size_t k = 0; k < which.size(); k++) {
-                        ovIdx[(size_t)which[k]] = (int32_t)overrides.size();
-                        overrides.emplace_back();
-                        overrides.back().inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
+                        int32_t& slot = ovIdx[(size_t)which[k]];
+                        if (slot < 0) { slot = (int32_t)overrides.size(); overrides.emplace_back(); }
+                        Override& o = overrides[(size_t)slot];
+                        o.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
+                        o.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
+                        epochOf[(size_t)which[k]] = epoch; checkedTo[(size_t)which[k]] = epoch;
                     }
                 }
             }

@@ -517,7 +517,7 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     if (STATS && S.lane == 0) S.cVote++;
     if (PROF) S.pfVote++;
     bool ovfAny;
-    if (S.nWaves > 1 && nList >= S.nWaves) {
+    if (S.nWaves > 1 && nList >= 4) {
         // wake the helper wavefronts: they walk their share of the voters while this wave walks its own
         if (S.lane == 0) {
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u);
