@@ -41,3 +41,31 @@ if allp:
     big = sorted(allp, key=lambda d: -d["ticks"])[:5]
     for d in big:
         print("   slow seed vid=%d st=%d ticks=%.1f us push=%d vote=%d inst=%d  -> %.1f us/push" % (d["vid"], d["st"], d["ticks"] / 100.0, d["push"], d["vote"], d["inst"], d["ticks"] / 100.0 / max(1, d["push"])))
+
+# ---- per-launch critical path: how much of each launch is its longest seed vs the work spread over the slots
+if allp:
+    rows = []
+    for lid, (nn, md, t) in launch.items():
+        sd = seeds.get(lid, [])
+        if not sd:
+            rows.append((nn, t, 0.0, 0.0, md)); continue
+        tks = np.array([d["ticks"] for d in sd]) / 1e5          # ms
+        wgs = collections.defaultdict(float)
+        for d in sd:
+            wgs[d.get("wg", 0)] += d["ticks"] / 1e5
+        rows.append((nn, t, tks.max(), max(wgs.values()), md))
+    rows = np.array([(r[0], r[1], r[2], r[3]) for r in rows])
+    tot = rows[:, 1].sum()
+    print("critical path: sum of launch ms %.1f | sum of longest-seed ms %.1f (%.0f%%) | sum of busiest-workgroup ms %.1f (%.0f%%)" % (
+        tot, rows[:, 2].sum(), 100 * rows[:, 2].sum() / tot, rows[:, 3].sum(), 100 * rows[:, 3].sum() / tot))
+    for lo, hi in ((1, 1), (2, 16), (17, 256), (257, 4096), (4097, 1 << 30)):
+        sel = (rows[:, 0] >= lo) & (rows[:, 0] <= hi)
+        if sel.any():
+            print("  launches with %6d..%-10d seeds: %5d launches %8.1f ms  longest-seed %8.1f ms  busiest-wg %8.1f ms  mean ms %.3f" % (
+                lo, hi, sel.sum(), rows[sel, 1].sum(), rows[sel, 2].sum(), rows[sel, 3].sum(), rows[sel, 1].mean()))
+    ppu = np.array([d["ticks"] / 100.0 / d["push"] for d in allp if d["push"] >= 50])
+    ins = np.array([d["inst"] for d in allp if d["push"] >= 50])
+    for lo, hi in ((0, 8), (8, 32), (32, 64), (64, 128), (128, 256), (256, 100000)):
+        s = (ins >= lo) & (ins < hi)
+        if s.any():
+            print("  us/push for seeds with max inst in [%d,%d): n=%d median %.2f" % (lo, hi, s.sum(), np.median(ppu[s])))

@@ -1,19 +1,9 @@
-export LCB_WATCHDOG_S=12
-LCB_SLOTS=1 LCB_MEDIUM_SLOTS=1 LCB_BIG_SLOTS=1 LCB_LIB=$PWD/sibeliaz_amd/variants/plain_nw1.so timeout 60 python - <<'PY' 2>&1 | grep -v "^  File\|Extension modules" | tail -12
-import sys, os, gzip, time
-sys.path.insert(0, os.getcwd())
-import sibeliaz_amd
-d = "tests/golden/collinear6"
-fa, gr = "/tmp/c6.fa", "/tmp/c6.bin"
-for s, t in (("genomes.fa.gz", fa), ("graph.bin.gz", gr)):
-    open(t, "wb").write(gzip.open(os.path.join(d, s)).read())
-st = sibeliaz_amd.JunctionStorage(gr, [fa], 15, 4, 150)
-dev = sibeliaz_amd.Device(st, sibeliaz_amd.Params.make(15, 200, 50), 0)
-seeds = st.seeds(4)
-t = time.time()
-try:
-    off, inst, sc, _ = dev.process_seeds(seeds[:400])
-    print("completed")
-except Exception as e:
-    print("EXC", e)
-PY
+# full GPU suite + bench on a library variant next to the shipped one
+mkdir -p gpurun_out
+export LCB_WATCHDOG_S=20
+V=$PWD/sibeliaz_amd/variants/fr0_v0.so
+LCB_LIB=$V timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 100 -x -k "not cli" 2>&1 | tail -4
+for i in 1 2; do
+LCB_LIB=$V python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fr0', d['value'], d['ms_per_step'])"
+python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fr1', d['value'], d['ms_per_step'])"
+done

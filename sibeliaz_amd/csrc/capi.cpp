@@ -125,8 +125,8 @@ namespace {
 struct CallbackProcessor : LcbProcessor {
     const lcb_hooks* h;
     explicit CallbackProcessor(const lcb_hooks* hooks) : h(hooks) {}
-    void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
-                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    void process(const lcb_seed* seeds, const uint32_t*, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override      // no predicted views: maxViews() == 0
     {
         off.assign((size_t)n + 1, 0);
         uint64_t cap = inst.size() < 4096 ? 4096 : inst.size();

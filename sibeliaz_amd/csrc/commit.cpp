@@ -30,6 +30,15 @@ bool lcb_committer::anyUsed(uint64_t lo, uint64_t hi) const
     return false;
 }
 
+bool lcb_committer::allUsed(uint64_t lo, uint64_t hi) const
+{
+    for (uint64_t i = lo; i < hi;) {
+        if ((i & 31) == 0 && i + 32 <= hi) { if (used[i >> 5] != 0xFFFFFFFFu) return false; i += 32; }
+        else { if (!((used[i >> 5] >> (i & 31)) & 1u)) return false; i++; }
+    }
+    return true;
+}
+
 void lcb_committer::finalize(const lcb_instance* inst, uint64_t n)                       // blocksfinder.h:312-332
 {
     const int64_t currentBlock = ++blocksFound;

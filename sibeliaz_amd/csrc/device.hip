@@ -56,6 +56,17 @@ __global__ __launch_bounds__(256) void lcb_init_slots_kernel(uint8_t* base, uint
     for (uint32_t i = threadIdx.x; i < voteCap; i += blockDim.x) { vKey[i] = LCB_EMPTY_KEY; vCount[i] = 0; vLast[i] = 0; }
 }
 
+// Predicted views 1..nViews of the `used` bitmap start as copies of the live state (view 0); stride is a multiple of 4 words.
+__global__ __launch_bounds__(256) void lcb_copy_views_kernel(uint32_t* used, uint32_t strideWords, uint32_t nViews)
+{
+    const uint4* src = (const uint4*)used;
+    const uint32_t n4 = strideWords / 4;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        for (uint32_t w = 1; w <= nViews; w++) ((uint4*)(used + (size_t)w * strideWords))[i] = v;
+    }
+}
+
 // MarkUsed over [lo, hi) (junctionstorage.h:285-295): one workgroup per range.
 __global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const uint64_t* ranges, uint32_t n)
 {
@@ -100,7 +111,8 @@ struct lcb_device_impl {
     LcbKParams KP{};
     std::vector<void*> owned;
     uint32_t* dUsed = nullptr;
-    size_t usedWords = 0;
+    size_t usedWords = 0;      // words of one view (a multiple of 4)
+    int maxViews = 0;          // predicted views allocated behind the live bitmap (view 0)
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t cursorBase = 0;
     unsigned long long arenaBase = 0;
@@ -271,10 +283,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             }
             d->T.occRec = d->upload(rec.data(), rec.size());
         }
-        d->usedWords = (size_t)(P / 32 + 2);
-        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4));
+        d->usedWords = ((size_t)(P / 32 + 2) + 3) & ~(size_t)3;
+        // predicted `used` views for the engine's dry-run launches: at most LCB_VIEWS (default 64), within 2 GiB
+        d->maxViews = (int)std::min<uint64_t>(envU32("LCB_VIEWS", 64), (2ull << 30) / (d->usedWords * 4));
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4 * (size_t)(d->maxViews + 1)));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
-        d->T.used = d->dUsed;
+        d->T.used = d->dUsed; d->T.usedStride = (uint32_t)d->usedWords;
         d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
@@ -381,6 +395,38 @@ void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
     }
 }
 
+void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* marks, int64_t nMarks)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    if (nViews < 0 || nViews > d->maxViews) throw LcbError("more predicted views requested than the device holds");
+    if (nViews == 0) return;
+    const uint32_t n4 = (uint32_t)(d->usedWords / 4);
+    hipLaunchKernelGGL(lcb_copy_views_kernel, dim3(std::min<uint32_t>((n4 + 255) / 256, 2048u)), dim3(256), 0, d->stream, d->dUsed,
+                       (uint32_t)d->usedWords, (uint32_t)nViews);
+    HIP_CHECK(hipGetLastError());
+    // a mark of view v is set in the views v..nViews: expand to bit ranges of the whole allocation
+    const uint64_t P = d->g->nPos(), viewBits = (uint64_t)d->usedWords * 32;
+    uint32_t m = 0;
+    auto flushRanges = [&]() {
+        if (!m) return;
+        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));   // hRanges is reused
+        m = 0;
+    };
+    for (int64_t k = 0; k < nMarks; k++) {
+        if (marks[k].hi > P || marks[k].firstView < 1) throw LcbError("bad predicted mark");
+        for (uint32_t v = marks[k].firstView; v <= (uint32_t)nViews; v++) {
+            d->hRanges[2 * m] = v * viewBits + marks[k].lo; d->hRanges[2 * m + 1] = v * viewBits + marks[k].hi;
+            if (++m == d->rangeCap) flushRanges();
+        }
+    }
+    flushRanges();
+}
+
+int lcb_device_max_views_impl(lcb_device* h) { return h->impl->maxViews; }
+
 void lcb_device_set_stats_impl(lcb_device* h, bool on) { h->impl->stats = on; }
 
 void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
@@ -394,7 +440,7 @@ int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries;
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut)
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view)
 {
     lcb_device_impl* d = h->impl;
     d->use();
@@ -434,7 +480,10 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         }
     for (size_t base = 0; base < firstPass.size(); base += d->batchCap) {
         const uint32_t m = (uint32_t)((firstPass.size() - base) < d->batchCap ? (firstPass.size() - base) : d->batchCap);
-        for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[firstPass[base + i]].vid; d->hSeeds[i].ch = seeds[firstPass[base + i]].ch; }
+        for (uint32_t i = 0; i < m; i++) {
+            const int64_t s = firstPass[base + i];
+            d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
+        }
         d->launch(d->small, m);
         for (uint32_t i = 0; i < m; i++) {
             const LcbSeedOut& o = d->hOut[i];
@@ -462,7 +511,10 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         std::vector<int64_t> again;
         for (size_t base = 0; base < retry.size(); base += d->batchCap) {
             const uint32_t m = (uint32_t)((retry.size() - base) < d->batchCap ? (retry.size() - base) : d->batchCap);
-            for (uint32_t i = 0; i < m; i++) { d->hSeeds[i].vid = seeds[retry[base + i]].vid; d->hSeeds[i].ch = seeds[retry[base + i]].ch; }
+            for (uint32_t i = 0; i < m; i++) {
+                const int64_t s = retry[base + i];
+                d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
+            }
             if (round > 0) d->bigRetries += m;
             d->launch(ws, m);
             for (uint32_t i = 0; i < m; i++) {
@@ -519,11 +571,13 @@ namespace {
 struct DeviceProcessor : LcbProcessor {
     lcb_device* dev;
     explicit DeviceProcessor(lcb_device* d) : dev(d) {}
-    void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+    void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
                  std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
-        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp);
+        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view);
     }
+    int maxViews() const override { return lcb_device_max_views_impl(dev); }
+    void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { lcb_device_build_views_impl(dev, nViews, marks, nMarks); }
     void mark(const uint64_t* ranges, int64_t n) override { lcb_device_mark_used_impl(dev, ranges, n); }
     void reset() override { lcb_device_reset_used_impl(dev); }
 };

@@ -1,23 +1,30 @@
 // engine.cpp — the phase loop of BlocksFinder::FindBlocks (blocksfinder.h:334-433,453-530) as a speculative,
-// exactly-validated round engine.
+// exactly-validated round engine with predicted `used` views.
 //
 // Reference semantics that must hold bit for bit: (i) every seed of a phase of 256 is processed against the `used`
-// bits as of the START of its phase; (ii) results are committed strictly in seed order; (iii) a result that fails the
-// weak conflict check is re-processed against the live state and committed without a second check.
+// bits as of the START of its phase — call that result E; (ii) results are committed strictly in seed order; (iii) an E
+// that fails the weak conflict check is re-processed against the live state — call that result F — and F is committed
+// without a second check.
 //
-// One phase per launch starves a GPU (256 wavefronts, most of them done in microseconds). Here a ROUND of many phases
-// is processed in one launch against the state at the round start. `used` bits only ever go 0 -> 1 and a seed's
-// computation is a deterministic function of the bits it read, so a speculative result equals the exact one iff no bit
-// inside its footprint (lcb_kernel.h: one position interval per instance ever created) has been set since the round
-// snapshot. While walking the round's phases in order, seeds whose footprint intersects the ranges marked since the
-// snapshot are recomputed against the exact phase-start state before that phase is committed; the same launch eagerly
-// recomputes the invalidated seeds of the next few phases too, and every result carries the EPOCH (launch) that produced
-// it: it is valid at its phase iff nothing inside its footprint was marked in that epoch or any later one.
-// Conflicting seeds of a phase are re-processed in batches as well: all seeds that currently conflict are launched
-// together against the live state, and each of those results is used at its turn iff nothing inside its footprint was
-// marked in between (otherwise it is launched again). With world > 1 the round's seeds are dealt round-robin to the
-// ranks and the per-seed results + footprints are all-gathered; every rank then runs the identical commit, so all
-// ranks hold the same `used` state and block list without further traffic.
+// One phase per launch starves a GPU, and worse: almost all of the time goes into the LONGEST seed of each dependent
+// launch (a block of a few kbp is ~1000 sequential extension steps), so what matters is the number of dependent
+// launches. A seed's computation is a deterministic function of the `used` bits it read, and the kernel reports a
+// FOOTPRINT that covers every position whose bit it read as 0 (lcb_kernel.h). Hence a result computed against ANY bitmap
+// W equals the one the reference computes against the true state T iff
+//     (1) W has no bit that T lacks (reads that returned 1 are not in the footprint, so W must not over-predict), and
+//     (2) no bit of T \ W lies inside the footprint.
+// The engine exploits this twice. A ROUND of many phases is launched against the state at the round start (W = an old
+// T: (1) holds because bits only go 0 -> 1). Then, whenever the ordered commit needs a result it does not have — an E
+// whose footprint was hit by an earlier commit, or the F of a conflicting seed — it does not launch that one seed: it
+// dry-runs the rest of the round with the results it has as PREDICTIONS of what will be committed, and launches every
+// seed that will need a new E or F at once, each against a predicted view W = live state + the blocks predicted to be
+// committed before its turn (the processor materialises these nested views; lcb_kernel.h reads the view a seed names).
+// Neighbouring blocks, which invalidate each other one after the other, are thereby recomputed in ONE launch instead of
+// a chain of launches; a result whose prediction did not come true fails (1) or (2) and is simply computed again at the
+// next stop, where the first missing result always runs against the live state itself, so the loop makes progress.
+// With world > 1 the round's speculative launch is dealt round-robin to the ranks and the per-seed results + footprints
+// are all-gathered; every rank then runs the identical commit (job launches are repeated on every rank), so all ranks
+// hold the same `used` state and block list without further traffic.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -29,7 +36,7 @@
 
 namespace {
 
-// Disjoint, sorted position ranges [lo, hi) marked used since some snapshot.
+// Disjoint, sorted position ranges [lo, hi).
 struct RangeSet {
     std::vector<std::pair<uint64_t, uint64_t>> r;
     void clear() { r.clear(); }
@@ -44,13 +51,34 @@ struct RangeSet {
         it = r.erase(first, it);
         r.insert(it, std::make_pair(lo, hi));
     }
-    // any marked position p with lo <= p <= hi ?
+    // any position p of the set with lo <= p <= hi ?
     bool hits(uint64_t lo, uint64_t hi) const
     {
         auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(hi, UINT64_MAX));
         if (it == r.begin()) return false;
         --it;
         return it->second > lo;
+    }
+    // is [lo, hi) entirely inside the set ?
+    bool covers(uint64_t lo, uint64_t hi) const
+    {
+        if (hi <= lo) return true;
+        auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(lo, UINT64_MAX));
+        if (it == r.begin()) return false;
+        --it;
+        return it->first <= lo && it->second >= hi;
+    }
+    // any position p of the set with lo <= p <= hi that is NOT in `except` (null = empty) ?
+    bool hitsOutside(uint64_t lo, uint64_t hi, const RangeSet* except) const
+    {
+        if (!except || except->empty()) return hits(lo, hi);
+        auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(lo, UINT64_MAX));
+        if (it != r.begin()) --it;
+        for (; it != r.end() && it->first <= hi; ++it) {
+            const uint64_t a = std::max(it->first, lo), b = std::min(it->second, hi + 1);
+            if (a < b && !except->covers(a, b)) return true;
+        }
+        return false;
     }
 };
 
@@ -60,7 +88,12 @@ struct Results {                       // per-seed results of one process() call
     std::vector<lcb_fp> fp;
 };
 
-struct Override {                      // a seed whose result was replaced (recomputed / re-processed)
+// A computed result together with the state it was computed against: the live state at launch `epoch` plus the
+// predicted marks of `view` (-1 = none).
+struct Cand {
+    int32_t epoch = 0, view = -1;
+    uint32_t checkedTo = 0;            // marks of the epochs before this one are known not to touch the footprint
+    bool viewOk = false;               // every predicted mark of the view is known to have come true
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
 };
@@ -76,6 +109,13 @@ void pack(const Results& r, int64_t n, std::vector<unsigned char>& buf)
     if (nFp) memcpy(q + nInst * sizeof(lcb_instance), r.fp.data(), nFp * sizeof(lcb_fp));
 }
 
+inline void instRange(const lcb_graph* g, const lcb_instance& in, uint64_t& lo, uint64_t& hi)
+{
+    const uint64_t base = g->chrStart[in.chr];
+    lo = base + (in.front_idx < in.back_idx ? in.front_idx : in.back_idx);
+    hi = base + (in.front_idx < in.back_idx ? in.back_idx : in.front_idx);
+}
+
 }  // namespace
 
 void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds, LcbProcessor& proc,
@@ -83,10 +123,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t phase = p->phase_size > 0 ? p->phase_size : 256;
-    // Round size adapts between 1 and maxRound phases: speculation pays where few results are invalidated (sparse
-    // stretches: many seeds that walk a little and commit nothing) and only adds redundant work where every seed of a
-    // region is invalidated by the region's first commit (dense stretches), so the size doubles after a round with few
-    // recomputed seeds and halves after one with many.
+    // Round size adapts between 1 and maxRound phases: the speculative launch pays where few results are invalidated
+    // (sparse stretches: many seeds that walk a little and commit nothing) and only adds redundant work where every seed
+    // of a region is invalidated by the region's first commit, so the size doubles after a round with few recomputed
+    // seeds and halves after one with many.
     int maxRound = cfg.roundPhases;
     if (maxRound <= 0) { const char* e = getenv("LCB_ROUND_PHASES"); maxRound = e && *e ? atoi(e) : 64; }
     if (maxRound < 1) maxRound = 1;
@@ -94,7 +134,12 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     const bool fixedRound = fixedEnv && *fixedEnv && atoi(fixedEnv) != 0;
     int roundPhases = fixedRound ? maxRound : 1;
     const char* eagerEnv = getenv("LCB_EAGER_PHASES");
-    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 64;
+    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 64;     // how far ahead a dry run plans
+    const char* viewEnv = getenv("LCB_VIEWS");
+    const int maxViews = std::min(proc.maxViews(), viewEnv && *viewEnv ? std::max(0, atoi(viewEnv)) : 1 << 30);
+    const bool debug = getenv("LCB_ENGINE_DEBUG") != nullptr;
+    const char* predEnv = getenv("LCB_PREDICT_F");
+    const int predictF = predEnv && *predEnv ? atoi(predEnv) : 3;   // how the dry run predicts the F of a conflicting seed
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
 
@@ -109,11 +154,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         pending.clear();
     };
     std::vector<RangeSet> epochMarks;              // epochMarks[e]: ranges marked after launch e of this round and before launch e+1
-    RangeSet dirtyBatch;                           // marked since the last conflict batch was launched
     auto takeMarks = [&]() {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
             epochMarks.back().add(com.marks[i], com.marks[i + 1]);
-            dirtyBatch.add(com.marks[i], com.marks[i + 1]);
             pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]);
         }
         com.marks.clear();
@@ -125,12 +168,12 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
 
     Results mine, round, tmp;
     std::vector<lcb_seed> sub;
+    std::vector<uint32_t> subView;
     std::vector<unsigned char> sendBuf, recvBuf;
-    std::vector<int32_t> ovIdx;                     // per seed of the round: index into overrides or -1
-    std::vector<Override> overrides;
-    std::vector<uint32_t> epochOf, checkedTo;       // per seed of the round: epoch of its current result / epochs already checked
-    std::vector<int32_t> batchIdx;                  // per seed of the phase: conflict-batch result or -1
-    std::vector<Override> batch;
+    std::vector<Cand> cands;                        // job results of this round
+    std::vector<int32_t> eIdx, fIdx;                // per seed of the round: its newest E / F job result in cands, or -1
+    std::vector<uint32_t> e0Checked;                // per seed: epochs already checked for its round-launch result
+    std::vector<RangeSet> viewSets;                 // predicted mark sets of this round's views
 
     for (int64_t pos = 0; pos < nSeeds;) {
         const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
@@ -140,7 +183,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // ---- speculative launch of the whole round (this rank's share) -------------------------------------------
         sub.clear();
         for (int64_t i = rank; i < nRound; i += world) sub.push_back(seeds[pos + i]);
-        proc.process(sub.data(), (int64_t)sub.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
+        proc.process(sub.data(), nullptr, (int64_t)sub.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
         if (world == 1) round = mine;
         else {
             // all-gather: sizes first, then the padded payload
@@ -182,96 +225,205 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 instAt[r] += ci; fpAt[r] += cf;
             }
         }
-        ovIdx.assign((size_t)nRound, -1);
-        overrides.clear();
-        epochOf.assign((size_t)nRound, 0);
-        checkedTo.assign((size_t)nRound, 0);
+        cands.clear(); viewSets.clear();
+        eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
+        e0Checked.assign((size_t)nRound, 0);
         const int64_t recomputedBefore = st.recomputedSeeds;
-        // is the current result of seed i still exact, i.e. was nothing inside its footprint marked since its launch?
-        auto stillValid = [&](int64_t i) -> bool {
-            const lcb_fp* f; size_t nf;
-            if (ovIdx[(size_t)i] >= 0) { const Override& o = overrides[(size_t)ovIdx[(size_t)i]]; f = o.fp.data(); nf = o.fp.size(); }
-            else { f = round.fp.data() + round.fpOff[i]; nf = (size_t)(round.fpOff[i + 1] - round.fpOff[i]); }
-            const uint32_t last = (uint32_t)epochMarks.size() - 1;
-            for (uint32_t e = std::max(epochOf[(size_t)i], checkedTo[(size_t)i]); e <= last; e++) {
-                if (epochMarks[e].empty()) continue;
-                for (size_t k = 0; k < nf; k++) if (epochMarks[e].hits(f[k].lo, f[k].hi)) return false;
+
+        // the newest E result of seed i: instances / footprint / provenance
+        auto eInst = [&](int64_t i, const lcb_instance*& r, uint64_t& cnt) {
+            if (eIdx[(size_t)i] >= 0) { const Cand& c = cands[(size_t)eIdx[(size_t)i]]; r = c.inst.data(); cnt = c.inst.size(); }
+            else { r = round.inst.data() + round.off[i]; cnt = round.off[i + 1] - round.off[i]; }
+        };
+        // Conditions (1) and (2) of the header for a result computed at launch `epoch` against view `view`, judged against
+        // the live state now. `checkedTo` caches the closed epochs already examined; `viewOk` caches (1), which is monotone.
+        auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf) -> bool {
+            const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
+            if (P && !(viewOk && *viewOk)) {
+                for (auto& q : P->r) if (!com.allUsed(q.first, q.second)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
+                if (viewOk) *viewOk = true;
             }
-            checkedTo[(size_t)i] = last;            // closed epochs need no second look; the open one is re-checked
+            const uint32_t last = (uint32_t)epochMarks.size() - 1;
+            for (uint32_t e = std::max((uint32_t)epoch, checkedTo); e <= last; e++) {
+                if (epochMarks[e].empty()) continue;
+                for (size_t k = 0; k < nf; k++) if (epochMarks[e].hitsOutside(f[k].lo, f[k].hi, P)) { if (debug) std::cerr << "   (2) footprint [" << f[k].lo << "," << f[k].hi << "] hit in epoch " << e << "\n"; return false; }
+            }
+            checkedTo = last;                       // closed epochs need no second look; the open one is re-checked
             return true;
+        };
+        auto eValidNow = [&](int64_t i) -> bool {
+            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
+            return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
+        };
+
+        // ---- dry run + job launch ---------------------------------------------------------------------------------------
+        // Called when the commit below stops at seed `stopAt` of the phase starting at `ph0` (midPhase: it needs F of that
+        // seed; otherwise it is at the phase start and needs E of some seeds). Simulates the rest of the round with the
+        // results at hand as predictions, collects every seed that will need a new E or F, and launches them all, each
+        // against the predicted state at its turn.
+        auto planAndLaunch = [&](int64_t ph0, int64_t stopAt, bool midPhase) {
+            flush();                                // processor state == live state
+            RangeSet simP;                          // predicted marks on top of the live state
+            std::vector<uint8_t> simChr(com.invalidChr.begin(), com.invalidChr.end());
+            std::vector<uint32_t> simChrList(com.invalidList.begin(), com.invalidList.end());
+            std::vector<LcbViewMark> vmarks;        // marks of the views of this launch
+            std::vector<std::pair<uint64_t, uint64_t>> sinceView;   // predicted marks not yet part of a view
+            int nViews = 0;                         // views of this launch so far (device ids 1..nViews)
+            int32_t curSet = -1;                    // viewSets index of the newest view (-1: the live state)
+            struct Job { int64_t seed; bool isF; uint32_t devView; int32_t set; };
+            std::vector<Job> jobs;
+            auto currentView = [&]() {
+                if (!sinceView.empty() && nViews < maxViews) {
+                    nViews++;
+                    for (auto& q : sinceView) vmarks.push_back(LcbViewMark{(uint32_t)nViews, q.first, q.second});
+                    sinceView.clear();
+                    viewSets.push_back(simP);
+                    curSet = (int32_t)viewSets.size() - 1;
+                }
+                // with no view left the newest one is used: it under-predicts, which is legal (condition (2) decides)
+            };
+            auto simAdd = [&](const lcb_instance* r, uint64_t cnt) {
+                for (uint64_t k = 0; k < cnt; k++) {
+                    if (!simChr[r[k].chr]) { simChr[r[k].chr] = 1; simChrList.push_back(r[k].chr); }
+                    uint64_t lo, hi; instRange(g, r[k], lo, hi);
+                    if (hi > lo && !(com.allUsed(lo, hi))) { simP.add(lo, hi); sinceView.emplace_back(lo, hi); }
+                }
+            };
+            auto simConflicts = [&](const lcb_instance* r, uint64_t cnt) -> bool {
+                for (uint64_t k = 0; k < cnt; k++) {
+                    if (!simChr[r[k].chr]) continue;
+                    uint64_t lo, hi; instRange(g, r[k], lo, hi);
+                    if (hi > lo && (com.anyUsed(lo, hi) || simP.hits(lo, hi - 1))) return true;
+                }
+                return false;
+            };
+            // would this result still be exact if the predicted marks came true? (conditions (1) and (2) against live + simP)
+            auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf) -> bool {
+                const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
+                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second)) {
+                    // a predicted mark that is neither true yet nor predicted now (partly true + partly predicted is rare: treat as invalid)
+                    return false;
+                }
+                const uint32_t last = (uint32_t)epochMarks.size() - 1;
+                for (uint32_t e = std::max((uint32_t)epoch, checkedTo); e <= last; e++) {
+                    if (epochMarks[e].empty()) continue;
+                    for (size_t k = 0; k < nf; k++) if (epochMarks[e].hitsOutside(f[k].lo, f[k].hi, P)) return false;
+                }
+                checkedTo = last;                   // closed epochs are final (the open one is looked at again)
+                if (!simP.empty()) for (size_t k = 0; k < nf; k++) if (simP.hitsOutside(f[k].lo, f[k].hi, P)) return false;
+                return true;
+            };
+            const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
+            std::vector<lcb_instance> guess;
+            for (int64_t ph = ph0; ph < lim; ph += phase) {
+                const int64_t n = std::min<int64_t>(phase, nRound - ph);
+                const bool first = ph == ph0;
+                if (!(first && midPhase)) {
+                    // phase start: which seeds will lack an exact E?
+                    bool any = false;
+                    for (int64_t j = ph; j < ph + n; j++) {
+                        bool ok;
+                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
+                        else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
+                        if (!ok) {
+                            if (!any) { currentView(); any = true; }
+                            jobs.push_back(Job{j, false, (uint32_t)nViews, curSet});
+                        }
+                    }
+                    if (!first) { for (uint32_t c : simChrList) simChr[c] = 0; simChrList.clear(); }
+                }
+                // ordered commit, simulated with the newest E of each seed as the prediction of its E
+                for (int64_t j = (first && midPhase) ? stopAt : ph; j < ph + n; j++) {
+                    const lcb_instance* r; uint64_t cnt;
+                    eInst(j, r, cnt);
+                    if (cnt <= 1) continue;
+                    if (!simConflicts(r, cnt)) { simAdd(r, cnt); continue; }
+                    // it will need F
+                    bool have = false;
+                    if (fIdx[(size_t)j] >= 0) {
+                        Cand& c = cands[(size_t)fIdx[(size_t)j]];
+                        have = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size());
+                        if (have && c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
+                    }
+                    if (!have) {
+                        currentView();
+                        jobs.push_back(Job{j, true, (uint32_t)nViews, curSet});
+                        if (predictF >= 3 && fIdx[(size_t)j] >= 0) {
+                            // a stale F (computed against a view that did not come true) is the best guess at hand
+                            const Cand& c = cands[(size_t)fIdx[(size_t)j]];
+                            if (c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
+                        } else if (predictF) {
+                            // prediction of F: the parts of E that are free, if the seed's own stretch survives; erring on
+                            // the small side is harmless (under-prediction), erring on the large side voids later views
+                            guess.clear();
+                            for (uint64_t k = 0; k < cnt; k++) {
+                                uint64_t lo, hi; instRange(g, r[k], lo, hi);
+                                if (hi > lo && !com.anyUsed(lo, hi) && !simP.hits(lo, hi - 1)) guess.push_back(r[k]);
+                            }
+                            if (guess.size() > 1 && predictF >= 2) simAdd(guess.data(), guess.size());
+                        }
+                    }
+                }
+                for (uint32_t c : simChrList) simChr[c] = 0;
+                simChrList.clear();
+            }
+            // ---- launch
+            if (jobs.empty()) throw LcbError("engine: commit stopped but the dry run found nothing to compute");
+            if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }
+            sub.clear(); subView.clear();
+            for (auto& jb : jobs) { sub.push_back(seeds[pos + jb.seed]); subView.push_back(jb.devView); }
+            proc.process(sub.data(), subView.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
+            st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
+            if (midPhase) st.conflictLaunches++;
+            if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views\n";
+            epochMarks.emplace_back();              // marks from here on belong to the new epoch
+            const int32_t epoch = (int32_t)epochMarks.size() - 1;
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const Job& jb = jobs[k];
+                if (jb.isF) st.conflictSeeds++;
+                int32_t& slot = jb.isF ? fIdx[(size_t)jb.seed] : eIdx[(size_t)jb.seed];
+                if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
+                Cand& c = cands[(size_t)slot];
+                c.epoch = epoch; c.view = jb.set; c.checkedTo = (uint32_t)epoch; c.viewOk = jb.set < 0;
+                c.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
+                c.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
+            }
         };
 
         // ---- walk the round's phases in order -----------------------------------------------------------------------
         for (int64_t ph = 0; ph < nRound; ph += phase) {
             const int64_t n = std::min<int64_t>(phase, nRound - ph);
-            // (a) exact phase-start results: recompute what earlier commits may have changed. If this phase has such
-            //     seeds, the launch also takes the currently invalid seeds of the next `eager` phases along.
-            {
-                std::vector<int64_t> which;
-                for (int64_t i = ph; i < ph + n; i++) if (!stillValid(i)) which.push_back(i);
-                if (!which.empty()) {
-                    const int64_t lim = std::min<int64_t>(nRound, ph + n + (int64_t)eagerPhases * phase);
-                    for (int64_t i = ph + n; i < lim; i++) if (!stillValid(i)) which.push_back(i);
-                    sub.clear();
-                    for (int64_t i : which) sub.push_back(seeds[pos + i]);
-                    flush();                        // == live state at the start of this phase
-                    proc.process(sub.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
-                    st.recomputeLaunches++; st.recomputedSeeds += (int64_t)which.size();
-                    epochMarks.emplace_back();      // marks from here on belong to the new epoch
-                    const uint32_t epoch = (uint32_t)epochMarks.size() - 1;
-                    for (size_t k = 0; k < which.size(); k++) {
-                        int32_t& slot = ovIdx[(size_t)which[k]];
-                        if (slot < 0) { slot = (int32_t)overrides.size(); overrides.emplace_back(); }
-                        Override& o = overrides[(size_t)slot];
-                        o.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
-                        o.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
-                        epochOf[(size_t)which[k]] = epoch; checkedTo[(size_t)which[k]] = epoch;
-                    }
-                }
+            // (a) exact phase-start results for every seed of the phase
+            for (;;) {
+                bool all = true;
+                for (int64_t i = ph; i < ph + n && all; i++) if (!eValidNow(i)) all = false;
+                if (all) break;
+                planAndLaunch(ph, ph, false);
             }
-            // (b) ordered commit (blocksfinder.h:372-414) with batched re-processing of conflicts
-            batchIdx.assign((size_t)n, -1);
-            batch.clear();
-            auto resultOf = [&](int64_t i, const lcb_instance*& r, uint64_t& cnt) {
-                if (ovIdx[(size_t)i] >= 0) { const Override& o = overrides[(size_t)ovIdx[(size_t)i]]; r = o.inst.data(); cnt = o.inst.size(); }
-                else { r = round.inst.data() + round.off[i]; cnt = round.off[i + 1] - round.off[i]; }
-            };
+            // (b) ordered commit (blocksfinder.h:372-414)
             for (int64_t i = ph; i < ph + n; i++) {
                 if (cfg.progress && (pos + i) % portion == 0) std::cout << '.' << std::flush;
                 const lcb_instance* r; uint64_t cnt;
-                resultOf(i, r, cnt);
+                eInst(i, r, cnt);
                 if (cnt <= 1) continue;                                                  // blocksfinder.h:375
-                if (!com.conflicts(r, cnt)) { com.finalize(r, cnt); takeMarks(); continue; }
+                if (!com.conflicts(r, cnt)) { com.finalize(r, cnt); takeMarks(); if (eIdx[(size_t)i] >= 0) st.jobsUsed++; continue; }
                 st.failures++;                                                           // blocksfinder.h:406
-                bool have = false;
-                if (batchIdx[(size_t)(i - ph)] >= 0) {
-                    const Override& b = batch[(size_t)batchIdx[(size_t)(i - ph)]];
-                    have = true;
-                    for (size_t f = 0; f < b.fp.size() && have; f++) if (dirtyBatch.hits(b.fp[f].lo, b.fp[f].hi)) have = false;
-                }
-                if (!have) {
-                    // re-process, against the live state, every seed of the rest of the phase that conflicts right now
-                    sub.clear();
-                    std::vector<int64_t> which;
-                    for (int64_t j = i; j < ph + n; j++) {
-                        const lcb_instance* rj; uint64_t cj;
-                        resultOf(j, rj, cj);
-                        if (cj > 1 && (j == i || com.conflicts(rj, cj))) { which.push_back(j); sub.push_back(seeds[pos + j]); }
+                for (;;) {
+                    if (fIdx[(size_t)i] >= 0) {
+                        Cand& c = cands[(size_t)fIdx[(size_t)i]];
+                        if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size())) break;
                     }
-                    flush();
-                    dirtyBatch.clear();
-                    proc.process(sub.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
-                    st.conflictLaunches++; st.conflictSeeds += (int64_t)which.size();
-                    for (size_t k = 0; k < which.size(); k++) {
-                        int32_t& slot = batchIdx[(size_t)(which[k] - ph)];
-                        if (slot < 0) { slot = (int32_t)batch.size(); batch.emplace_back(); }
-                        Override& b = batch[(size_t)slot];
-                        b.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
-                        b.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
-                    }
+                    planAndLaunch(ph, i, true);
                 }
-                const Override& b = batch[(size_t)batchIdx[(size_t)(i - ph)]];
-                if (b.inst.size() > 1) { com.finalize(b.inst.data(), b.inst.size()); takeMarks(); }   // blocksfinder.h:408-411
+                const Cand& c = cands[(size_t)fIdx[(size_t)i]];
+                st.jobsUsed++;
+                if (debug) {
+                    uint64_t eb = 0, fb = 0;
+                    for (uint64_t k = 0; k < cnt; k++) { uint64_t lo, hi; instRange(g, r[k], lo, hi); eb += hi - lo; }
+                    for (auto& in : c.inst) { uint64_t lo, hi; instRange(g, in, lo, hi); fb += hi - lo; }
+                    std::cerr << "   F of seed " << (pos + i) << ": E " << cnt << " inst / " << eb << " pos -> F " << c.inst.size() << " inst / " << fb << " pos\n";
+                }
+                if (c.inst.size() > 1) { com.finalize(c.inst.data(), c.inst.size()); takeMarks(); }   // blocksfinder.h:408-411
             }
             com.endPhase();
         }

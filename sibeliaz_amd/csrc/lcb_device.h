@@ -23,7 +23,11 @@ void lcb_device_set_stats_impl(lcb_device* d, bool on);
 // Processes seeds[0..n): fills offsets[n+1] and inst (resized), bestScore (optional, n entries), ctr (optional, accumulated).
 void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr);
+                             std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr,
+                             const uint32_t* view = nullptr);   // view[i]: `used` view of seed i (null = the live state)
+// Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
+void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
+int lcb_device_max_views_impl(lcb_device* d);
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,

@@ -54,6 +54,7 @@ struct lcb_committer {
     int64_t blocksFound = 0, failures = 0;
     lcb_committer(const lcb_graph* graph, const lcb_params& prm);
     bool anyUsed(uint64_t lo, uint64_t hi) const;
+    bool allUsed(uint64_t lo, uint64_t hi) const;
     bool conflicts(const lcb_instance* inst, uint64_t n) const;   // the weak check of blocksfinder.h:377-398
     void finalize(const lcb_instance* inst, uint64_t n);
     void endPhase();                                              // invalidChr_.clear(), blocksfinder.h:416
@@ -68,12 +69,21 @@ struct lcb_fp { uint32_t lo, hi; };
 // seeds against ITS current `used` state. The product's implementation is the HIP device (device.hip); tests plug in
 // a callback stand-in. Footprints are optional: an implementation that cannot produce them returns one interval
 // [0, UINT32_MAX] per seed, which makes every speculative result conservatively invalid after any commit.
+// One range of flat positions that a predicted `used` view has set in addition to the live state: it is set in the
+// views firstView, firstView + 1, ... of the launch (views are nested prefixes of the predicted commit sequence).
+struct LcbViewMark { uint32_t firstView; uint64_t lo, hi; };
+
 struct LcbProcessor {
     virtual ~LcbProcessor() {}
-    virtual void process(const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+    // view[i] (null = all 0) selects the `used` state seed i is processed against: 0 = the live state (every mark() so far),
+    // v >= 1 = view v of the last buildViews() call.
+    virtual void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
                          std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) = 0;
     virtual void mark(const uint64_t* ranges, int64_t n) = 0;
     virtual void reset() = 0;
+    // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
+    virtual int maxViews() const { return 0; }
+    virtual void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) { (void)nViews; (void)marks; (void)nMarks; }
 };
 
 // All-gather of a fixed-size buffer across ranks: recv holds world * bytes. Returns 0 on success.
@@ -90,6 +100,10 @@ struct LcbEngineConfig {
 struct LcbEngineStats {
     int64_t seeds = 0, blocksFound = 0, failures = 0, rounds = 0, recomputeLaunches = 0, recomputedSeeds = 0, conflictLaunches = 0,
             conflictSeeds = 0, exchanges = 0;
+    // predictive job launches: recomputeLaunches/recomputedSeeds count them and their jobs; of those jobs,
+    int64_t jobsUsed = 0;         // ... results that were committed from (exactly validated)
+    int64_t viewsBuilt = 0;       // predicted `used` views materialised
+    int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     double wallMs = 0;
 };
 

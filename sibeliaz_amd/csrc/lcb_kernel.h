@@ -66,12 +66,13 @@ struct LcbTables {
     const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
     const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
     const uint4* occRec;        // [nPos]  per occurrence, ascending in g: {g, chr, Position::pos, Position::id} (one 16-B load)
-    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx)
+    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx); view v of it starts at used + v * usedStride
+    uint32_t usedStride;        // words between consecutive `used` views (view 0 = the live state, views 1.. = predicted states)
     uint32_t nChr, nVertex, nPos;
 };
 
 struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
-struct LcbKSeed { int32_t vid; int32_t ch; };
+struct LcbKSeed { int32_t vid; int32_t ch; uint32_t view; uint32_t pad; };   // view: which `used` view this seed reads
 
 struct LcbSeedOut {            // per-seed header written by the kernel
     uint32_t nInst;
@@ -981,6 +982,7 @@ struct LcbLaunchArgs {
     unsigned long long* fpCursor;
     uint32_t* cursor;
     uint32_t cursorBase, nSeeds;
+    const uint32_t* usedView;      // `used` view of the seed wave 0 is working on (read by the helpers at each vote)
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
@@ -1068,6 +1070,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             for (;;) {
                 __syncthreads();
                 if (S.mail[LCB_MAIL_CMD] == LCB_CMD_EXIT) return;
+                S.T.used = sArgs.usedView;
                 const uint32_t flags = S.mail[LCB_MAIL_FLAGS];
                 S.cWalk = 0;
                 const bool ovf = lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, S.mail[LCB_MAIL_NLIST],
@@ -1095,6 +1098,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0;
         const uint64_t tick0 = PROF ? wall_clock64() : 0;
         const LcbKSeed sd = sArgs.seeds[s];
+        S.T.used = T.used + (size_t)sd.view * T.usedStride;
+        if (NW > 1 && S.lane == 0) sArgs.usedView = S.T.used;     // published to the helpers by the vote's first barrier
         lcb_process_seed<STATS, PROF>(S, sd.vid, sd.ch, bestScore);
         const uint64_t ticks = PROF ? wall_clock64() - tick0 : 0;
         const uint32_t n = S.status ? 0u : S.nBest;

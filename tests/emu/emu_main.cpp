@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+#include <omp.h>
+#include <algorithm>
+
 #include "emu_runtime.h"
 #include "lcb_host.h"
 #include "lcb_kernel.h"
@@ -26,68 +29,139 @@ extern "C" const char* lcb_last_error(void) { return g_err.c_str(); }
 
 namespace {
 
-struct Emu {
-    const lcb_graph* g;
-    lcb_params p;
-    std::vector<uint32_t> chrStart32, used;
-    LcbTables T;
-    LcbKParams KP;
-    int mode = 0;
-    bool big = false;
-    std::vector<uint4> occRec;
+// One emulated workgroup's private state: workspace slot, work-queue and arena cursors, result buffers.
+struct EmuCtx {
     std::vector<uint8_t> slot;
     LcbWork W;
     uint32_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint2> fpArena;
     std::vector<LcbSeedOut> out;
     std::vector<uint4> arena;
+    std::vector<LcbKSeed> ks;
+    std::vector<size_t> which;
+};
+
+struct Emu {
+    const lcb_graph* g;
+    lcb_params p;
+    std::vector<uint32_t> chrStart32, used;      // used: view 0 (live) followed by the predicted views
+    size_t usedWords = 0;
+    int nViewsAlloc = 0;
+    LcbTables T;
+    LcbKParams KP;
+    int mode = 0;
+    bool big = false;
+    std::vector<uint4> occRec;
+    std::vector<EmuCtx> ctx;                     // one per host thread
+    std::vector<uint2> fpArena;                  // merged results of the last run()
+    std::vector<LcbSeedOut> out;
+    std::vector<uint4> arena;
     lcb_counters ctr{};
+    uint64_t launches = 0, criticalPushes = 0, totalPushes = 0;   // sum over launches of the largest per-seed push count
 
     Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode == 2)
     {
         chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
-        used.assign(g->nPos() / 32 + 2, 0);
+        usedWords = g->nPos() / 32 + 2;
+        used.assign(usedWords, 0);
         T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
         T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
         occRec.resize(g->nPos());
         for (size_t j = 0; j < occRec.size(); j++) { const uint32_t q = g->occG[j]; occRec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]}; }
-        T.occRec = occRec.data(); T.used = used.data();
+        T.occRec = occRec.data(); T.used = used.data(); T.usedStride = (uint32_t)usedWords;
         T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
-        W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : (mode == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL); W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
-        LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
-        slot.assign(L.total, 0);
-        int32_t* pk = (int32_t*)(slot.data() + L.pKeys);
-        for (uint32_t i = 0; i < W.pathCap; i++) pk[i] = LCB_EMPTY_KEY;
-        if (big) { int32_t* vk = (int32_t*)(slot.data() + L.vKey); for (uint32_t i = 0; i < W.voteCap; i++) vk[i] = LCB_EMPTY_KEY; }
-        W.base = slot.data(); W.slotBytes = L.total;
-        W.dbg = nullptr; W.cursor = &cursor[0]; W.arenaCursor = (unsigned long long*)&cursor[2];
-        arena.resize(1 << 20);
-        fpArena.resize(1 << 20);
-        W.fpCursor = (unsigned long long*)&cursor[4];
+        const char* te = getenv("EMU_THREADS");
+        int nThreads = te ? atoi(te) : omp_get_max_threads();
+        if (getenv("EMU_NW") && atoi(getenv("EMU_NW")) > 1) nThreads = 1;     // multi-wave runs keep the single-threaded schedule
+        if (nThreads < 1) nThreads = 1;
+        ctx.resize((size_t)nThreads);
+        for (auto& c : ctx) {
+            LcbWork& W = c.W;
+            W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : (mode == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL); W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
+            LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
+            c.slot.assign(L.total, 0);
+            int32_t* pk = (int32_t*)(c.slot.data() + L.pKeys);
+            for (uint32_t i = 0; i < W.pathCap; i++) pk[i] = LCB_EMPTY_KEY;
+            if (big) { int32_t* vk = (int32_t*)(c.slot.data() + L.vKey); for (uint32_t i = 0; i < W.voteCap; i++) vk[i] = LCB_EMPTY_KEY; }
+            W.base = c.slot.data(); W.slotBytes = L.total;
+            W.dbg = nullptr; W.cursor = &c.cursor[0]; W.arenaCursor = (unsigned long long*)&c.cursor[2];
+            c.arena.resize(1 << 18);
+            c.fpArena.resize(1 << 18);
+            W.fpCursor = (unsigned long long*)&c.cursor[4];
+        }
     }
 
-    // runs the process kernel over seeds with ONE emulated wavefront (the work queue feeds it all seeds)
-    void run(const std::vector<LcbKSeed>& seeds)
+    // predicted views 1..nViews = live state + the marks whose firstView <= v
+    void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks)
     {
-        out.assign(seeds.size(), LcbSeedOut{});
-        W.cursorBase = cursor[0];
+        used.resize(usedWords * (size_t)(nViews + 1));
+        T.used = used.data();
+        for (int v = 1; v <= nViews; v++) {
+            uint32_t* w = used.data() + usedWords * (size_t)v;
+            memcpy(w, used.data(), usedWords * 4);
+            for (int64_t m = 0; m < nMarks; m++)
+                if ((int)marks[m].firstView <= v) for (uint64_t q = marks[m].lo; q < marks[m].hi; q++) w[q >> 5] |= 1u << (q & 31);
+        }
+        nViewsAlloc = nViews;
+    }
+
+    void runCtx(EmuCtx& c)
+    {
+        LcbWork& W = c.W;
+        c.cursor[2] = c.cursor[3] = c.cursor[4] = c.cursor[5] = 0;   // reuse the arenas
+        c.out.assign(c.ks.size(), LcbSeedOut{});
+        W.cursorBase = c.cursor[0];
         W.arenaBase = *W.arenaCursor;
         W.fpBase = *W.fpCursor;
-        const LcbKSeed* sp = seeds.data();
-        const uint32_t n = (uint32_t)seeds.size();
+        const LcbKSeed* sp = c.ks.data();
+        const uint32_t n = (uint32_t)c.ks.size();
+        if (!n) return;
         const char* nwEnv = getenv("EMU_NW");
         const int nw = nwEnv ? atoi(nwEnv) : 1;
-        if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1, false>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, true>(T, KP, sp, n, W, out.data(), arena.data(), arena.size(), fpArena.data(), fpArena.size()); });
-        for (auto& o : out) {
-            ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
-            ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
+        LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); uint2* fa = c.fpArena.data();
+        const size_t arc = c.arena.size(), fac = c.fpArena.size();
+        if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+    }
+
+    // runs the process kernel over the seeds: each host thread emulates ONE wavefront over its share of the seeds
+    // (seeds are independent; a thread's work queue feeds it all of its seeds)
+    void run(const std::vector<LcbKSeed>& seeds)
+    {
+        const size_t nT = ctx.size();
+        for (auto& c : ctx) { c.ks.clear(); c.which.clear(); }
+        for (size_t i = 0; i < seeds.size(); i++) { ctx[i % nT].ks.push_back(seeds[i]); ctx[i % nT].which.push_back(i); }
+        for (;;) {
+            #pragma omp parallel for schedule(dynamic, 1) num_threads((int)nT)
+            for (size_t t = 0; t < nT; t++) runCtx(ctx[t]);
+            bool grown = false;                  // a result arena overflowed: enlarge it and run that share again
+            for (auto& c : ctx) for (auto& o : c.out) if (o.status == LCB_ST_ARENA_OVF && !grown) { c.arena.resize(c.arena.size() * 4); c.fpArena.resize(c.fpArena.size() * 4); grown = true; }
+            if (!grown) break;
         }
+        out.assign(seeds.size(), LcbSeedOut{});
+        arena.clear(); fpArena.clear();
+        uint64_t maxPush = 0;
+        for (auto& c : ctx)
+            for (size_t j = 0; j < c.which.size(); j++) {
+                LcbSeedOut o = c.out[j];
+                if (o.status == 0) {
+                    const uint64_t ao = arena.size(), fo = fpArena.size();
+                    arena.insert(arena.end(), c.arena.begin() + o.arenaOff, c.arena.begin() + o.arenaOff + o.nInst);
+                    fpArena.insert(fpArena.end(), c.fpArena.begin() + o.fpOff, c.fpArena.begin() + o.fpOff + o.nFp);
+                    o.arenaOff = ao; o.fpOff = fo;
+                }
+                out[c.which[j]] = o;
+                ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
+                ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
+                maxPush = std::max<uint64_t>(maxPush, o.ctr[6]); totalPushes += o.ctr[6];
+            }
+        launches++; criticalPushes += maxPush;
+        if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush);
     }
 };
 
@@ -169,7 +243,7 @@ int main(int argc, char** argv)
             }
             if (getenv("EMU_ONLY")) { const lcb_seed one = seeds[atoi(getenv("EMU_ONLY"))]; seeds.assign(1, one); }
             std::vector<LcbKSeed> ks;
-            for (auto& s : seeds) ks.push_back(LcbKSeed{s.vid, s.ch});
+            for (auto& s : seeds) ks.push_back(LcbKSeed{s.vid, s.ch, 0u, 0u});
             emu.run(ks);
             std::vector<orc_inst> ref(1 << 16);
             for (size_t i = 0; i < seeds.size(); i++) {
@@ -202,12 +276,16 @@ int main(int argc, char** argv)
             // the product's speculative round engine (engine.cpp) over the emulated kernel, for several round sizes
             struct EmuProcessor : LcbProcessor {
                 Emu* emu;
-                void process(const lcb_seed* sd, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
-                             std::vector<lcb_fp>& fp) override
+                int views = 0;
+                void process(const lcb_seed* sd, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                             std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
                 {
                     std::vector<LcbKSeed> ks;
-                    for (int64_t i = 0; i < n; i++) ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch});
-                    emu->cursor[2] = emu->cursor[3] = emu->cursor[4] = emu->cursor[5] = 0;   // reuse the arenas
+                    for (int64_t i = 0; i < n; i++) {
+                        const uint32_t v = view ? view[i] : 0u;
+                        if ((int)v > emu->nViewsAlloc) throw LcbError("seed names a view that was not built");
+                        ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, v, 0u});
+                    }
                     if (n) emu->run(ks);
                     off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
                     for (int64_t i = 0; i < n; i++) {
@@ -223,15 +301,20 @@ int main(int argc, char** argv)
                 {
                     for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
                 }
-                void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); }
+                void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; }
+                int maxViews() const override { return views; }
+                void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
             };
             orc_block* ob = nullptr; orc_stats st;
             const int64_t nb = orc_find_blocks(og, &op, &ob, &st, nullptr);
             std::vector<lcb_block> blocks;
             const char* rp = getenv("EMU_ROUNDS");
             std::vector<int> rounds = rp ? std::vector<int>{atoi(rp)} : std::vector<int>{1, 3, 64};
+            const char* vp = getenv("EMU_VIEWS");
             for (int R : rounds) {
                 EmuProcessor proc; proc.emu = &emu;
+                proc.views = vp ? atoi(vp) : (R == 3 ? 0 : (R == 1 ? 2 : 64));   // no views / view starvation / plenty
+                emu.launches = emu.criticalPushes = emu.totalPushes = 0;
                 LcbEngineConfig cfg; cfg.roundPhases = R;
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
@@ -243,6 +326,9 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
+                fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes, total %llu pushes\n", proc.views,
+                        (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
+                        (unsigned long long)emu.totalPushes);
                 bad += diffs;
             }
             int64_t nTrim = 0; double cov = 0;

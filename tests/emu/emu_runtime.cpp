@@ -1,5 +1,6 @@
 // emu_runtime.cpp — TEST-ONLY lockstep wavefront emulator (see tests/emu/hip/hip_runtime.h).
-// A workgroup of nWaves x 64 coroutine lanes on one OS thread; x86-64 System V only.
+// A workgroup of nWaves x 64 coroutine lanes on one OS thread (state is thread-local, so several OS threads can each
+// emulate their own workgroup); x86-64 System V only.
 //
 // Wave-level cross-lane operations (__ballot/__shfl/wave barrier) complete when all 64 lanes of THAT wave have
 // arrived at the same call site; __syncthreads completes when every live lane of the workgroup has arrived.
@@ -61,7 +62,7 @@ struct Block {
     uint64_t collectives = 0;
 };
 
-Block g_blk;
+thread_local Block g_blk;   // one emulated workgroup per OS thread (emu_main runs independent seeds on several threads)
 
 void laneEntry()
 {

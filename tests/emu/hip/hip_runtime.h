@@ -19,7 +19,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 
 struct uint4 { uint32_t x, y, z, w; };
