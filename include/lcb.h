@@ -81,11 +81,14 @@ typedef struct {
     double kernel_ms;       /* sum of hipEvent-timed kernel durations on the device's stream */
     double wall_ms;         /* wall time of the phase loop */
     int64_t rounds;             /* speculative multi-phase launches */
-    int64_t recompute_launches; /* per-phase launches that recomputed seeds invalidated by earlier commits of the round */
-    int64_t recomputed_seeds;
-    int64_t conflict_launches;  /* batched re-process launches (blocksfinder.h:406-411) */
-    int64_t conflict_seeds;
+    int64_t recompute_launches; /* job launches: after a stop of the ordered commit, every seed the dry run expects to need a new result */
+    int64_t recomputed_seeds;   /* ... jobs in those launches */
+    int64_t conflict_launches;  /* job launches whose stop was a conflicting seed waiting for its re-processed result (blocksfinder.h:406-411) */
+    int64_t conflict_seeds;     /* jobs that re-process a (predicted) conflict against the (predicted) live state */
     int64_t exchanges;          /* all-gathers (multi-rank) */
+    int64_t jobs_used;          /* job results that passed the exact validation and were committed from */
+    int64_t views_built;        /* predicted `used` views materialised on the device */
+    int64_t over_predicted;     /* validations that failed because a predicted mark did not come true */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */

@@ -35,7 +35,8 @@ class Stats(C.Structure):
     _fields_ = [("seeds", C.c_int64), ("blocks_found", C.c_int64), ("failures", C.c_int64), ("launches", C.c_int64),
                 ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
-                ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64)]
+                ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
+                ("over_predicted", C.c_int64)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)

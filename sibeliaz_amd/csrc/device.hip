@@ -601,5 +601,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->wall_ms = es.wallMs;
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
+            stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
     }
 }
