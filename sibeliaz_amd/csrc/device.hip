@@ -284,8 +284,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             d->T.occRec = d->upload(rec.data(), rec.size());
         }
         d->usedWords = ((size_t)(P / 32 + 2) + 3) & ~(size_t)3;
-        // predicted `used` views for the engine's dry-run launches: at most LCB_VIEWS (default 64), within 2 GiB
-        d->maxViews = (int)std::min<uint64_t>(envU32("LCB_VIEWS", 64), (2ull << 30) / (d->usedWords * 4));
+        // predicted `used` views for the engine's dry-run launches: at most LCB_VIEWS (default 256), within 2 GiB
+        d->maxViews = (int)std::min<uint64_t>(envU32("LCB_VIEWS", 256), (2ull << 30) / (d->usedWords * 4));
         HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4 * (size_t)(d->maxViews + 1)));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
         d->T.used = d->dUsed; d->T.usedStride = (uint32_t)d->usedWords;

@@ -128,13 +128,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // of a region is invalidated by the region's first commit, so the size doubles after a round with few recomputed
     // seeds and halves after one with many.
     int maxRound = cfg.roundPhases;
-    if (maxRound <= 0) { const char* e = getenv("LCB_ROUND_PHASES"); maxRound = e && *e ? atoi(e) : 64; }
+    if (maxRound <= 0) { const char* e = getenv("LCB_ROUND_PHASES"); maxRound = e && *e ? atoi(e) : 256; }
     if (maxRound < 1) maxRound = 1;
     const char* fixedEnv = getenv("LCB_ROUND_FIXED");
     const bool fixedRound = fixedEnv && *fixedEnv && atoi(fixedEnv) != 0;
     int roundPhases = fixedRound ? maxRound : 1;
     const char* eagerEnv = getenv("LCB_EAGER_PHASES");
-    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 64;     // how far ahead a dry run plans
+    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 256;     // how far ahead a dry run plans
     const char* viewEnv = getenv("LCB_VIEWS");
     const int maxViews = std::min(proc.maxViews(), viewEnv && *viewEnv ? std::max(0, atoi(viewEnv)) : 1 << 30);
     const bool debug = getenv("LCB_ENGINE_DEBUG") != nullptr;

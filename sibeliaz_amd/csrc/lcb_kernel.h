@@ -104,7 +104,7 @@ struct LcbWork {               // per-wave global-memory workspace slots
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
-    uint64_t pKeys, pSlots, body, best;                       // always
+    uint64_t pKeys, pSlots, body, best, ck;                   // always (ck: forward-extension checkpoint, 6 words per instance)
     uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, vTouched, fp;   // big mode
     uint64_t total;
 };
@@ -118,6 +118,7 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.pSlots = o; o = lcb_align16(o + 4ull * (pathCap / 2 + 1));
     L.body = o; o = lcb_align16(o + 8ull * bodyCap);
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
+    L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
     L.inst = o; o = lcb_align16(o + 10ull * 4 * instCap);
     L.ordKey = o; o = lcb_align16(o + 2ull * 4 * instCap);
     L.ordIdx = o; o = lcb_align16(o + 2ull * 4 * instCap);
@@ -187,6 +188,11 @@ struct LcbState {
     uint32_t bodyCap;
     uint4* best;
     uint32_t bestCap;
+    // checkpoint of the forward extension at (or shortly before) the best-scoring point, so that the "replay" after the
+    // forward extension (blocksfinder.h:271-284) restarts there instead of at Init: 6 arrays of bestCap words in the slot
+    uint32_t* ck;
+    uint32_t ckN, ckInst, ckGood, ckPath;   // pushes / instances / good instances / path vertices at the checkpoint (ckN 0 = none)
+    int32_t ckFlank;
     // wave-uniform scalars
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
@@ -855,6 +861,43 @@ __device__ inline void lcb_snapshot(LcbState& S)
     S.nBest = S.nGood;
 }
 
+// Forward pushes only append instances, good-list entries and path vertices and only change the Back fields, the flags and
+// the ordered index of existing instances; the best-scoring point only moves forward. A checkpoint taken at a best point
+// therefore stays a valid restart for the replay whatever follows.
+#define LCB_CK_EVERY 32u
+__device__ inline void lcb_checkpoint(LcbState& S)
+{
+    const uint32_t n = S.nInst, cap = S.bestCap;
+    if (n > cap) return;
+    uint32_t* c = S.ck;
+    const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
+    const uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    for (uint32_t i = S.lane; i < n; i += 64) {
+        c[i] = S.iBackG[i]; c[cap + i] = S.iBackPos[i]; c[2 * cap + i] = (uint32_t)S.iBackDist[i]; c[3 * cap + i] = S.iFlags[i];
+        c[4 * cap + i] = oKey[i]; c[5 * cap + i] = oIdx[i];
+    }
+    S.ckN = S.nRight; S.ckInst = n; S.ckGood = S.nGood; S.ckPath = S.nPath; S.ckFlank = S.rightFlank;
+}
+
+// Back to the checkpoint: the state after ckN forward pushes (Front fields, chromosome data and the right-body list are
+// untouched by forward pushes; the Bloom filter and the footprints keep their supersets).
+__device__ inline void lcb_restore_checkpoint(LcbState& S)
+{
+    LCB_WAVE_SYNC();
+    for (uint32_t i = S.ckPath + S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+    const uint32_t n = S.ckInst, cap = S.bestCap;
+    const uint32_t* c = S.ck;
+    uint32_t* oKey = S.ordKey + S.cur * S.instCap;
+    uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    for (uint32_t i = S.lane; i < n; i += 64) {
+        S.iBackG[i] = c[i]; S.iBackPos[i] = c[cap + i]; S.iBackDist[i] = (int32_t)c[2 * cap + i]; S.iFlags[i] = c[3 * cap + i];
+        oKey[i] = c[4 * cap + i]; oIdx[i] = c[5 * cap + i];
+    }
+    S.nPath = S.ckPath; S.nInst = n; S.nGood = S.ckGood; S.nRight = S.ckN; S.nLeft = 0;
+    S.rightFlank = S.ckFlank; S.leftFlank = 0;
+    LCB_WAVE_SYNC();
+}
+
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
 template <bool FORWARD, bool STATS, bool PROF>
 __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
@@ -904,6 +947,7 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
                     bestScore = nowScore;
                     if (FORWARD) bestRightSize = S.nRight + 1;
                     if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
+                    if (FORWARD && !STATS && S.nRight >= S.ckN + LCB_CK_EVERY) lcb_checkpoint(S);
                 }
                 if (PROF) S.pfTScore += wall_clock64() - tp1;
             }
@@ -919,7 +963,7 @@ template <bool STATS, bool PROF>
 __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
     int64_t score = 0, bestScore = 0;
-    S.nBest = 0; S.status = LCB_ST_OK;
+    S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0;
     LCB_MARK(S, 2, 1);
     lcb_path_init<STATS>(S, vid, ch);
     LCB_MARK(S, 2, 2); LCB_MARK(S, 3, S.nInst);
@@ -938,9 +982,15 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
     LCB_MARK(S, 2, 3);
     if (!S.status) {                                                 // replay, blocksfinder.h:271-284
         const uint32_t nEdge = bestRightSize - 1;
-        lcb_path_clear(S);            // keeps the body list, resets everything else
-        lcb_path_init<STATS>(S, vid, ch);
-        for (uint32_t i = 0; i < nEdge && !S.status; i++) {
+        uint32_t from = 0;
+        if (!STATS && S.ckN && S.ckN <= nEdge) {
+            lcb_restore_checkpoint(S);    // the state after ckN pushes; stats mode replays from Init like the reference (event counts)
+            from = S.ckN;
+        } else {
+            lcb_path_clear(S);            // keeps the body list, resets everything else
+            lcb_path_init<STATS>(S, vid, ch);
+        }
+        for (uint32_t i = from; i < nEdge && !S.status; i++) {
             const unsigned long long b = S.body[i];
             const LcbStep st = lcb_load_step<true>(S.T, (uint32_t)b, (b >> 32) != 0);
             lcb_push<true, STATS, PROF>(S, (uint32_t)b, (b >> 32) != 0, false, st);
@@ -1025,6 +1075,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.pathCap = W.pathCap; S.pathShift = 32u - (uint32_t)__ffs((int)W.pathCap) + 1u;
     S.body = (unsigned long long*)(slot + L.body); S.bodyCap = W.bodyCap;
     S.best = (uint4*)(slot + L.best); S.bestCap = W.bestCap;
+    S.ck = (uint32_t*)(slot + L.ck); S.ckN = S.ckInst = S.ckGood = S.ckPath = 0; S.ckFlank = 0;
     uint32_t* instBase;
     if (BIG) {
         instBase = (uint32_t*)(slot + L.inst); S.instCap = W.instCap;
