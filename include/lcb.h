@@ -89,6 +89,8 @@ typedef struct {
     int64_t jobs_used;          /* job results that passed the exact validation and were committed from */
     int64_t views_built;        /* predicted `used` views materialised on the device */
     int64_t over_predicted;     /* validations that failed because a predicted mark did not come true */
+    double process_ms;          /* wall time inside launches + result gathering (kernel_ms is the device part of it) */
+    double plan_ms;             /* wall time of the dry runs */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */

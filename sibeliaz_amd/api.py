@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
-                ("over_predicted", C.c_int64)]
+                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)

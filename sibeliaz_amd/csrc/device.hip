@@ -138,6 +138,7 @@ struct lcb_device_impl {
     // seeds that overflowed the LDS capacities before: (vid, ch) -> kernel mode to start with next time, so that a
     // recomputation does not repeat the doomed small-mode attempt
     std::unordered_map<uint64_t, uint8_t> modeHint;
+    std::vector<uint64_t> hintBits = std::vector<uint64_t>(1024, 0);   // 65 536-bit prefilter in front of modeHint (most seeds have no hint)
     double kernelMs = 0;
     int64_t launches = 0, bigRetries = 0;
 
@@ -365,6 +366,7 @@ void lcb_device_reset_used_impl(lcb_device* h)
     lcb_device_impl* d = h->impl;
     d->use();
     d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
+    std::fill(d->hintBits.begin(), d->hintBits.end(), 0ull);
     HIP_CHECK(hipMemsetAsync(d->dUsed, 0, d->usedWords * 4, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
 }
@@ -447,12 +449,15 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     offsets.assign((size_t)n + 1, 0);
     inst.clear();
     d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
-    std::vector<std::vector<lcb_fp>> fps;               // per seed (only when footprints are wanted)
-    if (d->wantFp) fps.resize((size_t)n);
+    std::vector<lcb_fp> fpFlat;                         // footprints in arrival order (only when they are wanted) ...
+    std::vector<uint64_t> fpAt;                         // ... and where each seed's intervals start / how many there are
+    std::vector<uint32_t> fpCnt;
+    if (d->wantFp) { fpAt.assign((size_t)n, 0); fpCnt.assign((size_t)n, 0); fpFlat.reserve((size_t)n * 2); }
     auto takeFp = [&](int64_t s, const LcbSeedOut& o) {
         if (!d->wantFp) return;
-        fps[(size_t)s].resize(o.nFp);
-        for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = d->hFp[o.fpOff + e]; fps[(size_t)s][e] = lcb_fp{r.x, r.y}; }
+        fpAt[(size_t)s] = fpFlat.size(); fpCnt[(size_t)s] = o.nFp;
+        const uint2* src = d->hFp + o.fpOff;
+        for (uint32_t e = 0; e < o.nFp; e++) fpFlat.push_back(lcb_fp{src[e].x, src[e].y});
     };
     // per-seed results are gathered out of order (retries), then laid out in seed order
     std::vector<std::vector<lcb_instance>> late;        // results of retried seeds
@@ -468,12 +473,21 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     std::vector<int64_t> retry;                         // seeds that need larger workspaces (medium, then big)
     std::vector<int64_t> retryBig;                      // seeds known to need the big workspaces
     auto keyOf = [](const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; };
+    auto setHint = [&](const lcb_seed& sd, uint8_t mode) {
+        const uint64_t key = keyOf(sd);
+        const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
+        d->hintBits[hb >> 6] |= 1ull << (hb & 63);
+        d->modeHint[key] = mode;
+    };
     std::vector<int64_t> firstPass;
     firstPass.reserve((size_t)n);
     if (d->modeHint.empty()) for (int64_t s = 0; s < n; s++) firstPass.push_back(s);
     else
         for (int64_t s = 0; s < n; s++) {
-            auto it = d->modeHint.find(keyOf(seeds[s]));
+            const uint64_t key = keyOf(seeds[s]);
+            const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
+            if (!((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull)) { firstPass.push_back(s); continue; }
+            auto it = d->modeHint.find(key);
             if (it == d->modeHint.end()) firstPass.push_back(s);
             else if (it->second == 1) retry.push_back(s);
             else retryBig.push_back(s);
@@ -500,7 +514,7 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                 addCtr(o);
             } else if (o.status == LCB_ST_DIST_OVF) {
                 throw LcbError("a path longer than 2^31 bp is not supported");
-            } else { retry.push_back(s); if (o.status != LCB_ST_ARENA_OVF) d->modeHint[keyOf(seeds[s])] = 1; }
+            } else { retry.push_back(s); if (o.status != LCB_ST_ARENA_OVF) setHint(seeds[s], 1); }
         }
     }
     // retries: medium mode (4x LDS capacities) first, then big mode, growing its capacities while seeds keep overflowing
@@ -533,7 +547,7 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                     addCtr(o);
                 } else if (o.status == LCB_ST_DIST_OVF) {
                     throw LcbError("a path longer than 2^31 bp is not supported");
-                } else { again.push_back(s); if (o.status != LCB_ST_ARENA_OVF) d->modeHint[keyOf(seeds[s])] = 2; }
+                } else { again.push_back(s); if (o.status != LCB_ST_ARENA_OVF) setHint(seeds[s], 2); }
             }
         }
         if (!again.empty() && round > 0) {
@@ -556,11 +570,11 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     if (d->wantFp) {
         fpOffsets->assign((size_t)n + 1, 0);
         uint64_t tf = 0;
-        for (int64_t s = 0; s < n; s++) { (*fpOffsets)[(size_t)s] = tf; tf += fps[(size_t)s].size(); }
+        for (int64_t s = 0; s < n; s++) { (*fpOffsets)[(size_t)s] = tf; tf += fpCnt[(size_t)s]; }
         (*fpOffsets)[(size_t)n] = tf;
         fpOut->resize((size_t)tf);
         for (int64_t s = 0; s < n; s++)
-            if (!fps[(size_t)s].empty()) memcpy(fpOut->data() + (*fpOffsets)[(size_t)s], fps[(size_t)s].data(), fps[(size_t)s].size() * sizeof(lcb_fp));
+            if (fpCnt[(size_t)s]) memcpy(fpOut->data() + (*fpOffsets)[(size_t)s], fpFlat.data() + fpAt[(size_t)s], (size_t)fpCnt[(size_t)s] * sizeof(lcb_fp));
     }
     d->wantFp = false;
 }
@@ -602,5 +616,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
+            stats->process_ms = es.processMs; stats->plan_ms = es.planMs;
     }
 }

@@ -122,6 +122,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, LcbEngineStats* stats)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    auto msSince = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     const int64_t phase = p->phase_size > 0 ? p->phase_size : 256;
     // Round size adapts between 1 and maxRound phases: the speculative launch pays where few results are invalidated
     // (sparse stretches: many seeds that walk a little and commit nothing) and only adds redundant work where every seed
@@ -138,6 +139,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     const char* viewEnv = getenv("LCB_VIEWS");
     const int maxViews = std::min(proc.maxViews(), viewEnv && *viewEnv ? std::max(0, atoi(viewEnv)) : 1 << 30);
     const bool debug = getenv("LCB_ENGINE_DEBUG") != nullptr;
+    const char* jobsEnv = getenv("LCB_MAX_JOBS");
+    const size_t maxJobs = jobsEnv && *jobsEnv ? (size_t)std::max(1, atoi(jobsEnv)) : 16384;   // a dry run stops planning ahead beyond this
     const char* predEnv = getenv("LCB_PREDICT_F");
     const int predictF = predEnv && *predEnv ? atoi(predEnv) : 3;   // how the dry run predicts the F of a conflicting seed
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
@@ -183,7 +186,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // ---- speculative launch of the whole round (this rank's share) -------------------------------------------
         sub.clear();
         for (int64_t i = rank; i < nRound; i += world) sub.push_back(seeds[pos + i]);
-        proc.process(sub.data(), nullptr, (int64_t)sub.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
+        { const auto tp = std::chrono::steady_clock::now();
+          proc.process(sub.data(), nullptr, (int64_t)sub.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
+          st.processMs += msSince(tp); }
         if (world == 1) round = mine;
         else {
             // all-gather: sizes first, then the padded payload
@@ -262,6 +267,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // results at hand as predictions, collects every seed that will need a new E or F, and launches them all, each
         // against the predicted state at its turn.
         auto planAndLaunch = [&](int64_t ph0, int64_t stopAt, bool midPhase) {
+            const auto tPlan = std::chrono::steady_clock::now();
             flush();                                // processor state == live state
             RangeSet simP;                          // predicted marks on top of the live state
             std::vector<uint8_t> simChr(com.invalidChr.begin(), com.invalidChr.end());
@@ -316,6 +322,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
             std::vector<lcb_instance> guess;
             for (int64_t ph = ph0; ph < lim; ph += phase) {
+                if (jobs.size() >= maxJobs) break;      // enough speculation for one launch (the first job is always there)
                 const int64_t n = std::min<int64_t>(phase, nRound - ph);
                 const bool first = ph == ph0;
                 if (!(first && midPhase)) {
@@ -369,10 +376,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             }
             // ---- launch
             if (jobs.empty()) throw LcbError("engine: commit stopped but the dry run found nothing to compute");
-            if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }
             sub.clear(); subView.clear();
             for (auto& jb : jobs) { sub.push_back(seeds[pos + jb.seed]); subView.push_back(jb.devView); }
+            st.planMs += msSince(tPlan);
+            const auto tProc = std::chrono::steady_clock::now();
+            if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }
             proc.process(sub.data(), subView.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
+            st.processMs += msSince(tProc);
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
             if (midPhase) st.conflictLaunches++;
             if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views\n";

@@ -105,6 +105,7 @@ struct LcbEngineStats {
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     double wallMs = 0;
+    double processMs = 0, planMs = 0;   // wall time inside the processor (launches + result gathering) / inside the dry runs
 };
 
 void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds, LcbProcessor& proc,

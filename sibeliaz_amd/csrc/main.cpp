@@ -134,7 +134,7 @@ int main(int argc, char** argv)
             std::cerr << "lcb: seeds=" << st.seeds << " blocks=" << st.blocks_found << " conflicts=" << st.failures << " launches=" << st.launches
                       << " big_retries=" << st.big_retries << " kernel_ms=" << st.kernel_ms << " loop_ms=" << st.wall_ms << " | rounds=" << st.rounds
                       << " job_launches=" << st.recompute_launches << " (" << st.conflict_launches << " at a conflict) jobs=" << st.recomputed_seeds << " used="
-                      << st.jobs_used << " views=" << st.views_built << " over_predicted=" << st.over_predicted << std::endl;
+                      << st.jobs_used << " views=" << st.views_built << " over_predicted=" << st.over_predicted << " process_ms=" << st.process_ms << " plan_ms=" << st.plan_ms << std::endl;
         std::cout << "Generating the output..." << std::endl;                                  // sibeliaz.cpp:142
         // Blocks found / Coverage are printed by GenerateOutput before the files are written (blocksfinder.h:658-661);
         // the counts are only known after trimming, which lcb_generate_output does, so print right after it.

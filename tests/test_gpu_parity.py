@@ -134,6 +134,22 @@ def test_round_engine_variants_on_gpu(built, case, fixed, phases, monkeypatch):
     assert finder.stats["failures"] == int(summary["failure"])
 
 
+@pytest.mark.parametrize("env", [{"LCB_VIEWS": "0"}, {"LCB_VIEWS": "2", "LCB_ROUND_FIXED": "1", "LCB_ROUND_PHASES": "64"}, {"LCB_PREDICT_F": "0"},
+                                 {"LCB_PREDICT_F": "2", "LCB_MAX_JOBS": "8"}, {"LCB_EAGER_PHASES": "0"}])
+def test_predictive_engine_knobs_on_gpu(built, case, env, monkeypatch):
+    """Predictions only cost launches, never correctness: without predicted views, with too few of them, with other F
+    predictions, a tiny job cap or no look-ahead the block list is the reference's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    st, p, dev = _setup(case)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+
+
 def test_cli_drop_in(built, case, tmp_path):
     """The sibeliaz-lcb executable with the wrapper's argv (sibeliaz:146) writes the reference's blocks_coords.gff."""
     out = str(tmp_path / "cli")

@@ -138,11 +138,16 @@ def emu_built():
 
 
 @pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
-                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64"})])
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
+                                            # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
+                                            ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1"}),
+                                            # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "0", "LCB_MAX_JOBS": "8"}),
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
 def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode, env, tmp_path):
     """The unmodified device code of lcb_kernel.h on the CPU wavefront emulator (tests/emu) vs the oracle: per-seed results,
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
-    from conftest import Case
+    from tests.conftest import Case
     c = Case(name, case_dir)
     r = subprocess.run([emu_built, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
                        env=dict(os.environ, **env))
