@@ -30,8 +30,10 @@ for d, name in (("pmc3", "FETCH_SIZE"), ("pmc4", "WRITE_SIZE")):
         for k, v in agg.items():
             line = k + "  dispatches=%d  " % calls[k] + "  ".join("%s=%.6g" % kv for kv in sorted(v.items()))
             print(line); f.write(line + "\n")
-    tot[name] = sum(v[name] for k, v in agg.items() if "lcb_process_kernel" in k)
-    launches = sum(c for k, c in calls.items() if "lcb_process_kernel" in k)
+    # the shipped instantiations only: <MODE, false, NW, false>; a fresh box also runs bench.py's one-time stats-mode pass (<MODE, true, ...>)
+    ship = lambda k: "lcb_process_kernel" in k and ", true," not in k
+    tot[name] = sum(v[name] for k, v in agg.items() if ship(k))
+    launches = sum(c for k, c in calls.items() if ship(k))
     for fn in files: os.remove(fn)
     for fn in glob.glob("gpurun_out/%s/*kernel_trace.csv" % d): os.remove(fn)
 if len(tot) == 2:
