@@ -378,6 +378,14 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (jobs.empty()) throw LcbError("engine: commit stopped but the dry run found nothing to compute");
             sub.clear(); subView.clear();
             for (auto& jb : jobs) { sub.push_back(seeds[pos + jb.seed]); subView.push_back(jb.devView); }
+            if (debug && getenv("LCB_ENGINE_DEBUG_JOBS"))
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    const lcb_instance* r; uint64_t cnt; eInst(jobs[k].seed, r, cnt);
+                    uint64_t longest = 0, fl = 0;
+                    for (uint64_t q = 0; q < cnt; q++) { uint64_t lo, hi; instRange(g, r[q], lo, hi); longest = std::max(longest, hi - lo); }
+                    if (fIdx[(size_t)jobs[k].seed] >= 0) for (auto& in : cands[(size_t)fIdx[(size_t)jobs[k].seed]].inst) { uint64_t lo, hi; instRange(g, in, lo, hi); fl = std::max(fl, hi - lo); }
+                    std::cerr << "   job " << k << " seed " << (pos + jobs[k].seed) << (jobs[k].isF ? " F" : " E") << " eLongest " << longest << " eCnt " << cnt << " staleF " << (fIdx[(size_t)jobs[k].seed] >= 0 ? (int64_t)fl : -1) << " view " << jobs[k].devView << "\n";
+                }
             st.planMs += msSince(tPlan);
             const auto tProc = std::chrono::steady_clock::now();
             if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }

@@ -57,7 +57,7 @@ struct Emu {
     std::vector<LcbSeedOut> out;
     std::vector<uint4> arena;
     lcb_counters ctr{};
-    uint64_t launches = 0, criticalPushes = 0, totalPushes = 0;   // sum over launches of the largest per-seed push count
+    uint64_t launches = 0, criticalPushes = 0, totalPushes = 0, firstPushes = 0;   // sum over launches of the largest per-seed push count
 
     Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode == 2)
     {
@@ -165,7 +165,9 @@ struct Emu {
                 maxPush = std::max<uint64_t>(maxPush, o.ctr[6]); totalPushes += o.ctr[6];
             }
         launches++; criticalPushes += maxPush;
-        if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush);
+        if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes, first job %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush, (unsigned long long)out[0].ctr[6]);
+        firstPushes += out.empty() ? 0 : out[0].ctr[6];
+        if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (size_t i = 0; i < out.size(); i++) fprintf(stderr, "   done %zu pushes %llu inst %u\n", i, (unsigned long long)out[i].ctr[6], out[i].nInst);
     }
 };
 
@@ -318,7 +320,7 @@ int main(int argc, char** argv)
             for (int R : rounds) {
                 EmuProcessor proc; proc.emu = &emu;
                 proc.views = vp ? atoi(vp) : (R == 3 ? 0 : (R == 1 ? 2 : 64));   // no views / view starvation / plenty
-                emu.launches = emu.criticalPushes = emu.totalPushes = 0;
+                emu.launches = emu.criticalPushes = emu.totalPushes = emu.firstPushes = 0;
                 LcbEngineConfig cfg; cfg.roundPhases = R;
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
@@ -330,9 +332,9 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
-                fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes, total %llu pushes\n", proc.views,
+                fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
-                        (unsigned long long)emu.totalPushes);
+                        (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);
                 bad += diffs;
             }
             int64_t nTrim = 0; double cov = 0;
