@@ -1,6 +1,7 @@
 // lcb_kernel.h — gfx950 device code of the per-seed path-extension / bubble-scoring hot path.
 //
-// One seed (BlocksFinder::Bundle) per 64-lane wavefront; a workgroup is exactly one wavefront.
+// One seed (BlocksFinder::Bundle) per workgroup: wavefront 0 runs the per-seed algorithm, the other wavefronts of the
+// workgroup are helpers that share the look-ahead vote.
 // This replaces ProcessVertex::Process (blocksfinder.h:228-310) and everything under it:
 // MostPopularVertex (blocksfinder.h:708-768), ExtendPathForward/Backward (:770-895), Path::Init,
 // PointPushBack/Front + workers, Compatible, Score, Clear (path.h:33-46,380-677) and
@@ -21,7 +22,10 @@
 //    state and resolves the (rare) occurrences that fall into the same gap between two
 //    instances with a closed-form prefix rule that reproduces the sequential semantics;
 //  * Compatible's unbounded `used` walk (path.h:387-393) becomes a masked bitmap range test
-//    evaluated after the distance tests (it is a pure function).
+//    evaluated after the distance tests (it is a pure function);
+//  * a seed reads the `used` VIEW its record names (the live bitmap or a predicted state built by the engine,
+//    engine.cpp) and reports the FOOTPRINT of the bits it read as 0, which is what makes speculation exact;
+//  * the replay of the forward extension (blocksfinder.h:271-284) restarts at a checkpoint taken at a best point.
 //
 // All cross-lane operations (__ballot/__shfl/LCB_WAVE_SYNC) sit in wave-uniform control flow.
 // Integer arithmetic only; no MFMA — the work is indexing, not contraction.
@@ -33,14 +37,13 @@
 
 #define LCB_EMPTY_KEY INT32_MIN
 // The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
-// when the recorder is off. KNOWN ISSUE: with the sites compiled out, the small-mode kernel was observed to
-// hang or fault on gfx950 / ROCm 7.2 on seeds that the instrumented build, the CPU emulator and ASan/UBSan all handle
-// correctly; the cause is not understood yet, so the validated (instrumented) code shape is the one that ships.
+// when the recorder is off (measured: 0.3 %). An earlier build hung or faulted on gfx950 with the sites compiled out
+// (no longer reproducible); the recorder is what would localise a recurrence, so it stays in.
 #define LCB_FLIGHT_RECORDER 1
 
 // Three kernel variants by where the per-path state lives. Seeds that overflow one are re-run by the host in the next:
-//   mode 0 "small":  instances + vote table in 36 KB of LDS  -> 4 workgroups per CU
-//   mode 1 "medium": 4x the capacities in 146 KB of LDS       -> 1 workgroup per CU
+//   mode 0 "small":  instances + vote table in 79 KB of LDS  -> 2 workgroups per CU
+//   mode 1 "medium": 2x the capacities in 154 KB of LDS       -> 1 workgroup per CU
 //   mode 2 "big":    instances + vote table in the global-memory workspace, capacities chosen by the host
 #define LCB_IC_SMALL 512u    // instances
 #define LCB_VC_SMALL 2048u   // vote-table slots (power of two)

@@ -4,8 +4,8 @@ The reference has no distributed path (OpenMP only). The exact ro
 seeds of each speculative round to the ranks round-robin; each rank runs its share on its own MI355X (tables and the
 `used` bitmap are replicated), then per-seed results and footprints are all-gathered — two collectives per round (sizes,
 padded payload), KBs to a few MB, latency bound — and every rank runs the identical ordered commit, so all ranks hold
-the same `used` state and block list without further traffic. Recomputations of invalidated or conflicting seeds are
-deterministic and done redundantly by every rank on its own GPU.
+the same `used` state and block list without further traffic. The job launches that recompute invalidated or conflicting
+seeds against predicted `used` views are deterministic, latency-bound chains; every rank repeats them on its own GPU.
 
 This module only supplies the all-gather callback the C++ engine calls; the engine, commit and kernels are native.
 """
