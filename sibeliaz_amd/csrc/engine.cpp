@@ -142,7 +142,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     const char* jobsEnv = getenv("LCB_MAX_JOBS");
     const size_t maxJobs = jobsEnv && *jobsEnv ? (size_t)std::max(1, atoi(jobsEnv)) : 16384;   // a dry run stops planning ahead beyond this
     const char* predEnv = getenv("LCB_PREDICT_F");
-    const int predictF = predEnv && *predEnv ? atoi(predEnv) : 3;   // how the dry run predicts the F of a conflicting seed
+    const int predictF = predEnv && *predEnv ? atoi(predEnv) : 3;   // how the dry run predicts the F of a conflicting seed:
+                                                                    // 0/1 nothing, 2 the still-free instances of E, 3 a stale F if there is one, else as 2
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
 
