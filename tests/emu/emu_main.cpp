@@ -15,6 +15,7 @@
 
 #include <omp.h>
 #include <algorithm>
+#include <memory>
 
 #include "emu_runtime.h"
 #include "lcb_host.h"
@@ -160,6 +161,7 @@ struct Emu {
                     o.arenaOff = ao; o.fpOff = fo;
                 }
                 out[c.which[j]] = o;
+                if (o.status != 0) continue;     // an overflowed attempt is re-run in a larger mode (runRetry) and counted there
                 ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
                 ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
                 maxPush = std::max<uint64_t>(maxPush, o.ctr[6]); totalPushes += o.ctr[6];
@@ -168,6 +170,34 @@ struct Emu {
         if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes, first job %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush, (unsigned long long)out[0].ctr[6]);
         firstPushes += out.empty() ? 0 : out[0].ctr[6];
         if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (size_t i = 0; i < out.size(); i++) fprintf(stderr, "   done %zu pushes %llu inst %u\n", i, (unsigned long long)out[i].ctr[6], out[i].nInst);
+    }
+    // Like the product's retry chain (device.hip): seeds that overflow the LDS capacities of this mode are run again in the next
+    // larger mode (small -> medium -> big), against the same `used` views.
+    std::unique_ptr<Emu> next;
+    void runRetry(const std::vector<LcbKSeed>& seeds)
+    {
+        run(seeds);
+        std::vector<size_t> again;
+        for (size_t i = 0; i < out.size(); i++) if (out[i].status >= LCB_ST_INST_OVF && out[i].status <= LCB_ST_BEST_OVF) again.push_back(i);
+        if (again.empty() || mode >= 2) return;
+        if (!next) next.reset(new Emu(g, p, mode + 1));
+        next->used = used; next->T.used = next->used.data(); next->nViewsAlloc = nViewsAlloc;
+        std::vector<LcbKSeed> sub;
+        for (size_t i : again) sub.push_back(seeds[i]);
+        next->runRetry(sub);
+        for (size_t k = 0; k < again.size(); k++) {
+            LcbSeedOut o = next->out[k];
+            if (o.status == 0) {
+                const uint64_t ao = arena.size(), fo = fpArena.size();
+                arena.insert(arena.end(), next->arena.begin() + o.arenaOff, next->arena.begin() + o.arenaOff + o.nInst);
+                fpArena.insert(fpArena.end(), next->fpArena.begin() + o.fpOff, next->fpArena.begin() + o.fpOff + o.nFp);
+                o.arenaOff = ao; o.fpOff = fo;
+            }
+            out[again[k]] = o;
+        }
+        ctr.n_walk += next->ctr.n_walk; ctr.n_occ += next->ctr.n_occ; ctr.n_compat_call += next->ctr.n_compat_call; ctr.n_compat_step += next->ctr.n_compat_step;
+        ctr.n_inst_out += next->ctr.n_inst_out; ctr.n_vote += next->ctr.n_vote; ctr.n_push += next->ctr.n_push; ctr.n_process += next->ctr.n_process;
+        memset(&next->ctr, 0, sizeof(next->ctr));
     }
 };
 
@@ -250,7 +280,7 @@ int main(int argc, char** argv)
             if (getenv("EMU_ONLY")) { const lcb_seed one = seeds[atoi(getenv("EMU_ONLY"))]; seeds.assign(1, one); }
             std::vector<LcbKSeed> ks;
             for (auto& s : seeds) ks.push_back(LcbKSeed{s.vid, s.ch, 0u, 0u});
-            emu.run(ks);
+            emu.runRetry(ks);
             std::vector<orc_inst> ref(1 << 16);
             for (size_t i = 0; i < seeds.size(); i++) {
                 int64_t score = 0;
@@ -292,7 +322,7 @@ int main(int argc, char** argv)
                         if ((int)v > emu->nViewsAlloc) throw LcbError("seed names a view that was not built");
                         ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, v, 0u});
                     }
-                    if (n) emu->run(ks);
+                    if (n) emu->runRetry(ks);
                     off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
                     for (int64_t i = 0; i < n; i++) {
                         const LcbSeedOut& o = emu->out[(size_t)i];
