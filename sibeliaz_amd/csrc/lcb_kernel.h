@@ -734,6 +734,11 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
                             }
                         }
                         compat = okDist && !lcb_range_any_used_c(T, occ, ga, gb);
+                        // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
+                        // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
+                        // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
+                        // Equal path distance <=> same vertex (distances are strictly monotone along the path).
+                        if (cd == distance) compat = false;
                     }
                 }
                 if (compat) {

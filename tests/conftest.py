@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
-CASES = sorted(d for d in os.listdir(GOLDEN) if os.path.isfile(os.path.join(GOLDEN, d, "golden.json")))
+CASES = sorted(d for d in os.listdir(GOLDEN) if os.path.isfile(os.path.join(GOLDEN, d, "genomes.fa.gz")))   # full cases (inputs + all goldens)
 
 
 def pytest_configure(config):
