@@ -119,6 +119,23 @@ void lcb_free(void* p);
 
 /* ---- device: one MI355X. device_ordinal is the HIP device index. */
 lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int device_ordinal);
+/* Tuning knobs of a device; a zero field means "default". Results never depend on them (tests sweep them). */
+typedef struct {
+    uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 6 per CU */
+    uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
+    uint32_t big_slots;      /* ... of the big (global-memory) variant; default 1 per CU */
+    uint32_t path_cap;       /* path vertex set capacity of a compact slot (power of two); default 32768 */
+    uint32_t wide_path_cap;  /* ... of a wide slot; default max(131072, path_cap) */
+    uint32_t max_views;      /* predicted `used` views kept behind the live bitmap; default 256 (within 2 GiB) */
+    uint32_t batch;          /* seeds per launch; default 65536 */
+    uint32_t wide_threshold; /* calls with at most this many seeds start in the wide variant; default 2 * wide_slots */
+    uint32_t start_mode;     /* 0 = automatic; 1 / 2 / 3 = every seed starts in the compact / wide / big variant */
+    uint32_t screen_min;     /* launches of at least this many seeds are screened first; default 2048 */
+} lcb_device_opts;
+lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
+/* Seeds handed to the compact / wide / big kernel variant since the device was created (a seed that overflows one
+ * variant is counted again in the next). */
+int lcb_device_mode_seeds(lcb_device* d, int64_t counts[3]);
 void lcb_device_destroy(lcb_device* d);
 /* `used` bits (Position::used, junctionstorage.h:144) live in HBM as a bitmap over g. */
 int lcb_device_reset_used(lcb_device* d);
@@ -178,8 +195,15 @@ typedef struct {
     lcb_mark_cb mark;
     lcb_reset_cb reset;
     void* engine_user;
-    int32_t round_phases;       /* phases per speculative round; 0 = default (LCB_ROUND_PHASES or 64) */
+    int32_t round_phases;       /* phases per speculative round (upper bound of the adaptive size); 0 = default 256 */
     int32_t progress;
+    /* engine tuning, 0 = default; results never depend on these (tests sweep them) */
+    int32_t round_fixed;        /* 1: every round has round_phases phases (no adaptation) */
+    int32_t eager_phases;       /* phases a dry run plans ahead; default 256; -1 = none */
+    int32_t max_views;          /* predicted views used per job launch; default: all the device has; -1 = none */
+    int32_t max_jobs;           /* a dry run stops planning beyond this many jobs; default: the device's seeds in flight */
+    int32_t predict_f;          /* how a dry run predicts the re-processed result of a conflicting seed: 1 nothing,
+                                   2 the still-free instances of its phase-start result, 3 (default) a stale re-processed result if any, else as 2 */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

@@ -21,11 +21,12 @@ ms = np.array([v[2] for v in launch.values()])
 n = np.array([v[0] for v in launch.values()])
 mode = np.array([v[1] for v in launch.values()])
 print("launches %d  kernel ms %.1f" % (len(ms), ms.sum()))
-for md in ("small", "medium", "big"):
+for md in ("compact", "wide", "big"):
     sel = mode == md
     print("  %-6s launches %5d  ms %8.1f   single-seed launches %5d ms %8.1f" % (md, sel.sum(), ms[sel].sum(), (sel & (n == 1)).sum(), ms[sel & (n == 1)].sum()))
-ph = ms[(mode == "small") & (n > 1)]
-print("phase launches: %d sum %.1f ms  percentiles 10/50/90/99 = %s" % (len(ph), ph.sum(), np.round(np.percentile(ph, [10, 50, 90, 99]), 3)))
+ph = ms[(mode == "compact") & (n > 1)]
+if len(ph):
+    print("compact launches: %d sum %.1f ms  percentiles 10/50/90/99 = %s" % (len(ph), ph.sum(), np.round(np.percentile(ph, [10, 50, 90, 99]), 3)))
 allp = [d for v in seeds.values() for d in v]
 if allp:
     tk = np.array([d["ticks"] for d in allp]) / 100.0

@@ -48,7 +48,19 @@ RESET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 class Hooks(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allgather", ALLGATHER_CB), ("allgather_user", C.c_void_p),
                 ("process", PROCESS_CB), ("mark", MARK_CB), ("reset", RESET_CB), ("engine_user", C.c_void_p),
-                ("round_phases", C.c_int32), ("progress", C.c_int32)]
+                ("round_phases", C.c_int32), ("progress", C.c_int32),
+                # engine tuning (0 = default; results never depend on it)
+                ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
+                ("predict_f", C.c_int32)]
+
+
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f")
+
+
+class DeviceOpts(C.Structure):
+    """lcb_device_opts: tuning knobs of a device, 0 = default."""
+    _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "path_cap", "wide_path_cap", "max_views", "batch",
+                                          "wide_threshold", "start_mode", "screen_min")]
 
 
 class Counters(C.Structure):
@@ -65,7 +77,7 @@ _lib = None
 EXPORTS = [
     "lcb_last_error", "lcb_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
     "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
-    "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
+    "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
     "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
     "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
@@ -106,6 +118,9 @@ def load_library():
     L.lcb_free.argtypes = [vp]
     L.lcb_device_create.restype = vp
     L.lcb_device_create.argtypes = [vp, C.POINTER(Params), C.c_int]
+    L.lcb_device_create_ex.restype = vp
+    L.lcb_device_create_ex.argtypes = [vp, C.POINTER(Params), C.c_int, C.POINTER(DeviceOpts)]
+    L.lcb_device_mode_seeds.argtypes = [vp, C.POINTER(i64)]
     L.lcb_device_destroy.argtypes = [vp]
     L.lcb_device_reset_used.argtypes = [vp]
     L.lcb_device_mark_used.argtypes = [vp, vp, i64]
@@ -205,13 +220,27 @@ class JunctionStorage:
 class Device:
     """One MI355X holding the tables and the `used` bitmap in HBM."""
 
-    def __init__(self, storage, params, ordinal=0):
+    def __init__(self, storage, params, ordinal=0, **opts):
+        """opts: fields of lcb_device_opts (compact_slots, wide_slots, big_slots, path_cap, wide_path_cap, max_views, batch,
+        wide_threshold, start_mode, screen_min)."""
         self.L = load_library()
         self.storage = storage
         self.params = params
-        self.h = self.L.lcb_device_create(storage.h, C.byref(params), ordinal)
+        o = DeviceOpts()
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown device option %r" % k)
+            setattr(o, k, int(v))
+        self.h = self.L.lcb_device_create_ex(storage.h, C.byref(params), ordinal, C.byref(o))
         if not self.h:
             raise _err(self.L)
+
+    def mode_seeds(self):
+        """Seeds handed to the (compact, wide, big) kernel variants since creation."""
+        out = (C.c_int64 * 3)()
+        if self.L.lcb_device_mode_seeds(self.h, out):
+            raise _err(self.L)
+        return tuple(int(x) for x in out)
 
     def close(self):
         if getattr(self, "h", None):
@@ -343,8 +372,17 @@ class BlocksFinder:
         self.params = None
 
     def FindBlocks(self, minBlockSize, maxBranchSize, maxFlankingSize=None, lookingDepth=8, sampleSize=0, threads=1, device=None,
-                   seeds=None, hooks=None):
-        """hooks: an api.Hooks (multi-rank all-gather and/or callback engine); device may be None only with callback hooks."""
+                   seeds=None, hooks=None, **engine):
+        """hooks: an api.Hooks (multi-rank all-gather and/or callback engine); device may be None only with callback hooks.
+        engine: tuning knobs of the round engine (ENGINE_KNOBS), e.g. round_phases=7, round_fixed=1, max_views=-1."""
+        if engine:
+            if hooks is None:
+                hooks = Hooks()
+                hooks.world = 1
+            for k, v in engine.items():
+                if k not in ENGINE_KNOBS:
+                    raise TypeError("unknown engine knob %r" % k)
+                setattr(hooks, k, int(v))
         p = Params(self.k, minBlockSize, maxBranchSize, maxBranchSize if maxFlankingSize is None else maxFlankingSize, lookingDepth, 256)
         self.params = p
         callback_engine = hooks is not None and bool(hooks.process)

@@ -20,6 +20,8 @@ void lcb_set_error(const std::string& msg) { g_error = msg; }
     catch (std::exception & e) { g_error = e.what(); return ret; } \
     catch (...) { g_error = "unknown error"; return ret; }
 
+#define LCB_NEED(cond, what) do { if (!(cond)) throw LcbError(std::string(what) + ": null argument"); } while (0)
+
 extern "C" {
 
 const char* lcb_last_error(void) { return g_error.c_str(); }
@@ -49,6 +51,7 @@ const uint32_t* lcb_graph_pos_pos(const lcb_graph* g) { return g->posPos.data();
 int64_t lcb_enumerate_seeds(const lcb_graph* g, int threads, lcb_seed** out)
 {
     LCB_TRY
+    LCB_NEED(g && out, "lcb_enumerate_seeds");
     std::vector<lcb_seed> v;
     lcb_enumerate_seeds_impl(*g, threads, v);
     *out = (lcb_seed*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_seed));
@@ -65,17 +68,33 @@ lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int devic
     return lcb_device_create_impl(g, p, device_ordinal);
     LCB_CATCH(nullptr)
 }
+lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts)
+{
+    LCB_TRY
+    if (!g || !p) throw LcbError("lcb_device_create_ex: null argument");
+    return lcb_device_create_impl(g, p, device_ordinal, opts);
+    LCB_CATCH(nullptr)
+}
+int lcb_device_mode_seeds(lcb_device* d, int64_t counts[3])
+{
+    LCB_TRY
+    if (!d || !counts) throw LcbError("lcb_device_mode_seeds: null argument");
+    lcb_device_mode_seeds_impl(d, counts);
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
 void lcb_device_destroy(lcb_device* d) { lcb_device_destroy_impl(d); }
-int lcb_device_reset_used(lcb_device* d) { LCB_TRY lcb_device_reset_used_impl(d); return LCB_OK; LCB_CATCH(LCB_ERR) }
-int lcb_device_mark_used(lcb_device* d, const uint64_t* ranges, int64_t n) { LCB_TRY lcb_device_mark_used_impl(d, ranges, n); return LCB_OK; LCB_CATCH(LCB_ERR) }
-int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words) { LCB_TRY lcb_device_set_used_impl(d, words, n_words); return LCB_OK; LCB_CATCH(LCB_ERR) }
-int lcb_device_set_stats_mode(lcb_device* d, int on) { lcb_device_set_stats_impl(d, on != 0); return LCB_OK; }
-int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches) { lcb_device_kernel_time_impl(d, ms, launches); return LCB_OK; }
+int lcb_device_reset_used(lcb_device* d) { LCB_TRY LCB_NEED(d, "lcb_device_reset_used"); lcb_device_reset_used_impl(d); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_mark_used(lcb_device* d, const uint64_t* ranges, int64_t n) { LCB_TRY LCB_NEED(d && (ranges || n == 0), "lcb_device_mark_used"); lcb_device_mark_used_impl(d, ranges, n); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words) { LCB_TRY LCB_NEED(d && words, "lcb_device_set_used"); lcb_device_set_used_impl(d, words, n_words); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_set_stats_mode(lcb_device* d, int on) { LCB_TRY LCB_NEED(d, "lcb_device_set_stats_mode"); lcb_device_set_stats_impl(d, on != 0); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches) { LCB_TRY LCB_NEED(d, "lcb_device_kernel_time"); lcb_device_kernel_time_impl(d, ms, launches); return LCB_OK; LCB_CATCH(LCB_ERR) }
 
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
                       int64_t* best_score, lcb_counters* ctr)
 {
     LCB_TRY
+    LCB_NEED(d && (seeds || n == 0) && offsets && (inst || inst_cap == 0), "lcb_process_seeds");
     std::vector<uint64_t> off;
     std::vector<lcb_instance> res;
     lcb_device_process_impl(d, seeds, n, off, res, best_score, ctr);
@@ -151,11 +170,14 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
 {
     LCB_TRY
+    LCB_NEED(g && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks_ex");
     LcbEngineConfig cfg;
     if (hooks) {
         cfg.rank = hooks->rank; cfg.world = hooks->world > 0 ? hooks->world : 1;
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
+        cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -185,6 +207,7 @@ int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, cons
                     lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
 {
     LCB_TRY
+    LCB_NEED(g && d && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks");
     std::vector<lcb_block> v;
     LcbEngineConfig cfg;
     cfg.progress = progress != 0;
@@ -201,6 +224,7 @@ int lcb_generate_output(const lcb_graph* g, int64_t min_block, const lcb_block* 
                         const char* out_dir, int gen_seq, int64_t chunks, int64_t* n_trimmed, double* coverage)
 {
     LCB_TRY
+    LCB_NEED(g && (blocks || n_blocks == 0), "lcb_generate_output");
     lcb_generate_output_impl(*g, min_block, blocks, n_blocks, blocks_found, out_dir ? out_dir : "", gen_seq != 0, chunks, n_trimmed, coverage);
     return LCB_OK;
     LCB_CATCH(LCB_ERR)

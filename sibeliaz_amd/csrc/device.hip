@@ -3,9 +3,15 @@
 //
 // Data layout in HBM (one copy per GPU, read-only except `used`):
 //   chrStart u32[C+1] | posId i32[P] | posPos u32[P] | posCh u8[P] | posRevCh u8[P]
-//   occStart u32[V+1] | occG u32[P] | occChr u32[P] | used u32[ceil(P/32)+1]        ~ 18.1 B per occurrence
-// Seeds and results travel through pinned, device-mapped host memory (the kernel reads 8 B per seed
-// and writes a 96 B header + 16 B per result instance), so a launch needs no explicit copies.
+//   occStart u32[V+1] | occRec uint4[P] = {g, chr, pos, id} | used u32[ceil(P/32)+1] x (1 + views)      ~ 30 B per occurrence
+// Seeds and results travel through pinned, device-mapped host memory (the kernels read 16 B per seed and write a 40-B
+// header + 16 B per result instance + 8 B per footprint interval), so a launch needs no explicit copies.
+//
+// A launch is (optionally) a screening kernel — one thread per seed decides whether Path::Init would create any
+// instance at all and finalises the header of the seeds for which it would not — followed by the process kernel over
+// the surviving seeds in one of three variants (lcb_kernel.h): compact (1 wavefront per seed, 6 seeds per CU: launches
+// with many seeds are throughput-bound), wide (16 wavefronts share the votes of one seed: launches with few seeds are
+// as long as their longest seed) and big (per-path state in HBM for seeds that overflow the LDS capacities).
 #include <hip/hip_runtime.h>
 
 #include <time.h>
@@ -28,18 +34,23 @@
         if (e_ != hipSuccess) throw LcbError(std::string(#x) + " failed: " + hipGetErrorString(e_)); \
     } while (0)
 
-// MODE 0/1/2 = small / medium / big (lcb_kernel.h): where the per-path instance pool and vote table live.
-// NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest help with the votes (lcb_kernel.h).
-#define LCB_NW_SMALL 16
-#define LCB_NW_MEDIUM 16
-#define LCB_NW_BIG 4
-// PROF adds the flight recorder and the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
+// MODE 0/1/2 = compact / wide / big (lcb_kernel.h): where the per-path instance pool and vote table live.
+// NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest share the votes.
+#define LCB_NW_COMPACT 1
+#define LCB_NW_WIDE 16
+#define LCB_NW_BIG 8
+// PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
 template <int MODE, bool STATS, int NW, bool PROF>
 __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
                                                          LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                                          uint2* fpArena, unsigned long long fpCap)
 {
     lcb_process_body<MODE, STATS, NW, PROF>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
+}
+
+__global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
+{
+    lcb_screen_body(T, seeds, nSeeds, out, live, nLive);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(256) void lcb_init_slots_kernel(uint8_t* base, uint
     for (uint32_t i = threadIdx.x; i < pathCap; i += blockDim.x) pKeys[i] = LCB_EMPTY_KEY;
     int32_t* vKey = (int32_t*)(slot + L.vKey);
     uint32_t* vCount = (uint32_t*)(slot + L.vCount);
-    unsigned long long* vLast = (unsigned long long*)(slot + L.vLast);
+    uint32_t* vLast = (uint32_t*)(slot + L.vLast);
     for (uint32_t i = threadIdx.x; i < voteCap; i += blockDim.x) { vKey[i] = LCB_EMPTY_KEY; vCount[i] = 0; vLast[i] = 0; }
 }
 
@@ -67,19 +78,23 @@ __global__ __launch_bounds__(256) void lcb_copy_views_kernel(uint32_t* used, uin
     }
 }
 
-// MarkUsed over [lo, hi) (junctionstorage.h:285-295): one workgroup per range.
-__global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const uint64_t* ranges, uint32_t n)
+// MarkUsed over [lo, hi) (junctionstorage.h:285-295) in the views firstView .. lastView: one workgroup per range.
+struct LcbMarkRange { uint64_t lo, hi; uint32_t firstView, lastView; };
+__global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, size_t strideWords, const LcbMarkRange* ranges, uint32_t n)
 {
     const uint32_t r = blockIdx.x;
     if (r >= n) return;
-    const uint64_t lo = ranges[2 * r], hi = ranges[2 * r + 1];
+    const uint64_t lo = ranges[r].lo, hi = ranges[r].hi;
     if (hi <= lo) return;
     const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
-    for (uint64_t w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
-        uint32_t m = 0xFFFFFFFFu;
-        if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
-        if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
-        atomicOr(&used[w], m);
+    for (uint32_t v = ranges[r].firstView; v <= ranges[r].lastView; v++) {
+        uint32_t* u = used + (size_t)v * strideWords;
+        for (uint64_t w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
+            uint32_t m = 0xFFFFFFFFu;
+            if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
+            if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+            atomicOr(&u[w], m);
+        }
     }
 }
 
@@ -89,7 +104,7 @@ struct WorkSet {
     uint8_t* base = nullptr;
     uint64_t slotBytes = 0;
     uint32_t nSlots = 0, pathCap = 0, bodyCap = 0, bestCap = 0, instCap = 0, voteCap = 0;
-    int mode = 0;          // 0 small, 1 medium, 2 big
+    int mode = 0;          // 0 compact, 1 wide, 2 big
     bool big = false;      // mode == 2: instance pool and vote table in the workspace
 };
 
@@ -99,6 +114,8 @@ uint32_t envU32(const char* name, uint32_t dflt)
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+const char* modeName(int m) { return m == 2 ? "big" : (m == 1 ? "wide" : "compact"); }
+
 }  // namespace
 
 struct lcb_device_impl {
@@ -107,23 +124,24 @@ struct lcb_device_impl {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const lcb_graph* g = nullptr;
     lcb_params p{};
+    lcb_device_opts o{};
     LcbTables T{};
     LcbKParams KP{};
     std::vector<void*> owned;
     uint32_t* dUsed = nullptr;
     size_t usedWords = 0;      // words of one view (a multiple of 4)
     int maxViews = 0;          // predicted views allocated behind the live bitmap (view 0)
-    uint32_t* dCursor = nullptr;                 // [0] work tickets, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
-    uint32_t cursorBase = 0;
-    unsigned long long arenaBase = 0;
-    WorkSet small, medium, big;
+    uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
+    uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
+    WorkSet ws[3];                               // compact, wide, big
     // pinned, device-mapped host buffers
     LcbKSeed* hSeeds = nullptr;
     LcbSeedOut* hOut = nullptr;
+    LcbSeedCtr* hCtr = nullptr;                  // stats / instrumented variants only
     uint4* hArena = nullptr;
     uint2* hFp = nullptr;                        // footprint arena (pinned)
-    unsigned long long fpCap = 0, fpBase = 0;
-    uint64_t* hRanges = nullptr;
+    unsigned long long fpCap = 0;
+    LcbMarkRange* hRanges = nullptr;
     uint32_t* hDbg = nullptr;                    // flight recorder (LCB_DEBUG=1): 16 words per workgroup
     uint32_t dbgSlots = 0;
     bool forceProf = false;                      // LCB_FORCE_PROF=1: always use the instrumented kernel variants
@@ -136,11 +154,13 @@ struct lcb_device_impl {
     bool stats = false;
     bool wantFp = false;                         // emit footprints (speculative engine)
     // seeds that overflowed the LDS capacities before: (vid, ch) -> kernel mode to start with next time, so that a
-    // recomputation does not repeat the doomed small-mode attempt
+    // recomputation does not repeat the doomed attempt
     std::unordered_map<uint64_t, uint8_t> modeHint;
     std::vector<uint64_t> hintBits = std::vector<uint64_t>(1024, 0);   // 65 536-bit prefilter in front of modeHint (most seeds have no hint)
     double kernelMs = 0;
     int64_t launches = 0, bigRetries = 0;
+    int64_t modeSeeds[3] = {0, 0, 0};            // seeds handed to each kernel variant since creation
+    int64_t screened = 0, screenedDead = 0;
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
 
@@ -175,25 +195,34 @@ struct lcb_device_impl {
         HIP_CHECK(hipHostMalloc((void**)&hFp, (size_t)cap * sizeof(uint2), hipHostMallocDefault));
     }
 
-    // One launch over hSeeds[0..m): returns after the stream has drained.
-    void launch(WorkSet& w, uint32_t m)
+    // One launch over hSeeds[0..m): optional screening, then the process kernel of w's variant. Returns after the stream
+    // has drained; hOut[0..m) then holds every seed's header.
+    void launch(WorkSet& w, uint32_t m, bool screen)
     {
         LcbWork W;
         W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap;
         W.instCap = w.instCap; W.voteCap = w.voteCap;
-        W.cursor = dCursor; W.cursorBase = cursorBase;
-        W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = arenaBase;
-        W.fpCursor = (unsigned long long*)(dCursor + 4); W.fpBase = fpBase;
+        W.cursor = dCursor; W.cursorBase = 0;
+        W.live = screen ? dLive : nullptr; W.nLive = screen ? dCursor + 1 : nullptr;
+        W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = 0;
+        W.fpCursor = (unsigned long long*)(dCursor + 4); W.fpBase = 0;
+        const bool prof = (hDbg != nullptr) || seedTrace || forceProf;
+        W.ctr = (stats || prof) ? hCtr : nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
-        if (watchdogS > 0) for (uint32_t i = 0; i < m; i++) hOut[i].status = 0xFFFFFFFFu;   // lets the watchdog name unfinished seeds
+        if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
+        if (watchdogS > 0 && !screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // lets the watchdog name unfinished seeds
+        HIP_CHECK(hipMemsetAsync(dCursor, 0, 32, stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
-#define LCB_NW(MODE) (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_MEDIUM : LCB_NW_SMALL))
+        if (screen) {
+            hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
+            HIP_CHECK(hipGetLastError());
+        }
+#define LCB_NW(MODE) (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT))
 #define LCB_LAUNCH(MODE, ST, PF) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
                                                   T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
 #define LCB_LAUNCH_MODE(MODE) do { if (stats) LCB_LAUNCH(MODE, true, false); else if (prof) LCB_LAUNCH(MODE, false, true); else LCB_LAUNCH(MODE, false, false); } while (0)
-        const bool prof = W.dbg != nullptr || seedTrace || forceProf;
         if (w.mode == 2) LCB_LAUNCH_MODE(2);
         else if (w.mode == 1) LCB_LAUNCH_MODE(1);
         else LCB_LAUNCH_MODE(0);
@@ -210,14 +239,14 @@ struct lcb_device_impl {
                 if (q != hipErrorNotReady) HIP_CHECK(q);
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (el > watchdogS) {
-                    fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, w.mode == 2 ? "big" : (w.mode == 1 ? "medium" : "small"), grid, el);
+                    fprintf(stderr, "lcb: kernel watchdog: launch of %u seeds (%s mode, grid %u) still running after %.1f s\n", m, modeName(w.mode), grid, el);
                     {
                         int shownSeeds = 0;
                         uint32_t unfinished = 0;
-                        for (uint32_t i = 0; i < m; i++) if (hOut[i].status == 0xFFFFFFFFu) unfinished++;
+                        for (uint32_t i = 0; i < m; i++) if (hOut[i].status == LCB_ST_PENDING) unfinished++;
                         fprintf(stderr, "  %u of %u seeds unfinished; first ones:", unfinished, m);
                         for (uint32_t i = 0; i < m && shownSeeds < 8; i++)
-                            if (hOut[i].status == 0xFFFFFFFFu) { fprintf(stderr, " [%u] vid=%d ch=%d", i, hSeeds[i].vid, hSeeds[i].ch); shownSeeds++; }
+                            if (hOut[i].status == LCB_ST_PENDING) { fprintf(stderr, " [%u] vid=%d ch=%d", i, hSeeds[i].vid, hSeeds[i].ch); shownSeeds++; }
                         fprintf(stderr, "\n");
                     }
                     if (W.dbg) {
@@ -240,35 +269,52 @@ struct lcb_device_impl {
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         kernelMs += ms;
         launches++;
+        modeSeeds[w.mode] += m;
         if (traceFile) {
-            fprintf(traceFile, "%lld\t%u\t%u\t%s\t%.4f\n", (long long)launches, m, grid, w.mode == 2 ? "big" : (w.mode == 1 ? "medium" : "small"), ms);
-            if (!stats && seedTrace)          // per-seed profile of the slowest seeds of the launch (ticks are 10 ns)
+            fprintf(traceFile, "%lld\t%u\t%u\t%s\t%.4f\n", (long long)launches, m, grid, modeName(w.mode), ms);
+            if (!stats && seedTrace && hCtr)  // per-seed profile of the slowest seeds of the launch (ticks are 10 ns)
                 for (uint32_t i = 0; i < m; i++)
-                    if (hOut[i].ctr[0] > 2000) fprintf(traceFile, "#seed\t%lld\t%u\t%d\tst=%u\tn=%u\tticks=%llu\tpush=%llu\tvote=%llu\tprobe=%llu\tinst=%llu\ttv=%llu\ttp=%llu\tts=%llu\n", (long long)launches, i, hSeeds[i].vid,
-                            hOut[i].status, hOut[i].nInst, (unsigned long long)hOut[i].ctr[0], (unsigned long long)hOut[i].ctr[1], (unsigned long long)hOut[i].ctr[2],
-                            (unsigned long long)hOut[i].ctr[3], (unsigned long long)hOut[i].ctr[4], (unsigned long long)hOut[i].ctr[5], (unsigned long long)hOut[i].ctr[6],
-                            (unsigned long long)hOut[i].ctr[7]);
+                    if (hCtr[i].c[0] > 2000)
+                        fprintf(traceFile, "#seed\t%lld\t%u\t%d\tst=%u\tn=%u\tticks=%llu\tpush=%llu\tvote=%llu\tprobe=%llu\tinst=%llu\ttv=%llu\ttp=%llu\tts=%llu\n", (long long)launches, i, hSeeds[i].vid,
+                            hOut[i].status, hOut[i].nInst, (unsigned long long)hCtr[i].c[0], (unsigned long long)hCtr[i].c[1], (unsigned long long)hCtr[i].c[2],
+                            (unsigned long long)hCtr[i].c[3], (unsigned long long)hCtr[i].c[4], (unsigned long long)hCtr[i].c[5], (unsigned long long)hCtr[i].c[6],
+                            (unsigned long long)hCtr[i].c[7]);
         }
-        cursorBase += m + grid;                    // every workgroup consumed exactly one ticket past the end
-        for (uint32_t i = 0; i < m; i++) { arenaBase += hOut[i].nInst; fpBase += hOut[i].nFp; }
     }
 };
 
-lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal)
+lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal, const lcb_device_opts* opts)
 {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         throw LcbError("no HIP device available: the block-finder hot path runs only on the GPU (there is no CPU fallback)");
     if (ordinal < 0 || ordinal >= count) throw LcbError("HIP device ordinal out of range");
+    if (p->max_branch >= 65000 || p->looking_depth >= 65000) throw LcbError("maxBranchSize / lookingDepth of 65000 or more are not supported by the device vote table");
     auto* d = new lcb_device_impl();
     auto* handle = new lcb_device{d};
     try {
         d->ordinal = ordinal; d->g = g; d->p = *p;
+        if (opts) d->o = *opts;
+        lcb_device_opts& o = d->o;
         d->use();
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, ordinal));
+        const uint32_t nCu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+        // defaults: compact 6 workgroups per CU (LDS-bound), wide 1 per CU, big 1 per CU
+        if (!o.compact_slots) o.compact_slots = 6 * nCu;
+        if (!o.wide_slots) o.wide_slots = nCu;
+        if (!o.big_slots) o.big_slots = nCu;
+        if (!o.path_cap) o.path_cap = 32768;
+        if (!o.max_views) o.max_views = 256;
+        if (!o.batch) o.batch = 65536;
+        if (!o.wide_threshold) o.wide_threshold = 2 * o.wide_slots;
+        if (!o.screen_min) o.screen_min = 2048;
+        if (o.path_cap & (o.path_cap - 1)) throw LcbError("lcb_device_opts.path_cap must be a power of two");
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&d->ev0));
         HIP_CHECK(hipEventCreate(&d->ev1));
         const uint64_t P = g->nPos();
+        if (P >= (1ull << 32) - (1ull << 20)) throw LcbError("more than 2^32 - 2^20 junction occurrences are not supported by the device tables");
         std::vector<uint32_t> cs(g->chrStart.begin(), g->chrStart.end());
         d->T.chrStart = d->upload(cs.data(), cs.size());
         d->T.posId = d->upload(g->posId.data(), P);
@@ -278,15 +324,16 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->T.occStart = d->upload(g->occStart.data(), g->occStart.size());
         {
             std::vector<uint4> rec((size_t)P);
-            for (uint64_t j = 0; j < P; j++) {
+            #pragma omp parallel for schedule(static)
+            for (int64_t j = 0; j < (int64_t)P; j++) {
                 const uint32_t q = g->occG[j];
                 rec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]};
             }
             d->T.occRec = d->upload(rec.data(), rec.size());
         }
         d->usedWords = ((size_t)(P / 32 + 2) + 3) & ~(size_t)3;
-        // predicted `used` views for the engine's dry-run launches: at most LCB_VIEWS (default 256), within 2 GiB
-        d->maxViews = (int)std::min<uint64_t>(envU32("LCB_VIEWS", 256), (2ull << 30) / (d->usedWords * 4));
+        // predicted `used` views for the engine's dry-run launches: at most max_views, within 2 GiB
+        d->maxViews = (int)std::min<uint64_t>(o.max_views, (2ull << 30) / (d->usedWords * 4));
         HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4 * (size_t)(d->maxViews + 1)));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
         d->T.used = d->dUsed; d->T.usedStride = (uint32_t)d->usedWords;
@@ -295,22 +342,26 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->KP.depth = p->looking_depth;
         HIP_CHECK(hipMalloc((void**)&d->dCursor, 32));
         HIP_CHECK(hipMemset(d->dCursor, 0, 32));
-        // small (LDS) mode: instances / vote table in LDS, path set + bodies + snapshot in a 1/4-MB global slot
-        d->small.big = false; d->small.mode = 0; d->small.nSlots = envU32("LCB_SLOTS", 512);
-        d->small.pathCap = envU32("LCB_PATH_CAP", 32768); d->small.bodyCap = d->small.pathCap / 2; d->small.bestCap = LCB_IC_SMALL;
-        d->allocWork(d->small);
-        // medium mode: 4x the LDS capacities, one workgroup per CU
-        d->medium.big = false; d->medium.mode = 1; d->medium.nSlots = envU32("LCB_MEDIUM_SLOTS", 256);
-        d->medium.pathCap = d->small.pathCap < 131072 ? 131072 : d->small.pathCap; d->medium.bodyCap = d->medium.pathCap / 2; d->medium.bestCap = LCB_IC_MEDIUM;
-        if (envU32("LCB_FORCE_BIG", 0)) { d->medium.pathCap = d->small.pathCap; d->medium.bodyCap = d->small.bodyCap; }
-        d->allocWork(d->medium);
+        // compact and wide: instances / vote table in LDS, path set + bodies + snapshot in a global slot
+        WorkSet& c = d->ws[0];
+        c.big = false; c.mode = 0; c.nSlots = o.compact_slots;
+        c.pathCap = o.path_cap; c.bodyCap = c.pathCap / 2; c.bestCap = LcbCfg<0>::IC;
+        d->allocWork(c);
+        WorkSet& w = d->ws[1];
+        w.big = false; w.mode = 1; w.nSlots = o.wide_slots;
+        w.pathCap = o.wide_path_cap ? o.wide_path_cap : (o.path_cap < 131072 ? 131072 : o.path_cap); w.bodyCap = w.pathCap / 2; w.bestCap = LcbCfg<1>::IC;
+        if (w.pathCap & (w.pathCap - 1)) throw LcbError("lcb_device_opts.wide_path_cap must be a power of two");
+        d->allocWork(w);
         // big (global-memory) mode for seeds that overflow the LDS capacities; grows on demand
-        d->big.big = true; d->big.mode = 2; d->big.nSlots = envU32("LCB_BIG_SLOTS", 64);
-        d->big.pathCap = 262144; d->big.bodyCap = 131072; d->big.instCap = 4096; d->big.voteCap = 65536; d->big.bestCap = 4096;
-        d->allocWork(d->big);
-        d->batchCap = envU32("LCB_BATCH", 65536);
+        WorkSet& b = d->ws[2];
+        b.big = true; b.mode = 2; b.nSlots = o.big_slots;
+        b.pathCap = 262144; b.bodyCap = 131072; b.instCap = 8192; b.voteCap = 65536; b.bestCap = 8192;
+        d->allocWork(b);
+        d->batchCap = o.batch;
+        HIP_CHECK(hipMalloc((void**)&d->dLive, (size_t)d->batchCap * sizeof(uint32_t)));
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
         d->allocArena(1u << 20);
         const char* tf = getenv("LCB_TRACE_LAUNCHES");
         if (tf && *tf) d->traceFile = fopen(tf, "w");
@@ -319,13 +370,11 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         const char* wd = getenv("LCB_WATCHDOG_S");
         d->watchdogS = wd && *wd ? atof(wd) : 0;
         if (envU32("LCB_DEBUG", 0)) {
-            d->dbgSlots = d->small.nSlots;
-            if (d->medium.nSlots > d->dbgSlots) d->dbgSlots = d->medium.nSlots;
-            if (d->big.nSlots > d->dbgSlots) d->dbgSlots = d->big.nSlots;
+            d->dbgSlots = std::max(c.nSlots, std::max(w.nSlots, b.nSlots));
             HIP_CHECK(hipHostMalloc((void**)&d->hDbg, (size_t)d->dbgSlots * 16 * sizeof(uint32_t), hipHostMallocDefault));
         }
         d->rangeCap = 65536;
-        HIP_CHECK(hipHostMalloc((void**)&d->hRanges, (size_t)d->rangeCap * 2 * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&d->hRanges, (size_t)d->rangeCap * sizeof(LcbMarkRange), hipHostMallocDefault));
     } catch (...) {
         lcb_device_destroy_impl(handle);
         throw;
@@ -343,11 +392,11 @@ void lcb_device_destroy_impl(lcb_device* h)
         for (void* p : d->owned) (void)hipFree(p);
         if (d->dUsed) (void)hipFree(d->dUsed);
         if (d->dCursor) (void)hipFree(d->dCursor);
-        if (d->small.base) (void)hipFree(d->small.base);
-        if (d->medium.base) (void)hipFree(d->medium.base);
-        if (d->big.base) (void)hipFree(d->big.base);
+        if (d->dLive) (void)hipFree(d->dLive);
+        for (auto& w : d->ws) if (w.base) (void)hipFree(w.base);
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
+        if (d->hCtr) (void)hipHostFree(d->hCtr);
         if (d->hArena) (void)hipHostFree(d->hArena);
         if (d->hFp) (void)hipHostFree(d->hFp);
         if (d->hRanges) (void)hipHostFree(d->hRanges);
@@ -379,22 +428,30 @@ void lcb_device_set_used_impl(lcb_device* h, const uint32_t* words, int64_t nWor
     HIP_CHECK(hipMemcpy(d->dUsed, words, (size_t)nWords * 4, hipMemcpyHostToDevice));
 }
 
+namespace {
+// Applies ranges [lo, hi) to the views firstView..lastView of each entry, rangeCap entries per kernel; the pinned staging
+// buffer is reused, so each kernel is waited for.
+template <class F>
+void markRanges(lcb_device_impl* d, int64_t n, F fill)
+{
+    for (int64_t done = 0; done < n;) {
+        const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
+        for (uint32_t i = 0; i < m; i++) d->hRanges[i] = fill(done + i);
+        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->usedWords, d->hRanges, m);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        done += m;
+    }
+}
+}  // namespace
+
 void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
 {
     lcb_device_impl* d = h->impl;
     d->use();
     const uint64_t P = d->g->nPos();
-    for (int64_t done = 0; done < n;) {
-        const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
-        for (uint32_t i = 0; i < m; i++) {
-            if (ranges[2 * (done + i) + 1] > P) throw LcbError("used range beyond the position table");
-            d->hRanges[2 * i] = ranges[2 * (done + i)]; d->hRanges[2 * i + 1] = ranges[2 * (done + i) + 1];
-        }
-        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));   // hRanges is reused
-        done += m;
-    }
+    for (int64_t i = 0; i < n; i++) if (ranges[2 * i + 1] > P) throw LcbError("used range beyond the position table");
+    markRanges(d, n, [&](int64_t i) { return LcbMarkRange{ranges[2 * i], ranges[2 * i + 1], 0u, 0u}; });
 }
 
 void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* marks, int64_t nMarks)
@@ -407,27 +464,14 @@ void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* m
     hipLaunchKernelGGL(lcb_copy_views_kernel, dim3(std::min<uint32_t>((n4 + 255) / 256, 2048u)), dim3(256), 0, d->stream, d->dUsed,
                        (uint32_t)d->usedWords, (uint32_t)nViews);
     HIP_CHECK(hipGetLastError());
-    // a mark of view v is set in the views v..nViews: expand to bit ranges of the whole allocation
-    const uint64_t P = d->g->nPos(), viewBits = (uint64_t)d->usedWords * 32;
-    uint32_t m = 0;
-    auto flushRanges = [&]() {
-        if (!m) return;
-        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));   // hRanges is reused
-        m = 0;
-    };
-    for (int64_t k = 0; k < nMarks; k++) {
-        if (marks[k].hi > P || marks[k].firstView < 1) throw LcbError("bad predicted mark");
-        for (uint32_t v = marks[k].firstView; v <= (uint32_t)nViews; v++) {
-            d->hRanges[2 * m] = v * viewBits + marks[k].lo; d->hRanges[2 * m + 1] = v * viewBits + marks[k].hi;
-            if (++m == d->rangeCap) flushRanges();
-        }
-    }
-    flushRanges();
+    // a mark of view v is set in the views v..nViews (the kernel loops over them)
+    const uint64_t P = d->g->nPos();
+    for (int64_t k = 0; k < nMarks; k++) if (marks[k].hi > P || marks[k].firstView < 1) throw LcbError("bad predicted mark");
+    markRanges(d, nMarks, [&](int64_t k) { return LcbMarkRange{marks[k].lo, marks[k].hi, marks[k].firstView, (uint32_t)nViews}; });
 }
 
 int lcb_device_max_views_impl(lcb_device* h) { return h->impl->maxViews; }
+int lcb_device_concurrency_impl(lcb_device* h) { return (int)h->impl->ws[0].nSlots; }
 
 void lcb_device_set_stats_impl(lcb_device* h, bool on) { h->impl->stats = on; }
 
@@ -439,6 +483,7 @@ void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
 }
 
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
+void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[3]) { for (int i = 0; i < 3; i++) out[i] = h->impl->modeSeeds[i]; }
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
@@ -449,29 +494,14 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     offsets.assign((size_t)n + 1, 0);
     inst.clear();
     d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
+    // per-seed results arrive in launch order (retries out of seed order); they are laid out in seed order at the end
+    std::vector<lcb_instance> flat;                     // instances in arrival order
+    std::vector<uint64_t> flatOff((size_t)n, 0);
+    std::vector<uint32_t> cnt((size_t)n, 0);
     std::vector<lcb_fp> fpFlat;                         // footprints in arrival order (only when they are wanted) ...
     std::vector<uint64_t> fpAt;                         // ... and where each seed's intervals start / how many there are
     std::vector<uint32_t> fpCnt;
-    if (d->wantFp) { fpAt.assign((size_t)n, 0); fpCnt.assign((size_t)n, 0); fpFlat.reserve((size_t)n * 2); }
-    auto takeFp = [&](int64_t s, const LcbSeedOut& o) {
-        if (!d->wantFp) return;
-        fpAt[(size_t)s] = fpFlat.size(); fpCnt[(size_t)s] = o.nFp;
-        const uint2* src = d->hFp + o.fpOff;
-        for (uint32_t e = 0; e < o.nFp; e++) fpFlat.push_back(lcb_fp{src[e].x, src[e].y});
-    };
-    // per-seed results are gathered out of order (retries), then laid out in seed order
-    std::vector<std::vector<lcb_instance>> late;        // results of retried seeds
-    std::vector<int64_t> lateOf((size_t)n, -1);
-    std::vector<uint32_t> cnt((size_t)n, 0);
-    std::vector<lcb_instance> flat;                     // first-pass results in arena order
-    std::vector<uint64_t> flatOff((size_t)n, 0);
-    auto addCtr = [&](const LcbSeedOut& o) {
-        if (!ctr) return;
-        ctr->n_walk += o.ctr[0]; ctr->n_occ += o.ctr[1]; ctr->n_compat_call += o.ctr[2]; ctr->n_compat_step += o.ctr[3];
-        ctr->n_inst_out += o.ctr[4]; ctr->n_vote += o.ctr[5]; ctr->n_push += o.ctr[6]; ctr->n_process += o.ctr[7];
-    };
-    std::vector<int64_t> retry;                         // seeds that need larger workspaces (medium, then big)
-    std::vector<int64_t> retryBig;                      // seeds known to need the big workspaces
+    if (d->wantFp) { fpAt.assign((size_t)n, 0); fpCnt.assign((size_t)n, 0); }
     auto keyOf = [](const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; };
     auto setHint = [&](const lcb_seed& sd, uint8_t mode) {
         const uint64_t key = keyOf(sd);
@@ -479,94 +509,93 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         d->hintBits[hb >> 6] |= 1ull << (hb & 63);
         d->modeHint[key] = mode;
     };
-    std::vector<int64_t> firstPass;
-    firstPass.reserve((size_t)n);
-    if (d->modeHint.empty()) for (int64_t s = 0; s < n; s++) firstPass.push_back(s);
+    // first mode of every seed: the caller's choice, else wide for launches of few seeds (as long as their longest seed)
+    // and compact for launches of many (throughput); a seed known to overflow a mode starts in the next
+    const int base = d->o.start_mode ? (int)d->o.start_mode - 1 : (n <= (int64_t)d->o.wide_threshold ? 1 : 0);
+    std::vector<int64_t> todo[3];
+    if (d->modeHint.empty() || d->o.start_mode) { todo[base].resize((size_t)n); for (int64_t s = 0; s < n; s++) todo[base][(size_t)s] = s; }
     else
         for (int64_t s = 0; s < n; s++) {
             const uint64_t key = keyOf(seeds[s]);
             const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
-            if (!((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull)) { firstPass.push_back(s); continue; }
-            auto it = d->modeHint.find(key);
-            if (it == d->modeHint.end()) firstPass.push_back(s);
-            else if (it->second == 1) retry.push_back(s);
-            else retryBig.push_back(s);
+            int m = base;
+            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end() && it->second > m) m = it->second; }
+            todo[m].push_back(s);
         }
-    for (size_t base = 0; base < firstPass.size(); base += d->batchCap) {
-        const uint32_t m = (uint32_t)((firstPass.size() - base) < d->batchCap ? (firstPass.size() - base) : d->batchCap);
-        for (uint32_t i = 0; i < m; i++) {
-            const int64_t s = firstPass[base + i];
-            d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
-        }
-        d->launch(d->small, m);
-        for (uint32_t i = 0; i < m; i++) {
-            const LcbSeedOut& o = d->hOut[i];
-            const int64_t s = firstPass[base + i];
-            if (o.status == LCB_ST_OK) {
-                cnt[(size_t)s] = o.nInst;
-                flatOff[(size_t)s] = flat.size();
-                for (uint32_t e = 0; e < o.nInst; e++) {
-                    const uint4 r = d->hArena[o.arenaOff + e];
-                    flat.push_back(lcb_instance{r.x, r.y, r.z, r.w});
-                }
-                if (bestScore) bestScore[s] = o.bestScore;
-                takeFp(s, o);
-                addCtr(o);
-            } else if (o.status == LCB_ST_DIST_OVF) {
-                throw LcbError("a path longer than 2^31 bp is not supported");
-            } else { retry.push_back(s); if (o.status != LCB_ST_ARENA_OVF) setHint(seeds[s], 1); }
-        }
-    }
-    // retries: medium mode (4x LDS capacities) first, then big mode, growing its capacities while seeds keep overflowing
-    for (int round = 0; !retry.empty() || !retryBig.empty(); round++) {
-        if (round > 13) throw LcbError("a seed keeps overflowing the device workspaces");
-        WorkSet& ws = round == 0 ? d->medium : d->big;
-        if (round == 1) { retry.insert(retry.end(), retryBig.begin(), retryBig.end()); retryBig.clear(); }
-        std::vector<int64_t> again;
-        for (size_t base = 0; base < retry.size(); base += d->batchCap) {
-            const uint32_t m = (uint32_t)((retry.size() - base) < d->batchCap ? (retry.size() - base) : d->batchCap);
+    for (int round = 0; ; round++) {
+        int mode = -1;
+        for (int m = 0; m < 3; m++) if (!todo[m].empty()) { mode = m; break; }
+        if (mode < 0) break;
+        if (round > 16) throw LcbError("a seed keeps overflowing the device workspaces");
+        WorkSet& ws = d->ws[mode];
+        std::vector<int64_t> list;
+        list.swap(todo[mode]);
+        bool bigOverflow = false;
+        for (size_t at = 0; at < list.size(); at += d->batchCap) {
+            const uint32_t m = (uint32_t)std::min<size_t>(list.size() - at, d->batchCap);
             for (uint32_t i = 0; i < m; i++) {
-                const int64_t s = retry[base + i];
+                const int64_t s = list[at + i];
                 d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
             }
-            if (round > 0) d->bigRetries += m;
-            d->launch(ws, m);
+            if (mode == 2) d->bigRetries += m;
+            const bool screen = !d->stats && m >= d->o.screen_min;
+            d->launch(ws, m, screen);
+            if (screen) d->screened += m;
             for (uint32_t i = 0; i < m; i++) {
                 const LcbSeedOut& o = d->hOut[i];
-                const int64_t s = retry[base + i];
+                const int64_t s = list[at + i];
                 if (o.status == LCB_ST_OK) {
+                    if (screen && o.nInst == 0 && o.nFp == 0) d->screenedDead++;
                     cnt[(size_t)s] = o.nInst;
-                    lateOf[(size_t)s] = (int64_t)late.size();
-                    late.emplace_back();
-                    for (uint32_t e = 0; e < o.nInst; e++) {
-                        const uint4 r = d->hArena[o.arenaOff + e];
-                        late.back().push_back(lcb_instance{r.x, r.y, r.z, r.w});
+                    flatOff[(size_t)s] = flat.size();
+                    if (o.nInst) {
+                        const uint4* src = d->hArena + o.arenaOff;
+                        const size_t f0 = flat.size();
+                        flat.resize(f0 + o.nInst);
+                        for (uint32_t e = 0; e < o.nInst; e++) flat[f0 + e] = lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w};
                     }
                     if (bestScore) bestScore[s] = o.bestScore;
-                    takeFp(s, o);
-                    addCtr(o);
+                    if (d->wantFp) {
+                        fpAt[(size_t)s] = fpFlat.size(); fpCnt[(size_t)s] = o.nFp;
+                        const uint2* src = d->hFp + o.fpOff;
+                        const size_t f0 = fpFlat.size();
+                        fpFlat.resize(f0 + o.nFp);
+                        for (uint32_t e = 0; e < o.nFp; e++) fpFlat[f0 + e] = lcb_fp{src[e].x, src[e].y};
+                    }
+                    if (ctr) {
+                        const LcbSeedCtr& k = d->hCtr[i];
+                        ctr->n_walk += k.c[0]; ctr->n_occ += k.c[1]; ctr->n_compat_call += k.c[2]; ctr->n_compat_step += k.c[3];
+                        ctr->n_inst_out += k.c[4]; ctr->n_vote += k.c[5]; ctr->n_push += k.c[6]; ctr->n_process += k.c[7];
+                    }
                 } else if (o.status == LCB_ST_DIST_OVF) {
                     throw LcbError("a path longer than 2^31 bp is not supported");
-                } else { again.push_back(s); if (o.status != LCB_ST_ARENA_OVF) setHint(seeds[s], 2); }
+                } else if (o.status == LCB_ST_PENDING) {
+                    throw LcbError("device: a seed of the launch was not processed");
+                } else if (o.status == LCB_ST_ARENA_OVF) {
+                    todo[mode].push_back(s);                          // same mode again: the arena is emptied between launches
+                } else {
+                    const int nextMode = mode < 2 ? mode + 1 : 2;
+                    if (mode == 2) bigOverflow = true; else setHint(seeds[s], (uint8_t)nextMode);
+                    todo[nextMode].push_back(s);
+                }
             }
         }
-        if (!again.empty() && round > 0) {
+        if (!todo[mode].empty() && mode < 2 && todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
+        if (bigOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
+            WorkSet& b = d->ws[2];
+            if (b.instCap >= 32768) throw LcbError("a seed needs more than 32768 path instances: not supported by the device");
             d->allocArena(d->arenaCap * 4);
-            d->big.pathCap *= 2; d->big.bodyCap *= 2; d->big.instCap *= 2; d->big.voteCap *= 2; d->big.bestCap *= 2;
-            d->allocWork(d->big);
-        }
-        retry.swap(again);
+            b.pathCap *= 2; b.bodyCap *= 2; b.instCap *= 2; b.voteCap *= 2; b.bestCap *= 2;
+            d->allocWork(b);
+        } else if (mode == 2 && !todo[2].empty()) d->allocArena(d->arenaCap * 4);
     }
     uint64_t total = 0;
     for (int64_t s = 0; s < n; s++) { offsets[(size_t)s] = total; total += cnt[(size_t)s]; }
     offsets[(size_t)n] = total;
     inst.resize((size_t)total);
-    for (int64_t s = 0; s < n; s++) {
-        if (!cnt[(size_t)s]) continue;
-        const lcb_instance* src = lateOf[(size_t)s] >= 0 ? late[(size_t)lateOf[(size_t)s]].data() : flat.data() + flatOff[(size_t)s];
-        memcpy(inst.data() + offsets[(size_t)s], src, (size_t)cnt[(size_t)s] * sizeof(lcb_instance));
-    }
+    for (int64_t s = 0; s < n; s++)
+        if (cnt[(size_t)s]) memcpy(inst.data() + offsets[(size_t)s], flat.data() + flatOff[(size_t)s], (size_t)cnt[(size_t)s] * sizeof(lcb_instance));
     if (d->wantFp) {
         fpOffsets->assign((size_t)n + 1, 0);
         uint64_t tf = 0;
@@ -591,6 +620,7 @@ struct DeviceProcessor : LcbProcessor {
         lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view);
     }
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
+    int concurrency() const override { return lcb_device_concurrency_impl(dev); }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { lcb_device_build_views_impl(dev, nViews, marks, nMarks); }
     void mark(const uint64_t* ranges, int64_t n) override { lcb_device_mark_used_impl(dev, ranges, n); }
     void reset() override { lcb_device_reset_used_impl(dev); }
@@ -615,7 +645,7 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->wall_ms = es.wallMs;
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
-            stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-            stats->process_ms = es.processMs; stats->plan_ms = es.planMs;
+        stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
+        stats->process_ms = es.processMs; stats->plan_ms = es.planMs;
     }
 }

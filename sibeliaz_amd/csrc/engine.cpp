@@ -128,22 +128,18 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // (sparse stretches: many seeds that walk a little and commit nothing) and only adds redundant work where every seed
     // of a region is invalidated by the region's first commit, so the size doubles after a round with few recomputed
     // seeds and halves after one with many.
-    int maxRound = cfg.roundPhases;
-    if (maxRound <= 0) { const char* e = getenv("LCB_ROUND_PHASES"); maxRound = e && *e ? atoi(e) : 256; }
-    if (maxRound < 1) maxRound = 1;
-    const char* fixedEnv = getenv("LCB_ROUND_FIXED");
-    const bool fixedRound = fixedEnv && *fixedEnv && atoi(fixedEnv) != 0;
+    int maxRound = cfg.roundPhases > 0 ? cfg.roundPhases : 256;
+    const bool fixedRound = cfg.roundFixed;
     int roundPhases = fixedRound ? maxRound : 1;
-    const char* eagerEnv = getenv("LCB_EAGER_PHASES");
-    const int eagerPhases = eagerEnv && *eagerEnv ? std::max(0, atoi(eagerEnv)) : 256;     // how far ahead a dry run plans
-    const char* viewEnv = getenv("LCB_VIEWS");
-    const int maxViews = std::min(proc.maxViews(), viewEnv && *viewEnv ? std::max(0, atoi(viewEnv)) : 1 << 30);
-    const bool debug = getenv("LCB_ENGINE_DEBUG") != nullptr;
-    const char* jobsEnv = getenv("LCB_MAX_JOBS");
-    const size_t maxJobs = jobsEnv && *jobsEnv ? (size_t)std::max(1, atoi(jobsEnv)) : 16384;   // a dry run stops planning ahead beyond this
-    const char* predEnv = getenv("LCB_PREDICT_F");
-    const int predictF = predEnv && *predEnv ? atoi(predEnv) : 3;   // how the dry run predicts the F of a conflicting seed:
-                                                                    // 0/1 nothing, 2 the still-free instances of E, 3 a stale F if there is one, else as 2
+    const int eagerPhases = cfg.eagerPhases < 0 ? 0 : (cfg.eagerPhases ? cfg.eagerPhases : 256);   // how far ahead a dry run plans
+    const int maxViews = cfg.maxViews < 0 ? 0 : (cfg.maxViews ? std::min(cfg.maxViews, proc.maxViews()) : proc.maxViews());
+    const bool debug = getenv("LCB_ENGINE_DEBUG") != nullptr;                                      // diagnostics only
+    // A dry run stops planning ahead beyond this many jobs: a launch is as long as its longest seed as long as every job
+    // has a workgroup of its own; jobs beyond the processor's seeds in flight only queue up behind speculation that may
+    // never be used.
+    const size_t maxJobs = (size_t)std::max(1, cfg.maxJobs > 0 ? cfg.maxJobs : proc.concurrency());
+    const int predictF = cfg.predictF > 0 ? cfg.predictF : 3;       // how the dry run predicts the F of a conflicting seed:
+                                                                    // 1 nothing, 2 the still-free instances of E, 3 a stale F if there is one, else as 2
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
 
@@ -360,7 +356,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                             // a stale F (computed against a view that did not come true) is the best guess at hand
                             const Cand& c = cands[(size_t)fIdx[(size_t)j]];
                             if (c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
-                        } else if (predictF) {
+                        } else if (predictF >= 2) {
                             // prediction of F: the parts of E that are free, if the seed's own stretch survives; erring on
                             // the small side is harmless (under-prediction), erring on the large side voids later views
                             guess.clear();
@@ -368,7 +364,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                                 uint64_t lo, hi; instRange(g, r[k], lo, hi);
                                 if (hi > lo && !com.anyUsed(lo, hi) && !simP.hits(lo, hi - 1)) guess.push_back(r[k]);
                             }
-                            if (guess.size() > 1 && predictF >= 2) simAdd(guess.data(), guess.size());
+                            if (guess.size() > 1) simAdd(guess.data(), guess.size());
                         }
                     }
                 }

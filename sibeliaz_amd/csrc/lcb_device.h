@@ -14,7 +14,7 @@ struct lcb_device {
     lcb_device_impl* impl;
 };
 
-lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal);
+lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int ordinal, const lcb_device_opts* opts = nullptr);
 void lcb_device_destroy_impl(lcb_device* d);
 void lcb_device_reset_used_impl(lcb_device* d);
 void lcb_device_mark_used_impl(lcb_device* d, const uint64_t* ranges, int64_t n);
@@ -28,6 +28,8 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
 void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_max_views_impl(lcb_device* d);
+int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
+void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[3]);
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,

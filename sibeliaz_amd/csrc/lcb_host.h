@@ -83,6 +83,8 @@ struct LcbProcessor {
     virtual void reset() = 0;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
     virtual int maxViews() const { return 0; }
+    // seeds the processor works on at the same time: a dry run plans about this many jobs per launch (more only queue up)
+    virtual int concurrency() const { return 16384; }
     virtual void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) { (void)nViews; (void)marks; (void)nMarks; }
 };
 
@@ -93,8 +95,13 @@ struct LcbEngineConfig {
     int rank = 0, world = 1;
     lcb_allgather_fn allgather = nullptr;
     void* allgatherUser = nullptr;
-    int roundPhases = 0;      // phases launched speculatively per round (0 = LCB_ROUND_PHASES or the default)
+    int roundPhases = 0;      // phases launched speculatively per round, upper bound of the adaptive size (0 = 256)
     bool progress = false;
+    bool roundFixed = false;  // every round has roundPhases phases
+    int eagerPhases = 0;      // phases a dry run plans ahead (0 = 256, -1 = none)
+    int maxViews = 0;         // predicted views per job launch (0 = all the processor has, -1 = none)
+    int maxJobs = 0;          // a dry run stops planning beyond this many jobs (0 = the processor's concurrency)
+    int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
 };
 
 struct LcbEngineStats {

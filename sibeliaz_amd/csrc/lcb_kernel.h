@@ -1,8 +1,8 @@
 // lcb_kernel.h — gfx950 device code of the per-seed path-extension / bubble-scoring hot path.
 //
-// One seed (BlocksFinder::Bundle) per workgroup: wavefront 0 runs the per-seed algorithm, the other wavefronts of the
-// workgroup are helpers that share the look-ahead vote.
-// This replaces ProcessVertex::Process (blocksfinder.h:228-310) and everything under it:
+// One seed (BlocksFinder::Bundle) per workgroup. Wavefront 0 runs the per-seed algorithm; the other wavefronts of the
+// workgroup (NW - 1 of them, none in the compact mode) share the look-ahead vote: its voter walks, its arg-max and the
+// clearing of the vote table. This replaces ProcessVertex::Process (blocksfinder.h:228-310) and everything under it:
 // MostPopularVertex (blocksfinder.h:708-768), ExtendPathForward/Backward (:770-895), Path::Init,
 // PointPushBack/Front + workers, Compatible, Score, Clear (path.h:33-46,380-677) and
 // DistanceKeeper (distancekeeper.h:9-41). It is a new design, not a translation:
@@ -14,10 +14,13 @@
 //  * the dense per-thread vote array count[2V+1] becomes an LDS hash table filled with
 //    ds atomics; the order-dependent running arg-max of the reference is restated order-free
 //    (max count, then smallest origin of the last contributing instance in list order, then
-//    earliest walk step — SURVEY.md Q7) so all (instance, step) pairs can vote concurrently;
+//    earliest walk step — SURVEY.md Q7) so all (instance, step) pairs can vote concurrently; the voters of a vote
+//    (instances that end at the path end) are found lane-parallel, 64 list entries per pass;
 //  * the dense DistanceKeeper int[2V] becomes a per-wave open-addressing vertex set in global
-//    memory; distances are carried by the instances (an instance's back/front distance IS the
-//    path distance of its end vertex), so no distance lookups remain;
+//    memory behind an LDS Bloom filter; distances are carried by the instances (an instance's back/front
+//    distance IS the path distance of its end vertex), so no distance lookups remain;
+//  * the edges between the origin of a vote and the chosen vertex are fetched as one batch (lanes = edges: table rows
+//    and CSR bounds of all of them at once), and the occurrence records of edge j+1 are in flight while edge j is pushed;
 //  * a push evaluates all occurrences of the pushed vertex lane-parallel against the pre-push
 //    state and resolves the (rare) occurrences that fall into the same gap between two
 //    instances with a closed-form prefix rule that reproduces the sequential semantics;
@@ -27,7 +30,9 @@
 //    engine.cpp) and reports the FOOTPRINT of the bits it read as 0, which is what makes speculation exact;
 //  * the replay of the forward extension (blocksfinder.h:271-284) restarts at a checkpoint taken at a best point.
 //
-// All cross-lane operations (__ballot/__shfl/LCB_WAVE_SYNC) sit in wave-uniform control flow.
+// Wave-uniform values are kept in scalar registers explicitly (lcb_rfl / lcb_rl): what a lane loads from a uniform
+// address is uniform, but the compiler cannot know that, and per-lane copies of uniform state turn every branch into
+// exec-mask bookkeeping. All cross-lane operations sit in wave-uniform control flow.
 // Integer arithmetic only; no MFMA — the work is indexing, not contraction.
 #ifndef LCB_KERNEL_H
 #define LCB_KERNEL_H
@@ -37,19 +42,20 @@
 
 #define LCB_EMPTY_KEY INT32_MIN
 // The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
-// when the recorder is off (measured: 0.3 %). An earlier build hung or faulted on gfx950 with the sites compiled out
-// (no longer reproducible); the recorder is what would localise a recurrence, so it stays in.
+// when the recorder is off. The recorder is what localises a hang on the device (host watchdog, device.hip).
 #define LCB_FLIGHT_RECORDER 1
 
-// Three kernel variants by where the per-path state lives. Seeds that overflow one are re-run by the host in the next:
-//   mode 0 "small":  instances + vote table in 79 KB of LDS  -> 2 workgroups per CU
-//   mode 1 "medium": 2x the capacities in 154 KB of LDS       -> 1 workgroup per CU
-//   mode 2 "big":    instances + vote table in the global-memory workspace, capacities chosen by the host
-#define LCB_IC_SMALL 512u    // instances
-#define LCB_VC_SMALL 2048u   // vote-table slots (power of two)
+// Three kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
+// re-run by the host in the next:
+//   mode 0 "compact": 256 instances / 512 vote slots in 25 KB of LDS -> 6 single-wave workgroups per CU (throughput)
+//   mode 1 "wide":    1024 / 2048 in 110 KB of LDS, 16 wavefronts share the votes -> 1 workgroup per CU (latency)
+//   mode 2 "big":     instances + vote table in the global-memory workspace, capacities chosen by the host
+template <int MODE> struct LcbCfg;
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 512, BW = 512; };
+template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 2048; };
+template <> struct LcbCfg<2> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048; };
+#define LCB_IC_SMALL 256u
 #define LCB_IC_MEDIUM 1024u
-#define LCB_VC_MEDIUM 4096u
-#define LCB_BLOOM_WORDS 1024u  // LDS Bloom filter in front of the path vertex set (32768 bits, 2 hashes)
 
 enum LcbStatus : uint32_t {
     LCB_ST_OK = 0,
@@ -59,6 +65,7 @@ enum LcbStatus : uint32_t {
     LCB_ST_BEST_OVF = 4,   // result snapshot buffer full
     LCB_ST_ARENA_OVF = 5,  // batch result arena full
     LCB_ST_DIST_OVF = 6,   // path distance does not fit 32 bits (unsupported, > 2 Gbp paths)
+    LCB_ST_PENDING = 0xFFFFFFFFu,   // header written by the screening kernel for a live seed (the process kernel overwrites it)
 };
 
 struct LcbTables {
@@ -77,7 +84,7 @@ struct LcbTables {
 struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
 struct LcbKSeed { int32_t vid; int32_t ch; uint32_t view; uint32_t pad; };   // view: which `used` view this seed reads
 
-struct LcbSeedOut {            // per-seed header written by the kernel
+struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint32_t nInst;
     uint32_t status;
     int64_t bestScore;
@@ -85,10 +92,10 @@ struct LcbSeedOut {            // per-seed header written by the kernel
     uint64_t fpOff;            // first footprint interval of this seed in the footprint arena
     uint32_t nFp;              // number of footprint intervals (= instances ever created)
     uint32_t pad;
-    uint64_t ctr[8];           // lcb_counters order in stats mode, a cheap profile otherwise
 };
+struct LcbSeedCtr { uint64_t c[8]; };   // lcb_counters order in stats mode, a cheap profile in the instrumented variant
 
-struct LcbWork {               // per-wave global-memory workspace slots
+struct LcbWork {               // per-workgroup global-memory workspace slots + the work queue of one launch
     uint8_t* base;
     uint64_t slotBytes;
     uint32_t pathCap;          // power of two
@@ -97,18 +104,21 @@ struct LcbWork {               // per-wave global-memory workspace slots
     uint32_t instCap;          // big mode only
     uint32_t voteCap;          // big mode only, power of two
     uint32_t* cursor;          // work-queue head: monotone ticket counter, never reset ...
-    uint32_t cursorBase;       // ... tickets of this launch are [cursorBase, cursorBase + nSeeds)
+    uint32_t cursorBase;       // ... tickets of this launch are [cursorBase, cursorBase + nTickets)
+    const uint32_t* live;      // ticket -> seed index (written by lcb_screen_kernel), or null: ticket == seed index
+    const uint32_t* nLive;     // number of tickets when `live` is set
     unsigned long long* arenaCursor;   // monotone result-arena allocator
     unsigned long long arenaBase;
     unsigned long long* fpCursor;      // monotone footprint-arena allocator
     unsigned long long fpBase;
+    LcbSeedCtr* ctr;           // per-seed counters (stats / instrumented variants), or null
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
 };
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
     uint64_t pKeys, pSlots, body, best, ck;                   // always (ck: forward-extension checkpoint, 6 words per instance)
-    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, vTouched, fp;   // big mode
+    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, fp;   // big mode
     uint64_t total;
 };
 __host__ __device__ inline uint64_t lcb_align16(uint64_t x) { return (x + 15) & ~15ull; }
@@ -122,21 +132,20 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.body = o; o = lcb_align16(o + 8ull * bodyCap);
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
     L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
-    L.inst = o; o = lcb_align16(o + 10ull * 4 * instCap);
+    L.inst = o; o = lcb_align16(o + 9ull * 4 * instCap);
     L.ordKey = o; o = lcb_align16(o + 2ull * 4 * instCap);
     L.ordIdx = o; o = lcb_align16(o + 2ull * 4 * instCap);
     L.good = o; o = lcb_align16(o + 4ull * instCap);
     L.vKey = o; o = lcb_align16(o + 4ull * voteCap);
     L.vCount = o; o = lcb_align16(o + 4ull * voteCap);
-    L.vLast = o; o = lcb_align16(o + 8ull * voteCap);
-    L.vTouched = o; o = lcb_align16(o + 4ull * voteCap);
+    L.vLast = o; o = lcb_align16(o + 4ull * voteCap);
     L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
     L.total = lcb_align16(o);
     return L;
 }
 
 // ---- wave primitives ---------------------------------------------------------------------------
-// Orders LDS/global accesses between the lanes of the (single) wavefront of the workgroup.
+// Orders LDS/global accesses between the lanes of one wavefront.
 #define LCB_WAVE_SYNC()                                           \
     do {                                                          \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    \
@@ -150,16 +159,39 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
         if (LCB_FLIGHT_RECORDER && (S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
     } while (0)
 
+// wave-uniform value -> scalar register (every lane must hold the same value; uniform control flow only)
+__device__ __forceinline__ uint32_t lcb_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int32_t lcb_rfl(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane `l` (l wave-uniform) -> scalar register
+__device__ __forceinline__ uint32_t lcb_rl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ int32_t lcb_rl(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
+
+// Wave-wide max / min of a 32-bit value as a scalar: four row-shift steps inside the 16-lane rows, two row broadcasts,
+// result in lane 63 (DPP, no LDS traffic).
+__device__ __forceinline__ uint32_t lcb_wave_umax(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:1
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:2
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:4
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:8
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;   // row_bcast:15
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;   // row_bcast:31
+    return lcb_rl(v, 63);
+}
+__device__ __forceinline__ uint32_t lcb_wave_umin(uint32_t v) { return ~lcb_wave_umax(~v); }
+
 #define LCB_FLAG_POS 1u
 #define LCB_FLAG_BACKFIN 2u
 #define LCB_FLAG_FRONTFIN 4u
+#define LCB_FLAG_BITS 3u       // iFlags = (chromosome << 3) | flags
 
 struct LcbState {
     LcbTables T;
     LcbKParams P;
     uint32_t lane;
     // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
-    uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iChr, *iLo, *iHi, *iFlags;
+    uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iLo, *iHi, *iFlags;
     int32_t *iFrontDist, *iBackDist;
     uint32_t* ordKey;          // instance_ ordered sets flattened: keys (flat compare position) ... [2][instCap], half `cur` is live
     uint32_t* ordIdx;          // ... and pool indices, double buffered the same way
@@ -171,18 +203,19 @@ struct LcbState {
     uint32_t *fpLo, *fpHi;
     uint32_t nFp;
     uint32_t instCap;
-    // vote table
+    // vote table (open addressing): key, accumulated weight, (list ordinal << 16) | step of the last contribution
     int32_t* vKey;
     uint32_t* vCount;
-    unsigned long long* vLast; // (list ordinal << 32) | step of the last contribution
-    uint32_t* vTouched;
-    uint32_t* vNTouched;       // LDS counter
+    uint32_t* vLast;
+    uint32_t* vNClaimed;       // LDS counter: slots claimed in the current vote
+    uint32_t* vOvf;            // LDS flag: a walk of the current vote could not place a vertex
     uint32_t voteCap, voteShift;
     uint32_t* scr;             // LDS scratch, 4 * 64 words
     uint32_t* bloom;           // LDS Bloom filter over the path vertex set
+    uint32_t bloomShift;
     uint32_t* mail;            // LDS mailbox to the helper wavefronts (LCB_MAIL_*)
+    uint32_t* part;            // LDS: per-wave partial arg-max results, 8 words per wave
     unsigned long long* mailWalk;   // stats: walk steps counted by the helpers
-    uint32_t nWaves;           // wavefronts in this workgroup (1 = no helpers)
     // path vertex set + bodies + result snapshot (global workspace)
     int32_t* pKeys;
     uint32_t* pSlots;
@@ -200,7 +233,7 @@ struct LcbState {
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
     uint32_t* dbg;             // flight recorder of this workgroup (may be null)
-    uint32_t pfPush, pfVote, pfMaxProbe, pfMaxInst;   // cheap always-on per-seed profile (wave-uniform)
+    uint32_t pfPush, pfVote, pfMaxProbe, pfMaxInst;   // cheap per-seed profile of the instrumented variant (wave-uniform)
     uint64_t pfTVote, pfTPush, pfTScore;              // 10 ns ticks spent in the vote / push / score+snapshot sections
     // per-lane event counters (stats mode)
     uint64_t cWalk, cOcc, cCompatCall, cCompatStep, cVote, cPush;
@@ -265,15 +298,15 @@ __device__ __forceinline__ int64_t lcb_wave_sum(int64_t v)
 }
 
 // ---- path vertex set (DistanceKeeper::IsSet / Set / Unset, distancekeeper.h:17-35) --------------
-// Exact open-addressing set in the wave's global workspace, fronted by an LDS Bloom filter: the common
+// Exact open-addressing set in the workgroup's global workspace, fronted by an LDS Bloom filter: the common
 // answer during a look-ahead walk is "not in the path", which the filter gives from LDS without touching
 // global memory; only filter hits probe the exact table.
-__device__ __forceinline__ uint32_t lcb_bloom1(int32_t vid) { return ((uint32_t)vid * 2654435761u) >> 17; }
-__device__ __forceinline__ uint32_t lcb_bloom2(int32_t vid) { return ((uint32_t)vid * 0xC2B2AE35u + 0x27D4EB2Fu) >> 17; }
+__device__ __forceinline__ uint32_t lcb_bloom1(int32_t vid, uint32_t sh) { return ((uint32_t)vid * 2654435761u) >> sh; }
+__device__ __forceinline__ uint32_t lcb_bloom2(int32_t vid, uint32_t sh) { return ((uint32_t)vid * 0xC2B2AE35u + 0x27D4EB2Fu) >> sh; }
 
 __device__ __forceinline__ bool lcb_bloom_maybe(const LcbState& S, int32_t vid)
 {
-    const uint32_t a = lcb_bloom1(vid), b = lcb_bloom2(vid);
+    const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
     return ((S.bloom[a >> 5] >> (a & 31)) & (S.bloom[b >> 5] >> (b & 31)) & 1u) != 0;
 }
 
@@ -281,13 +314,14 @@ __device__ inline bool lcb_path_probe(const LcbState& S, int32_t vid, uint32_t& 
 {
     uint32_t h = lcb_hash(vid, S.pathShift);
     const uint32_t mask = S.pathCap - 1;
-    for (uint32_t probe = 0; probe < S.pathCap; probe++) {      // the set is at most half full; the bound only guards a corrupted table
-        const int32_t k = S.pKeys[h];
-        if (k == vid || k == LCB_EMPTY_KEY) { probes = probe; return k == vid; }
-        h = (h + 1) & mask;
+    uint32_t probe = 0;
+    int32_t k = S.pKeys[h];
+    while (k != vid && k != LCB_EMPTY_KEY && probe < S.pathCap) {   // the set is at most half full; the bound only guards a corrupted table
+        h = (h + 1) & mask; probe++;
+        k = S.pKeys[h];
     }
-    probes = S.pathCap;
-    return false;
+    probes = probe;
+    return k == vid;
 }
 
 __device__ __forceinline__ bool lcb_path_contains(const LcbState& S, int32_t vid)
@@ -295,16 +329,6 @@ __device__ __forceinline__ bool lcb_path_contains(const LcbState& S, int32_t vid
     if (!lcb_bloom_maybe(S, vid)) return false;
     uint32_t probes;
     return lcb_path_probe(S, vid, probes);
-}
-
-// same, also reporting the probe length (profiling); wave-uniform callers only
-__device__ __forceinline__ bool lcb_path_contains_p(LcbState& S, int32_t vid)
-{
-    if (!lcb_bloom_maybe(S, vid)) return false;
-    uint32_t probes = 0;
-    const bool r = lcb_path_probe(S, vid, probes);
-    if (probes > S.pfMaxProbe) S.pfMaxProbe = probes;
-    return r;
 }
 
 // Wave-uniform: inserts vid (not present). Lane 0 writes.
@@ -319,7 +343,7 @@ __device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
     LCB_WAVE_SYNC();               // every lane has finished probing before lane 0 publishes the key
     if (S.lane == 0) {
         S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
-        const uint32_t a = lcb_bloom1(vid), b = lcb_bloom2(vid);
+        const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
         S.bloom[a >> 5] |= 1u << (a & 31);
         S.bloom[b >> 5] |= 1u << (b & 31);
     }
@@ -328,10 +352,11 @@ __device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
 }
 
 // Path::Clear (path.h:650-677): wave-uniform. The right-body list is kept (the replay reads it).
+template <int BW>
 __device__ inline void lcb_path_clear(LcbState& S)
 {
     for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
-    if (S.nPath) for (uint32_t i = S.lane; i < LCB_BLOOM_WORDS; i += 64) S.bloom[i] = 0;
+    if (S.nPath) for (uint32_t i = S.lane; i < (uint32_t)BW; i += 64) S.bloom[i] = 0;
     S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0;
     S.rightFlank = 0; S.leftFlank = 0;
     LCB_WAVE_SYNC();
@@ -377,7 +402,7 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
     lcb_path_insert(S, vid);          // distanceKeeper_.Set(vid, 0)
     if (S.status) return;
     const uint32_t av = (uint32_t)(vid < 0 ? -vid : vid);
-    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
+    const uint32_t o0 = lcb_rfl(T.occStart[av]), o1 = lcb_rfl(T.occStart[av + 1]);
     for (uint32_t base = o0; base < o1; base += 64) {
         const uint32_t j = base + S.lane;
         bool ok = false;
@@ -397,8 +422,8 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
         if (ok) {
             const uint32_t i = S.nInst + (uint32_t)__popcll(m & ((1ull << S.lane) - 1));
             S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
-            S.iFrontDist[i] = 0; S.iBackDist[i] = 0; S.iChr[i] = chr; S.iLo[i] = lo; S.iHi[i] = hi;
-            S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
+            S.iFrontDist[i] = 0; S.iBackDist[i] = 0; S.iLo[i] = lo; S.iHi[i] = hi;
+            S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }        // the replay re-creates instance i at the same occurrence
             S.ordKey[S.cur * S.instCap + i] = g;   // occurrences ascend in g, so pool order == key order here
             S.ordIdx[S.cur * S.instCap + i] = i;
@@ -410,65 +435,92 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
 }
 
 // ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
-// Returns the chosen vertex (0 = none) and the pool index of the origin instance.
-// The voter walks of one vote. With helper wavefronts (nWaves > 1) wave w takes list entries e == w (mod nWaves); all
-// waves accumulate into the shared LDS vote table with atomics, so the split needs no merging.
+// One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717). Its scalars live in SGPRs.
+struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
+struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
+
+// The voter walks of one vote. Wave w of nWaves takes the voters with ordinal == w (mod nWaves); all waves accumulate
+// into the shared vote table with atomics, so the split needs no merging. The list is scanned 64 entries per pass.
 template <bool STATS>
-__device__ inline bool lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
+__device__ inline void lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
                                      uint32_t waveId, uint32_t nWaves)
 {
     const LcbTables& T = S.T;
-    const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
     const uint32_t vmask = S.voteCap - 1;
-    bool ovf = false;
-    // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717); its look-ahead window is
-    // walked 64 steps per pass, lanes = steps. The three table reads of a pass (pos, id, used word) are independent and
-    // issued together; the first pass of the NEXT voter is issued before the current one is consumed, so its latency
-    // hides behind the LDS work of this one.
-    struct Voter { uint32_t e, i, g0, pos0, lo, hi, weight; int32_t dir; bool positive; };
-    struct Walk { uint32_t g, pos; int32_t id; bool valid, used; };
-    auto nextVoter = [&](uint32_t e, Voter& v) -> bool {
-        for (; e < nList; e += nWaves) {
-            const uint32_t i = useGood ? S.good[e] : e;
-            // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
-            if ((forward ? S.iBackDist[i] : S.iFrontDist[i]) != flank) continue;
-            v.e = e; v.i = i;
-            v.positive = (S.iFlags[i] & LCB_FLAG_POS) != 0;
-            v.g0 = forward ? S.iBackG[i] : S.iFrontG[i];
-            v.pos0 = forward ? S.iBackPos[i] : S.iFrontPos[i];
-            v.lo = S.iLo[i]; v.hi = S.iHi[i];
-            v.weight = lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]) + 1u;            // blocksfinder.h:719
+    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
+    const uint32_t depth = (uint32_t)S.P.depth, maxBranch = (uint32_t)S.P.maxBranch;
+    // list scan state: the current chunk of 64 list entries (per-lane fields) and the voters still to hand out from it
+    uint32_t chunkBase = 0, ordinal = 0;
+    unsigned long long pend = 0;
+    uint32_t fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
+    bool scanned = false;
+    auto nextVoter = [&](LcbVoter& v) -> bool {
+        for (;;) {
+            while (pend == 0) {
+                if (scanned) chunkBase += 64;
+                scanned = true;
+                if (chunkBase >= nList) return false;
+                const uint32_t e = chunkBase + S.lane;
+                bool is = false;
+                if (e < nList) {
+                    fI = useGood ? S.good[e] : e;
+                    // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
+                    is = (forward ? S.iBackDist[fI] : S.iFrontDist[fI]) == flank;
+                    if (is) {
+                        fFl = S.iFlags[fI];
+                        const uint32_t fp = S.iFrontPos[fI], bp = S.iBackPos[fI];
+                        fG = forward ? S.iBackG[fI] : S.iFrontG[fI];
+                        fPos = forward ? bp : fp;
+                        fLo = S.iLo[fI]; fHi = S.iHi[fI];
+                        fW = lcb_absdiff(fp, bp) + 1u;                                       // blocksfinder.h:719
+                    }
+                }
+                pend = __ballot(is);
+            }
+            const uint32_t b = (uint32_t)__ffsll((long long)pend) - 1u;
+            pend &= pend - 1;
+            const uint32_t o = ordinal++;
+            if (nWaves > 1 && (o % nWaves) != waveId) continue;
+            v.e = chunkBase + b;
+            v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
+            const uint32_t hi = lcb_rl(fHi, b);
+            v.weight = lcb_rl(fW, b);
+            v.positive = (lcb_rl(fFl, b) & LCB_FLAG_POS) != 0;
             v.dir = (forward == v.positive) ? 1 : -1;
+            v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
             return true;
         }
-        return false;
     };
-    auto issue = [&](const Voter& v, uint32_t c) -> Walk {
-        Walk w;
+    // The table reads of a pass (pos, id, used word) are independent and issued together; the first pass of the NEXT
+    // voter is issued before the current one is consumed, so its latency hides behind the LDS work of this one.
+    auto issue = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
+        LcbWalk w;
         const uint32_t d = c * 64 + S.lane + 1;
-        const int64_t gg = (int64_t)v.g0 + (int64_t)v.dir * (int64_t)d;
-        w.valid = gg >= (int64_t)v.lo && gg < (int64_t)v.hi;                       // it.Valid()
-        w.g = (uint32_t)gg; w.pos = 0; w.id = 0; w.used = false;
+        w.valid = d <= v.rem;                                                               // it.Valid()
+        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
+        w.pos = 0; w.id = 0; w.uw = 0;
         if (w.valid) {
             w.pos = T.posPos[w.g];
             w.id = T.posId[w.g];
-            w.used = lcb_it_used(T, w.g, v.positive, v.lo);
+            // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
+            const uint32_t ub = w.g - (v.positive ? 0u : 1u);
+            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = T.used[ub >> 5] >> (ub & 31);
         }
         return w;
     };
-    Voter cur, nxt;
-    Walk wcur, wnxt;
-    bool have = nextVoter(waveId, cur);
+    LcbVoter cur, nxt;
+    LcbWalk wcur, wnxt;
+    bool have = nextVoter(cur);
     if (have) wcur = issue(cur, 0);
     while (have) {
-        const bool haveNext = nextVoter(cur.e + nWaves, nxt);
+        const bool haveNext = nextVoter(nxt);
         if (haveNext) wnxt = issue(nxt, 0);
         for (uint32_t c = 0;; c++) {
-            const Walk w = c == 0 ? wcur : issue(cur, c);
+            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
             const uint32_t d = c * 64 + S.lane + 1;
-            const bool cond = w.valid && (d < (uint32_t)S.P.depth || lcb_absdiff(w.pos, cur.pos0) <= (uint32_t)S.P.maxBranch);
+            const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
-            const bool stop = cond && ((!tryUsed && w.used) || lcb_path_contains(S, vid));
+            const bool stop = cond && ((w.uw & 1u) != 0 || lcb_path_contains(S, vid));
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
             const unsigned long long endM = failM | stopM;
@@ -480,140 +532,159 @@ __device__ inline bool lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bo
             }
             if (S.lane < first) {
                 uint32_t h = lcb_hash(vid, S.voteShift);
+                int32_t old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
                 uint32_t probe = 0;
-                for (; probe < S.voteCap; probe++) {
-                    const int32_t old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
-                    if (old == LCB_EMPTY_KEY) {
-                        const uint32_t t = atomicAdd(S.vNTouched, 1u);
-                        if (t < touchedCap) S.vTouched[t] = h; else ovf = true;
-                        break;
-                    }
-                    if (old == vid) break;
-                    h = (h + 1) & vmask;
+                while (old != LCB_EMPTY_KEY && old != vid && probe < S.voteCap) {
+                    h = (h + 1) & vmask; probe++;
+                    old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
                 }
-                if (probe == S.voteCap) ovf = true;
-                else {
+                if (old == LCB_EMPTY_KEY) { if (atomicAdd(S.vNClaimed, 1u) >= claimCap) *S.vOvf = 1u; }
+                if (old == LCB_EMPTY_KEY || old == vid) {
                     atomicAdd(&S.vCount[h], cur.weight);
-                    atomicMax(&S.vLast[h], ((unsigned long long)cur.e << 32) | d);
-                }
+                    atomicMax(&S.vLast[h], (cur.e << 16) | d);
+                } else *S.vOvf = 1u;
             }
             if (first < 64) {
                 if (!tryUsed && S.lane == 0) {
                     // steps 1 .. c*64+first-1 read used == 0 (one step of slack keeps the - strand's bit g-1 inside)
-                    const int64_t ext = (int64_t)cur.g0 + (int64_t)cur.dir * (int64_t)(c * 64 + first);
-                    const uint32_t ge = ext < (int64_t)cur.lo ? cur.lo : (ext >= (int64_t)cur.hi ? cur.hi - 1 : (uint32_t)ext);
-                    if (ge < S.fpLo[cur.i]) S.fpLo[cur.i] = ge;
-                    if (ge > S.fpHi[cur.i]) S.fpHi[cur.i] = ge;
+                    const uint32_t st = c * 64 + first;
+                    const uint32_t ge = st > cur.rem ? (cur.dir > 0 ? cur.g0 + cur.rem : cur.lo) : (cur.dir > 0 ? cur.g0 + st : cur.g0 - st);
+                    atomicMin(&S.fpLo[cur.i], ge);
+                    atomicMax(&S.fpHi[cur.i], ge);
                 }
                 break;
             }
         }
         have = haveNext; cur = nxt; wcur = wnxt;
     }
-    return __ballot(ovf) != 0;
+}
+
+// Arg-max over the slots [s0, s1) of the vote table, wave-wide: max count; ties -> smallest origin (strand, g) of the
+// last contributing instance in list order; ties -> earliest step. Equal counts are the NORMAL case (collinear voters
+// give every vertex of their common window the same total), so the tie key is always computed.
+struct LcbBest { uint32_t cnt, keyHi, keyLo; int32_t vid; uint32_t e; };
+
+__device__ inline LcbBest lcb_vote_argmax(const LcbState& S, bool forward, bool useGood, uint32_t s0, uint32_t s1)
+{
+    uint32_t bCnt = 0, bHi = 0xFFFFFFFFu, bLo = 0xFFFFFFFFu, bE = 0;
+    int32_t bVid = 0;
+    for (uint32_t t = s0 + S.lane; t < s1; t += 64) {
+        const int32_t key = S.vKey[t];
+        if (key == LCB_EMPTY_KEY) continue;
+        const uint32_t cnt = S.vCount[t], last = S.vLast[t];
+        const uint32_t e = last >> 16, d = last & 0xFFFFu;
+        const uint32_t i = useGood ? S.good[e] : e;
+        const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
+        // JunctionSequentialIterator::operator< (junctionstorage.h:349-362): negative strand first, then chr, idx
+        const uint32_t hi = ((S.iFlags[i] & LCB_FLAG_POS) << 31) | (g0 >> 1), lo = (g0 << 31) | d;
+        if (cnt > bCnt || (cnt == bCnt && (hi < bHi || (hi == bHi && lo < bLo)))) { bCnt = cnt; bHi = hi; bLo = lo; bVid = key; bE = e; }
+    }
+    LcbBest r;
+    r.cnt = lcb_wave_umax(bCnt);
+    bool c = bCnt == r.cnt && r.cnt != 0;
+    r.keyHi = lcb_wave_umin(c ? bHi : 0xFFFFFFFFu);
+    c = c && bHi == r.keyHi;
+    r.keyLo = lcb_wave_umin(c ? bLo : 0xFFFFFFFFu);
+    c = c && bLo == r.keyLo;
+    const unsigned long long m = __ballot(c);
+    const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+    r.vid = m ? lcb_rl(bVid, w) : 0;
+    r.e = lcb_rl(bE, w);
+    return r;
 }
 
 // Mailbox words through which wave 0 hands a vote to the helper wavefronts of its workgroup.
-enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_OVF, LCB_MAIL_WORDS = 8 };
+enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_WORDS = 8 };
 enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
 
-template <bool STATS, bool PROF>
+// One wave's share of a vote after the walks: partial arg-max over its slice of the table, then (after everyone has
+// read) the clearing of that slice (blocksfinder.h:761-766).
+template <int NW>
+__device__ inline void lcb_vote_reduce_slice(LcbState& S, bool forward, bool useGood, uint32_t waveId)
+{
+    const uint32_t per = S.voteCap / NW;                       // voteCap is a power of two, a multiple of NW
+    const uint32_t s0 = waveId * per, s1 = s0 + per;
+    const LcbBest b = lcb_vote_argmax(S, forward, useGood, s0, s1);
+    if (S.lane == 0) {
+        uint32_t* p = S.part + 8 * waveId;
+        p[0] = b.cnt; p[1] = b.keyHi; p[2] = b.keyLo; p[3] = (uint32_t)b.vid; p[4] = b.e;
+    }
+    __syncthreads();                                           // C: every slice has been read, partials are visible
+    for (uint32_t t = s0 + S.lane; t < s1; t += 64) { S.vKey[t] = LCB_EMPTY_KEY; S.vCount[t] = 0; S.vLast[t] = 0; }
+}
+
+template <bool STATS, bool PROF, int NW>
 __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
 {
     const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
     const uint32_t nList = useGood ? S.nGood : S.nInst;
-    const uint32_t touchedCap = S.voteCap - (S.voteCap >> 2);
     const int32_t flank = forward ? S.rightFlank : S.leftFlank;
     if (STATS && S.lane == 0) S.cVote++;
     if (PROF) S.pfVote++;
+    originInst = 0;
+    if (nList == 0) return 0;                                      // nobody votes: nothing to walk, nothing to clear
+    LcbBest b;
     bool ovfAny;
-    if (S.nWaves > 1 && nList >= 4) {
-        // wake the helper wavefronts: they walk their share of the voters while this wave walks its own
+    if (NW > 1) {
+        // wake the helper wavefronts: every wave walks its share of the voters, reduces and clears its slice of the table
         if (S.lane == 0) {
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u);
-            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_OVF] = 0;
+            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
-        __syncthreads();
-        const bool mine = lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, S.nWaves);
-        __syncthreads();
-        ovfAny = mine || S.mail[LCB_MAIL_OVF] != 0;
+        __syncthreads();                                           // A
+        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, NW);
+        __syncthreads();                                           // B: all walks done
+        ovfAny = lcb_rfl(*S.vOvf) != 0;
         if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; }
-        LCB_WAVE_SYNC();
+        lcb_vote_reduce_slice<NW>(S, forward, useGood, 0);        // contains barrier C
         if (STATS && S.lane == 0) *S.mailWalk = 0;
+        if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
+        // final reduction over the NW partial results
+        uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0;
+        if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; }
+        b.cnt = lcb_wave_umax(pc);
+        bool c = pc == b.cnt && b.cnt != 0;
+        b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
+        b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
+        const unsigned long long m = __ballot(c);
+        const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+        b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
+        b.e = lcb_rl(pe, w);
     } else {
-        ovfAny = lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
+        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
+        LCB_WAVE_SYNC();
+        ovfAny = lcb_rfl(*S.vOvf) != 0;
+        b = lcb_vote_argmax(S, forward, useGood, 0, S.voteCap);
+        LCB_WAVE_SYNC();
+        for (uint32_t t = S.lane; t < S.voteCap; t += 64) { S.vKey[t] = LCB_EMPTY_KEY; S.vCount[t] = 0; S.vLast[t] = 0; }
+        if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
+        LCB_WAVE_SYNC();
     }
-    LCB_WAVE_SYNC();
-    uint32_t nTouched = *S.vNTouched;
-    if (ovfAny || nTouched > touchedCap) { S.status = LCB_ST_VOTE_OVF; if (nTouched > touchedCap) nTouched = touchedCap; }
-    // order-free arg-max: max count; ties -> smallest origin (strand, g) of the last contributing
-    // instance; ties -> earliest step.  key = (positive << 63) | (g0 << 31 >> ...) packed below.
-    uint32_t bestCount = 0, bestSlot = 0xFFFFFFFFu;
-    unsigned long long bestKey = ~0ull;
-    for (uint32_t t = S.lane; t < nTouched; t += 64) {
-        const uint32_t h = S.vTouched[t];
-        const uint32_t cnt = S.vCount[h];
-        const unsigned long long last = S.vLast[h];
-        const uint32_t e = (uint32_t)(last >> 32), d = (uint32_t)last;
-        const uint32_t i = useGood ? S.good[e] : e;
-        const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
-        // JunctionSequentialIterator::operator< (junctionstorage.h:349-362): negative strand first, then chr, idx
-        const unsigned long long key = ((unsigned long long)(S.iFlags[i] & LCB_FLAG_POS) << 62) |
-                                       ((unsigned long long)g0 << 30) | (unsigned long long)(d & 0x3FFFFFFFu);
-        if (cnt > bestCount || (cnt == bestCount && key < bestKey)) { bestCount = cnt; bestKey = key; bestSlot = h; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t oc = (uint32_t)__shfl_xor((int)bestCount, o);
-        const uint32_t os = (uint32_t)__shfl_xor((int)bestSlot, o);
-        const uint32_t klo = (uint32_t)__shfl_xor((int)(uint32_t)bestKey, o);
-        const uint32_t khi = (uint32_t)__shfl_xor((int)(uint32_t)(bestKey >> 32), o);
-        const unsigned long long ok = ((unsigned long long)khi << 32) | klo;
-        if (oc > bestCount || (oc == bestCount && ok < bestKey)) { bestCount = oc; bestKey = ok; bestSlot = os; }
-    }
-    int32_t bestVid = 0;
-    originInst = 0;
-    if (bestSlot != 0xFFFFFFFFu && bestCount > 0) {
-        bestVid = S.vKey[bestSlot];
-        const uint32_t e = (uint32_t)(S.vLast[bestSlot] >> 32);
-        originInst = useGood ? S.good[e] : e;
-    }
-    LCB_WAVE_SYNC();
-    for (uint32_t t = S.lane; t < nTouched; t += 64) {              // blocksfinder.h:761-766
-        const uint32_t h = S.vTouched[t];
-        S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0;
-    }
-    if (S.lane == 0) *S.vNTouched = 0;
-    LCB_WAVE_SYNC();
-    return bestVid;
-}
-
-// The table reads one push needs about the walked edge, loadable one step ahead of the push itself.
-struct LcbStep { int32_t idIt, idN; uint32_t posIt, posN; int32_t ech; };
-
-template <bool BACK>
-__device__ __forceinline__ LcbStep lcb_load_step(const LcbTables& T, uint32_t gIt, bool itPositive)
-{
-    const uint32_t gN = BACK ? (itPositive ? gIt + 1 : gIt - 1) : (itPositive ? gIt - 1 : gIt + 1);
-    LcbStep st;
-    st.idIt = T.posId[gIt]; st.idN = T.posId[gN]; st.posIt = T.posPos[gIt]; st.posN = T.posPos[gN];
-    // e.GetChar(): outgoing -> char at gIt, ingoing -> char at the previous position gN (junctionstorage.h:191-227)
-    st.ech = (int32_t)lcb_it_char(T, BACK ? gIt : gN, itPositive);
-    return st;
+    if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
+    if (b.cnt == 0) return 0;
+    originInst = useGood ? lcb_rfl(S.good[b.e]) : b.e;
+    return b.vid;
 }
 
 // One occurrence of the pushed vertex: its record plus the three `used` words around it, so that IsUsed and (almost
 // always) the Compatible gap test need no further global loads.
 struct LcbOcc { uint4 rec; uint32_t lo, wbase, uw0, uw1, uw2; };
 
-__device__ __forceinline__ LcbOcc lcb_load_occ(const LcbTables& T, uint32_t j, bool active)
+__device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, uint32_t j, bool active)
+{
+    uint4 r = uint4{0u, 0u, 0u, 0u};
+    if (active) r = T.occRec[j];
+    return r;
+}
+
+__device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const uint4& rec, bool active)
 {
     LcbOcc o;
-    o.rec = uint4{0u, 0u, 0u, 0u}; o.lo = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
+    o.rec = rec; o.lo = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
     if (active) {
-        o.rec = T.occRec[j];
-        o.lo = T.chrStart[o.rec.y];
-        const uint32_t wi = o.rec.x >> 5;
+        o.lo = T.chrStart[rec.y];
+        const uint32_t wi = rec.x >> 5;
         o.wbase = wi ? wi - 1 : 0;
         o.uw0 = T.used[o.wbase]; o.uw1 = T.used[o.wbase + 1]; o.uw2 = T.used[o.wbase + 2];
     }
@@ -633,15 +704,17 @@ __device__ inline bool lcb_range_any_used_c(const LcbTables& T, const LcbOcc& o,
     if (a >= b) return false;
     const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
     if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(T.used, a, b);
-    bool any = false;
-    for (uint32_t w = wa; w <= wb; w++) {
-        uint32_t word = (w - o.wbase) == 0 ? o.uw0 : ((w - o.wbase) == 1 ? o.uw1 : o.uw2);
-        if (w == wa) word &= 0xFFFFFFFFu << (a & 31);
-        if (w == wb) word &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-        any = any || word != 0;
-    }
-    return any;
+    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    const uint32_t ia = wa - o.wbase, ib = wb - o.wbase;
+    uint32_t acc = 0;
+    acc |= (ia == 0 ? o.uw0 : (ia == 1 ? o.uw1 : o.uw2)) & ma & (ia == ib ? mb : 0xFFFFFFFFu);
+    if (ib > ia) acc |= (ib == 1 ? o.uw1 : o.uw2) & mb;
+    if (ib == ia + 2) acc |= o.uw1;
+    return acc != 0;
 }
+
+// What a push needs to know about the walked edge (wave-uniform, in scalar registers).
+struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posIt, posN; int32_t ech; uint32_t o0, o1; };
 
 // ---- a push: PointPushBack / PointPushFront with their workers (path.h:430-602) ------------------
 // Per-occurrence outcomes.
@@ -653,24 +726,25 @@ __device__ inline bool lcb_range_any_used_c(const LcbTables& T, const LcbOcc& o,
 
 // BACK=true:  PointPushBack(e), e = OutgoingEdge of iterator (gIt, itPositive): vertex = end vertex.
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
+// rec0: the occurrence records o0 + lane of the pushed vertex, already loaded by the caller.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
 template <bool BACK, bool STATS, bool PROF>
-__device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool record, const LcbStep& st)
+__device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
-    const int32_t vertex = itPositive ? st.idN : -st.idN;            // pushed vertex
-    const int32_t otherVertex = itPositive ? st.idIt : -st.idIt;     // e.GetEndVertex() for a front push
-    // the CSR lookup is issued before the path-set probe so that the two global round trips overlap
-    const uint32_t av = (uint32_t)(vertex < 0 ? -vertex : vertex);
-    const uint32_t o0 = T.occStart[av], o1 = T.occStart[av + 1];
-    if (PROF ? lcb_path_contains_p(S, vertex) : lcb_path_contains(S, vertex)) return false;
-    const uint32_t length = lcb_absdiff(st.posN, st.posIt);
-    const int32_t ech = st.ech;
+    const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
+    const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
+    const uint32_t o0 = E.o0, o1 = E.o1;
+    // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
+    LcbOcc occ = lcb_finish_occ(T, rec0, o0 + S.lane < o1);
+    bool inPath = lcb_bloom_maybe(S, vertex);
+    if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
+    if (inPath) return false;
+    const uint32_t length = lcb_absdiff(E.posN, E.posIt);
+    const int32_t ech = E.ech;
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
     if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
     const int32_t distance = (int32_t)dist64;
-    // first chunk of occurrences: in flight while the vertex is published in the path set
-    LcbOcc occ = lcb_load_occ(T, o0 + S.lane, o0 + S.lane < o1);
     lcb_path_insert(S, vertex);
     if (S.status) return false;
 
@@ -684,7 +758,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         bool positive = false, usedS = false, usesP = false;
-        if (base != o0) occ = lcb_load_occ(T, j, active);
+        if (base != o0) occ = lcb_finish_occ(T, lcb_load_rec(T, j, active), active);
         if (active) {
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
@@ -695,11 +769,13 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
             uint32_t a = 0, b = n;
             while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
             u = a;
-            const bool hasX = u < n && S.iChr[oIdx[u]] == chr;
-            const bool hasP = u > 0 && S.iChr[oIdx[u - 1]] == chr;
+            uint32_t x = 0, p = 0, xFl = 0, pFl = 0;
+            if (u < n) { x = oIdx[u]; xFl = S.iFlags[x]; }
+            if (u > 0) { p = oIdx[u - 1]; pFl = S.iFlags[p]; }
+            const bool hasX = u < n && (xFl >> LCB_FLAG_BITS) == chr;
+            const bool hasP = u > 0 && (pFl >> LCB_FLAG_BITS) == chr;
             bool skip = false;
             if (hasX) {                                              // Instance::Within (path.h:170-175)
-                const uint32_t x = oIdx[u];
                 const uint32_t f = S.iFrontG[x], bk = S.iBackG[x];
                 skip = g >= (f < bk ? f : bk) && g <= (f < bk ? bk : f);
             }
@@ -708,10 +784,12 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
                 usesP = BACK ? positive : !positive;
                 const bool has = usesP ? hasP : hasX;
                 bool compat = false;
+                uint32_t cFl = 0;
                 if (has) {
-                    cand = usesP ? oIdx[u - 1] : oIdx[u];
+                    cand = usesP ? p : x;
+                    cFl = usesP ? pFl : xFl;
                     if (STATS) stCall = 1;
-                    const bool cpos = (S.iFlags[cand] & LCB_FLAG_POS) != 0;
+                    const bool cpos = (cFl & LCB_FLAG_POS) != 0;
                     if (cpos == positive) {                          // path.h:382-385
                         const uint32_t cg = BACK ? S.iBackG[cand] : S.iFrontG[cand];
                         const uint32_t cp = BACK ? S.iBackPos[cand] : S.iFrontPos[cand];
@@ -742,7 +820,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
                     }
                 }
                 if (compat) {
-                    const bool fin = (S.iFlags[cand] & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
+                    const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
                     act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
                 } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
             }
@@ -812,9 +890,9 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
             const uint32_t r = (uint32_t)__popcll(insM & ((1ull << S.lane) - 1));
             const uint32_t i = S.nInst + r;
             S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
-            S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iChr[i] = chr; S.iLo[i] = lo;
+            S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iLo[i] = lo;
             S.iHi[i] = T.chrStart[chr + 1];
-            S.iFlags[i] = positive ? LCB_FLAG_POS : 0u;
+            S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
         }
@@ -826,7 +904,7 @@ __device__ inline bool lcb_push(LcbState& S, uint32_t gIt, bool itPositive, bool
     if (BACK) {
         if (record) {
             if (S.nRight >= S.bodyCap) { S.status = LCB_ST_PATH_OVF; return true; }
-            if (S.lane == 0) S.body[S.nRight] = ((unsigned long long)(itPositive ? 1u : 0u) << 32) | gIt;
+            if (S.lane == 0) S.body[S.nRight] = ((unsigned long long)(E.itPositive ? 1u : 0u) << 32) | E.gIt;
         }
         S.nRight++;
         S.rightFlank = distance;
@@ -852,8 +930,9 @@ __device__ inline int64_t lcb_score(const LcbState& S)
         else sum += lcb_real_length(S, i) - (rightPenalty + leftPenalty) * (rightPenalty + leftPenalty);
     }
     const bool anyBad = __ballot(bad) != 0;
-    sum = lcb_wave_sum(sum);
-    return anyBad ? -(int64_t)INT32_MAX : sum;
+    if (anyBad) return -(int64_t)INT32_MAX;
+    if (S.nGood == 0) return 0;
+    return lcb_wave_sum(sum);
 }
 
 // bestInstance <- goodInstance_ (blocksfinder.h:820-824,883-887)
@@ -862,8 +941,9 @@ __device__ inline void lcb_snapshot(LcbState& S)
     if (S.nGood > S.bestCap) { S.status = LCB_ST_BEST_OVF; return; }
     for (uint32_t e = S.lane; e < S.nGood; e += 64) {
         const uint32_t i = S.good[e];
+        const uint32_t fl = S.iFlags[i];
         uint4 r;
-        r.x = S.iChr[i]; r.y = S.iFrontG[i] - S.iLo[i]; r.z = S.iBackG[i] - S.iLo[i]; r.w = (S.iFlags[i] & LCB_FLAG_POS);
+        r.x = fl >> LCB_FLAG_BITS; r.y = S.iFrontG[i] - S.iLo[i]; r.z = S.iBackG[i] - S.iLo[i]; r.w = (fl & LCB_FLAG_POS);
         S.best[e] = r;
     }
     S.nBest = S.nGood;
@@ -906,110 +986,181 @@ __device__ inline void lcb_restore_checkpoint(LcbState& S)
     LCB_WAVE_SYNC();
 }
 
+// ---- edge batches ---------------------------------------------------------------------------------
+// Up to 64 consecutive edges to push, one per lane: the table rows of both ends and the CSR bounds of the pushed vertex
+// are fetched for all of them at once (two dependent global round trips per batch instead of three per push).
+struct LcbEdgeBatch { uint32_t gIt, itPos, posIt, posN, o0, o1; int32_t idIt, idN, ech; };
+
+// Edges along a chromosome walk: edge l goes from position g + dir*l to g + dir*(l+1) (ExtendPathForward/Backward,
+// blocksfinder.h:789-802,852-865). Returns the number of edges up to the first position whose vertex is `next`
+// (64 if it is further away; the caller then asks for the following batch).
+template <bool FORWARD>
+__device__ inline uint32_t lcb_batch_from_walk(const LcbState& S, uint32_t g, int dir, bool positive, uint32_t lo, uint32_t hi, int32_t next, LcbEdgeBatch& b)
+{
+    const LcbTables& T = S.T;
+    const int64_t q0 = (int64_t)g + (int64_t)dir * (int64_t)S.lane, q1 = q0 + dir;
+    const bool v0 = q0 >= (int64_t)lo && q0 < (int64_t)hi, v1 = q1 >= (int64_t)lo && q1 < (int64_t)hi;
+    b.gIt = (uint32_t)q0; b.itPos = positive ? 1u : 0u;
+    b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.o1 = 0;
+    int32_t ch0 = 0, ch1 = 0;
+    if (v0) { b.idIt = T.posId[q0]; b.posIt = T.posPos[q0]; ch0 = (int32_t)lcb_it_char(T, (uint32_t)q0, positive); }
+    if (v1) { b.idN = T.posId[q1]; b.posN = T.posPos[q1]; ch1 = (int32_t)lcb_it_char(T, (uint32_t)q1, positive); }
+    // e.GetChar(): outgoing -> char at the iterator, ingoing -> char at the previous position (junctionstorage.h:191-227)
+    b.ech = FORWARD ? ch0 : ch1;
+    // the walk stops at the first position whose vertex is `next`; positions past the chromosome end never match
+    const unsigned long long hit = __ballot(v1 && (positive ? b.idN : -b.idN) == next);
+    const unsigned long long out = __ballot(!v1);
+    const unsigned long long endM = hit | out;
+    const uint32_t firstEnd = endM ? (uint32_t)__ffsll((long long)endM) - 1u : 64u;
+    uint32_t n = 64;
+    if (hit && (uint32_t)__ffsll((long long)hit) - 1u == firstEnd) n = firstEnd + 1;   // edges 0 .. firstEnd end at `next`
+    else if (firstEnd < 64) n = firstEnd;                                               // ran off the chromosome (cannot happen for a voted vertex)
+    if (S.lane < n) {
+        const uint32_t av = (uint32_t)(b.idN < 0 ? -b.idN : b.idN);
+        b.o0 = T.occStart[av]; b.o1 = T.occStart[av + 1];
+    }
+    return n;
+}
+
+// Edges of the recorded right body [from, from + 64) for the replay (blocksfinder.h:271-284).
+__device__ inline void lcb_batch_from_body(const LcbState& S, uint32_t from, uint32_t n, LcbEdgeBatch& b)
+{
+    const LcbTables& T = S.T;
+    b.gIt = 0; b.itPos = 0; b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.o1 = 0;
+    if (S.lane < n) {
+        const unsigned long long r = S.body[from + S.lane];
+        b.gIt = (uint32_t)r; b.itPos = (uint32_t)(r >> 32);
+        const uint32_t gN = b.itPos ? b.gIt + 1 : b.gIt - 1;
+        b.idIt = T.posId[b.gIt]; b.idN = T.posId[gN]; b.posIt = T.posPos[b.gIt]; b.posN = T.posPos[gN];
+        b.ech = (int32_t)lcb_it_char(T, b.gIt, b.itPos != 0);
+        const uint32_t av = (uint32_t)(b.idN < 0 ? -b.idN : b.idN);
+        b.o0 = T.occStart[av]; b.o1 = T.occStart[av + 1];
+    }
+}
+
+__device__ __forceinline__ LcbEdge lcb_edge_of(const LcbEdgeBatch& b, uint32_t l)
+{
+    LcbEdge e;
+    e.gIt = lcb_rl(b.gIt, l); e.itPositive = lcb_rl(b.itPos, l) != 0; e.idIt = lcb_rl(b.idIt, l); e.idN = lcb_rl(b.idN, l);
+    e.posIt = lcb_rl(b.posIt, l); e.posN = lcb_rl(b.posN, l); e.ech = lcb_rl(b.ech, l); e.o0 = lcb_rl(b.o0, l); e.o1 = lcb_rl(b.o1, l);
+    return e;
+}
+
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
-template <bool FORWARD, bool STATS, bool PROF>
+template <bool FORWARD, bool STATS, bool PROF, int NW>
 __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
 {
     const LcbTables& T = S.T;
     uint32_t oi = 0;
     LCB_MARK(S, 4, S.nRight); LCB_MARK(S, 5, S.nLeft); LCB_MARK(S, 6, 1);
     const uint64_t tv0 = PROF ? wall_clock64() : 0;
-    int32_t next = lcb_vote<STATS, PROF>(S, FORWARD, false, oi);
+    int32_t next = lcb_vote<STATS, PROF, NW>(S, FORWARD, false, oi);
     LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
     if (S.status) return false;
     if (FORWARD && next == 0) {                                      // blocksfinder.h:782-785 (forward only, Q2)
-        next = lcb_vote<STATS, PROF>(S, true, true, oi);
+        next = lcb_vote<STATS, PROF, NW>(S, true, true, oi);
         if (S.status) return false;
     }
     if (PROF) S.pfTVote += wall_clock64() - tv0;
     bool success = false;
     if (next != 0) {
-        const bool positive = (S.iFlags[oi] & LCB_FLAG_POS) != 0;
-        uint32_t g = FORWARD ? S.iBackG[oi] : S.iFrontG[oi];
+        const bool positive = (lcb_rfl(S.iFlags[oi]) & LCB_FLAG_POS) != 0;
+        uint32_t g = lcb_rfl(FORWARD ? S.iBackG[oi] : S.iFrontG[oi]);
         const int dir = (FORWARD == positive) ? 1 : -1;
-        const uint32_t lo = S.iLo[oi], hi = S.iHi[oi];
-        // the walk from the origin to the chosen vertex reads consecutive positions: keep the position after the next
-        // one in flight, so a push never waits for its own edge data
-        struct At { int32_t id; uint32_t pos; int32_t ch; };
-        auto loadAt = [&](int64_t q) -> At {
-            At a; a.id = 0; a.pos = 0; a.ch = 0;
-            if (q >= (int64_t)lo && q < (int64_t)hi) { a.id = T.posId[q]; a.pos = T.posPos[q]; a.ch = (int32_t)lcb_it_char(T, (uint32_t)q, positive); }
-            return a;
-        };
-        At cur = loadAt(g), nxt = loadAt((int64_t)g + dir);
+        const uint32_t lo = lcb_rfl(S.iLo[oi]), hi = lcb_rfl(S.iHi[oi]);
         for (;;) {
-            if ((positive ? cur.id : -cur.id) == next) break;
-            const At ahead = loadAt((int64_t)g + 2 * dir);
-            LcbStep st;
-            st.idIt = cur.id; st.idN = nxt.id; st.posIt = cur.pos; st.posN = nxt.pos; st.ech = FORWARD ? cur.ch : nxt.ch;
-            LCB_MARK(S, 6, 3); LCB_MARK(S, 8, g);
-            const uint64_t tp0 = PROF ? wall_clock64() : 0;
-            success = lcb_push<FORWARD, STATS, PROF>(S, g, positive, true, st);
-            const uint64_t tp1 = PROF ? wall_clock64() : 0;
-            if (PROF) S.pfTPush += tp1 - tp0;
-            LCB_MARK(S, 6, 4);
-            if (S.status) return false;
-            if (success) {
-                nowScore = lcb_score(S);
-                if (nowScore > bestScore) {
-                    bestScore = nowScore;
-                    if (FORWARD) bestRightSize = S.nRight + 1;
-                    if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
-                    if (FORWARD && !STATS && S.nRight >= S.ckN + LCB_CK_EVERY) lcb_checkpoint(S);
+            LcbEdgeBatch bt;
+            const uint32_t nE = lcb_batch_from_walk<FORWARD>(S, g, dir, positive, lo, hi, next, bt);
+            if (nE == 0) break;                                      // defensive: a voted vertex is always reached
+            // occurrence records of the first edge; those of edge l+1 are requested before edge l is pushed
+            uint4 rec = lcb_load_rec(T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            for (uint32_t l = 0; l < nE; l++) {
+                const LcbEdge E = lcb_edge_of(bt, l);
+                uint4 recN = uint4{0u, 0u, 0u, 0u};
+                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+                LCB_MARK(S, 6, 3); LCB_MARK(S, 8, E.gIt);
+                const uint64_t tp0 = PROF ? wall_clock64() : 0;
+                success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec);
+                const uint64_t tp1 = PROF ? wall_clock64() : 0;
+                if (PROF) S.pfTPush += tp1 - tp0;
+                LCB_MARK(S, 6, 4);
+                if (S.status) return false;
+                if (success) {
+                    nowScore = lcb_score(S);
+                    if (nowScore > bestScore) {
+                        bestScore = nowScore;
+                        if (FORWARD) bestRightSize = S.nRight + 1;
+                        if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
+                        if (FORWARD && !STATS && S.nRight >= S.ckN + LCB_CK_EVERY) lcb_checkpoint(S);
+                    }
+                    if (PROF) S.pfTScore += wall_clock64() - tp1;
                 }
-                if (PROF) S.pfTScore += wall_clock64() - tp1;
+                rec = recN;
             }
-            g = (uint32_t)((int64_t)g + dir);
-            cur = nxt; nxt = ahead;
+            if (nE < 64 || (positive ? lcb_rl(bt.idN, 63) : -lcb_rl(bt.idN, 63)) == next) break;
+            g = (uint32_t)((int64_t)g + 64 * dir);
         }
     }
     return success;
 }
 
 // ProcessVertex::Process (blocksfinder.h:228-310)
-template <bool STATS, bool PROF>
+template <int MODE, bool STATS, bool PROF, int NW>
 __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
+    constexpr int BW = (int)LcbCfg<MODE>::BW;
     int64_t score = 0, bestScore = 0;
     S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0;
     LCB_MARK(S, 2, 1);
     lcb_path_init<STATS>(S, vid, ch);
     LCB_MARK(S, 2, 2); LCB_MARK(S, 3, S.nInst);
+    // No unused occurrence carries the seed's character: nothing can vote, nothing is pushed, the result is empty
+    // (blocksfinder.h:781-786 finds no vertex in either direction). Stats mode walks through the motions for the counters.
+    const bool dead = !STATS && !S.status && S.nInst == 0;
     uint32_t bestRightSize = 1;
     const int64_t minRun = 2 * (int64_t)S.P.maxBranch;
-    if (!S.status) {
+    if (!S.status && !dead) {
         for (;;) {                                                   // blocksfinder.h:255-269
             bool ret = true, positive = false;
             const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
-            while ((ret = lcb_extend<true, STATS, PROF>(S, bestRightSize, bestScore, score)) &&
+            while ((ret = lcb_extend<true, STATS, PROF, NW>(S, bestRightSize, bestScore, score)) &&
                    ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
                 positive = positive || (score > 0);
             if (!ret || !positive || S.status) break;
         }
     }
     LCB_MARK(S, 2, 3);
-    if (!S.status) {                                                 // replay, blocksfinder.h:271-284
+    if (!S.status && !dead) {                                        // replay, blocksfinder.h:271-284
         const uint32_t nEdge = bestRightSize - 1;
         uint32_t from = 0;
         if (!STATS && S.ckN && S.ckN <= nEdge) {
             lcb_restore_checkpoint(S);    // the state after ckN pushes; stats mode replays from Init like the reference (event counts)
             from = S.ckN;
         } else {
-            lcb_path_clear(S);            // keeps the body list, resets everything else
+            lcb_path_clear<BW>(S);        // keeps the body list, resets everything else
             lcb_path_init<STATS>(S, vid, ch);
         }
-        for (uint32_t i = from; i < nEdge && !S.status; i++) {
-            const unsigned long long b = S.body[i];
-            const LcbStep st = lcb_load_step<true>(S.T, (uint32_t)b, (b >> 32) != 0);
-            lcb_push<true, STATS, PROF>(S, (uint32_t)b, (b >> 32) != 0, false, st);
+        while (from < nEdge && !S.status) {
+            const uint32_t nE = nEdge - from < 64 ? nEdge - from : 64;
+            LcbEdgeBatch bt;
+            lcb_batch_from_body(S, from, nE, bt);
+            uint4 rec = lcb_load_rec(S.T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            for (uint32_t l = 0; l < nE && !S.status; l++) {
+                const LcbEdge E = lcb_edge_of(bt, l);
+                uint4 recN = uint4{0u, 0u, 0u, 0u};
+                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+                lcb_push<true, STATS, PROF>(S, E, false, rec);
+                rec = recN;
+            }
+            from += nE;
         }
     }
     LCB_MARK(S, 2, 4);
-    if (!S.status) {
+    if (!S.status && !dead) {
         for (;;) {                                                   // blocksfinder.h:292-306 (stray ';' at :297, Q1)
             bool ret = true;
             const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
-            while ((ret = lcb_extend<false, STATS, PROF>(S, bestRightSize, bestScore, score)) &&
+            while ((ret = lcb_extend<false, STATS, PROF, NW>(S, bestRightSize, bestScore, score)) &&
                    ((int64_t)S.rightFlank - S.leftFlank) - prevLength <= minRun)
                 ;
             const bool positive = score > 0;
@@ -1017,28 +1168,24 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         }
     }
     LCB_MARK(S, 2, 5);
-    lcb_path_clear(S);                // Path::Clear (blocksfinder.h:308)
-    if (S.status == LCB_ST_VOTE_OVF) {
-        // the vote table may hold stale keys after an overflow: wipe it
-        for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
-        if (S.lane == 0) *S.vNTouched = 0;
-    }
-    LCB_WAVE_SYNC();
+    lcb_path_clear<BW>(S);            // Path::Clear (blocksfinder.h:308)
     bestScoreOut = bestScore;
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
 // Per-launch arguments that are only touched between seeds (work queue, result arenas). They are parked in LDS so that
-// they do not occupy scalar registers for the whole kernel: the per-seed code already needs the 102-SGPR budget.
+// they do not occupy scalar registers for the whole kernel.
 struct LcbLaunchArgs {
     const LcbKSeed* seeds;
     LcbSeedOut* out;
+    LcbSeedCtr* ctr;
     uint4* arena;
     uint2* fpArena;
     unsigned long long arenaCap, fpCap, arenaBase, fpBase;
     unsigned long long* arenaCursor;
     unsigned long long* fpCursor;
     uint32_t* cursor;
+    const uint32_t* live;
     uint32_t cursorBase, nSeeds;
     const uint32_t* usedView;      // `used` view of the seed wave 0 is working on (read by the helpers at each vote)
 };
@@ -1050,27 +1197,26 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                                         uint2* fpArena, unsigned long long fpCap)
 {
     constexpr bool BIG = MODE == 2;
-    constexpr uint32_t IC = BIG ? 1u : (MODE == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL);
-    constexpr uint32_t VC = BIG ? 1u : (MODE == 1 ? LCB_VC_MEDIUM : LCB_VC_SMALL);
-    __shared__ uint32_t sInst[10 * IC];
+    constexpr uint32_t IC = LcbCfg<MODE>::IC, VC = LcbCfg<MODE>::VC, BW = LcbCfg<MODE>::BW;
+    __shared__ uint32_t sInst[9 * IC];
     __shared__ uint32_t sOrdKey[2 * IC];
     __shared__ uint32_t sOrdIdx[2 * IC];
     __shared__ uint32_t sGood[IC];
     __shared__ uint32_t sFp[2 * IC];
     __shared__ int32_t sVKey[VC];
     __shared__ uint32_t sVCount[VC];
-    __shared__ unsigned long long sVLast[VC];
-    __shared__ uint32_t sVTouched[VC];
-    __shared__ uint32_t sBloom[LCB_BLOOM_WORDS];
+    __shared__ uint32_t sVLast[VC];
+    __shared__ uint32_t sBloom[BW];
     __shared__ uint32_t sScr[4 * 64];
     __shared__ uint32_t sMisc[4];
     __shared__ uint32_t sMail[LCB_MAIL_WORDS];
+    __shared__ uint32_t sPart[8 * NW];
     __shared__ unsigned long long sMailWalk[1];
     __shared__ LcbLaunchArgs sArgs;
     if (threadIdx.x == 0) {
-        sArgs.seeds = seeds; sArgs.out = out; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
+        sArgs.seeds = seeds; sArgs.out = out; sArgs.ctr = W.ctr; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
         sArgs.arenaBase = W.arenaBase; sArgs.fpBase = W.fpBase; sArgs.arenaCursor = W.arenaCursor; sArgs.fpCursor = W.fpCursor;
-        sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.nSeeds = nSeeds;
+        sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.live = W.live; sArgs.nSeeds = W.live ? *W.nLive : nSeeds;
     }
 
     LcbState S;
@@ -1092,7 +1238,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         S.good = (uint32_t*)(slot + L.good);
         S.fpLo = (uint32_t*)(slot + L.fp); S.fpHi = S.fpLo + W.instCap;
         S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
-        S.vLast = (unsigned long long*)(slot + L.vLast); S.vTouched = (uint32_t*)(slot + L.vTouched);
+        S.vLast = (uint32_t*)(slot + L.vLast);
         S.voteCap = W.voteCap;
     } else {
         instBase = sInst; S.instCap = IC;
@@ -1100,55 +1246,58 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         S.ordIdx = sOrdIdx;
         S.good = sGood;
         S.fpLo = sFp; S.fpHi = sFp + IC;
-        S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast; S.vTouched = sVTouched;
+        S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast;
         S.voteCap = VC;
-        for (uint32_t h = S.lane; h < VC; h += 64) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
+        for (uint32_t h = threadIdx.x; h < VC; h += 64 * NW) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
     }
     S.bloom = sBloom;
-    for (uint32_t h = S.lane; h < LCB_BLOOM_WORDS; h += 64) sBloom[h] = 0;
+    S.bloomShift = 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u;
+    for (uint32_t h = threadIdx.x; h < BW; h += 64 * NW) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
     S.iFrontG = instBase; S.iBackG = instBase + S.instCap; S.iFrontPos = instBase + 2 * S.instCap;
-    S.iBackPos = instBase + 3 * S.instCap; S.iChr = instBase + 4 * S.instCap; S.iLo = instBase + 5 * S.instCap;
-    S.iHi = instBase + 6 * S.instCap; S.iFlags = instBase + 7 * S.instCap;
-    S.iFrontDist = (int32_t*)(instBase + 8 * S.instCap); S.iBackDist = (int32_t*)(instBase + 9 * S.instCap);
-    S.scr = sScr; S.vNTouched = &sMisc[0];
-    S.mail = sMail; S.mailWalk = sMailWalk; S.nWaves = NW;
-    const uint32_t waveId = threadIdx.x >> 6;
+    S.iBackPos = instBase + 3 * S.instCap; S.iLo = instBase + 4 * S.instCap;
+    S.iHi = instBase + 5 * S.instCap; S.iFlags = instBase + 6 * S.instCap;
+    S.iFrontDist = (int32_t*)(instBase + 7 * S.instCap); S.iBackDist = (int32_t*)(instBase + 8 * S.instCap);
+    S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1];
+    S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
+    const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
     S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     LCB_MARK(S, 0, 1);
-    if (S.lane == 0) { sMisc[0] = 0; sMail[LCB_MAIL_CMD] = 0; sMail[LCB_MAIL_OVF] = 0; sMailWalk[0] = 0; }
+    if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
     S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;
     LCB_WAVE_SYNC();
     if (NW > 1) {
-        __syncthreads();           // the LDS tables above were initialised (redundantly) by every wave
+        __syncthreads();           // the LDS tables and sArgs above are initialised
         if (waveId != 0) {
-            // helper wavefront: sleeps at the barrier until wave 0 posts a vote, walks its share of the voters
+            // helper wavefront: sleeps at the barrier until wave 0 posts a vote; walks its share of the voters, reduces and
+            // clears its slice of the vote table
             for (;;) {
-                __syncthreads();
-                if (S.mail[LCB_MAIL_CMD] == LCB_CMD_EXIT) return;
+                __syncthreads();                                   // A
+                if (lcb_rfl(S.mail[LCB_MAIL_CMD]) == LCB_CMD_EXIT) return;
                 S.T.used = sArgs.usedView;
-                const uint32_t flags = S.mail[LCB_MAIL_FLAGS];
+                const uint32_t flags = lcb_rfl(S.mail[LCB_MAIL_FLAGS]);
                 S.cWalk = 0;
-                const bool ovf = lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, S.mail[LCB_MAIL_NLIST],
-                                                      (int32_t)S.mail[LCB_MAIL_FLANK], waveId, NW);
-                if (ovf && S.lane == 0) atomicOr(&S.mail[LCB_MAIL_OVF], 1u);
+                lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
+                                     (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW);
                 if (STATS) {
                     const unsigned long long w = (unsigned long long)lcb_wave_sum((int64_t)S.cWalk);
                     if (S.lane == 0 && w) atomicAdd(S.mailWalk, w);
                 }
-                __syncthreads();
+                __syncthreads();                                   // B
+                lcb_vote_reduce_slice<NW>(S, (flags & 1u) != 0, (flags & 4u) != 0, waveId);   // contains barrier C
             }
         }
-    }
+    } else LCB_WAVE_SYNC();
 
     for (;;) {
-        uint32_t s = 0;
-        if (S.lane == 0) s = atomicAdd(sArgs.cursor, 1u) - sArgs.cursorBase;   // every workgroup overshoots by exactly one ticket
-        s = lcb_bcast(s, 0);
-        if (s >= sArgs.nSeeds) break;
+        uint32_t tk = 0;
+        if (S.lane == 0) tk = atomicAdd(sArgs.cursor, 1u) - sArgs.cursorBase;   // every workgroup overshoots by exactly one ticket
+        tk = lcb_rfl(tk);
+        if (tk >= sArgs.nSeeds) break;
+        const uint32_t s = sArgs.live ? lcb_rfl(sArgs.live[tk]) : tk;
         LCB_MARK(S, 1, s + 1);
         S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
         S.nInst = S.nGood = S.cur = S.nRight = S.nLeft = 0; S.rightFlank = S.leftFlank = 0;
@@ -1157,16 +1306,24 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0;
         const uint64_t tick0 = PROF ? wall_clock64() : 0;
         const LcbKSeed sd = sArgs.seeds[s];
-        S.T.used = T.used + (size_t)sd.view * T.usedStride;
+        const int32_t vid = lcb_rfl(sd.vid), ch = lcb_rfl(sd.ch);
+        S.T.used = T.used + (size_t)lcb_rfl(sd.view) * T.usedStride;
         if (NW > 1 && S.lane == 0) sArgs.usedView = S.T.used;     // published to the helpers by the vote's first barrier
-        lcb_process_seed<STATS, PROF>(S, sd.vid, sd.ch, bestScore);
+        lcb_process_seed<MODE, STATS, PROF, NW>(S, vid, ch, bestScore);
+        if (S.status == LCB_ST_VOTE_OVF) {
+            // the vote table may hold stale keys after an overflow (the helpers have cleared their slices; wave 0 wipes all)
+            LCB_WAVE_SYNC();
+            for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
+            if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
+            LCB_WAVE_SYNC();
+        }
         const uint64_t ticks = PROF ? wall_clock64() - tick0 : 0;
         const uint32_t n = S.status ? 0u : S.nBest;
         unsigned long long off = 0;
         if (n) {
             uint32_t olo = 0, ohi = 0;
             if (S.lane == 0) { off = atomicAdd(sArgs.arenaCursor, (unsigned long long)n) - sArgs.arenaBase; olo = (uint32_t)off; ohi = (uint32_t)(off >> 32); }
-            olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
+            olo = lcb_rfl(olo); ohi = lcb_rfl(ohi);
             off = ((unsigned long long)ohi << 32) | olo;
             if (off + n > sArgs.arenaCap) S.status = LCB_ST_ARENA_OVF;
             else { uint4* ar = sArgs.arena; for (uint32_t e = S.lane; e < n; e += 64) ar[off + e] = S.best[e]; }
@@ -1179,7 +1336,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         if (nfp) {
             uint32_t olo = 0, ohi = 0;
             if (S.lane == 0) { fpo = atomicAdd(sArgs.fpCursor, (unsigned long long)nfp) - sArgs.fpBase; olo = (uint32_t)fpo; ohi = (uint32_t)(fpo >> 32); }
-            olo = lcb_bcast(olo, 0); ohi = lcb_bcast(ohi, 0);
+            olo = lcb_rfl(olo); ohi = lcb_rfl(ohi);
             fpo = ((unsigned long long)ohi << 32) | olo;
             if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
             else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
@@ -1195,10 +1352,14 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             o.nInst = n;   // kept on ARENA_OVF so the host can track the allocator
             o.status = S.status; o.bestScore = bestScore; o.arenaOff = off;
             o.fpOff = fpo; o.nFp = nfp; o.pad = 0;
-            for (int q = 0; q < 8; q++) o.ctr[q] = 0;
-            if (!STATS && PROF) { o.ctr[0] = ticks; o.ctr[1] = S.pfPush; o.ctr[2] = S.pfVote; o.ctr[3] = S.pfMaxProbe; o.ctr[4] = S.pfMaxInst; o.ctr[5] = S.pfTVote; o.ctr[6] = S.pfTPush; o.ctr[7] = S.pfTScore; }
-            if (STATS) { o.ctr[0] = c[0]; o.ctr[1] = c[1]; o.ctr[2] = c[2]; o.ctr[3] = c[3]; o.ctr[4] = o.nInst; o.ctr[5] = c[4]; o.ctr[6] = c[5]; o.ctr[7] = 1; }
             sArgs.out[s] = o;
+            if ((STATS || PROF) && sArgs.ctr) {
+                LcbSeedCtr k;
+                for (int q = 0; q < 8; q++) k.c[q] = 0;
+                if (!STATS && PROF) { k.c[0] = ticks; k.c[1] = S.pfPush; k.c[2] = S.pfVote; k.c[3] = S.pfMaxProbe; k.c[4] = S.pfMaxInst; k.c[5] = S.pfTVote; k.c[6] = S.pfTPush; k.c[7] = S.pfTScore; }
+                if (STATS) { k.c[0] = c[0]; k.c[1] = c[1]; k.c[2] = c[2]; k.c[3] = c[3]; k.c[4] = o.nInst; k.c[5] = c[4]; k.c[6] = c[5]; k.c[7] = 1; }
+                sArgs.ctr[s] = k;
+            }
         }
         LCB_MARK(S, 2, 6);
     }
@@ -1207,6 +1368,44 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         __syncthreads();
     }
     LCB_MARK(S, 0, 2);
+}
+
+// ---- screening --------------------------------------------------------------------------------------
+// A seed none of whose occurrences is unused with the seed's character has an empty Path::Init (path.h:33-46), so its
+// Process() returns nothing and reads no bit as 0: its header is final here. Later rounds consist almost entirely of such
+// seeds (their neighbourhood is covered by committed blocks); the others are queued for the process kernel.
+// One thread per seed.
+__device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    bool alive = false;
+    if (s < nSeeds) {
+        const LcbKSeed sd = seeds[s];
+        const uint32_t* used = T.used + (size_t)sd.view * T.usedStride;
+        const uint32_t av = (uint32_t)(sd.vid < 0 ? -sd.vid : sd.vid);
+        const uint32_t o1 = T.occStart[av + 1];
+        for (uint32_t j = T.occStart[av]; j < o1 && !alive; j++) {
+            const uint4 rec = T.occRec[j];
+            const bool positive = (int32_t)rec.w == sd.vid;
+            const uint32_t g = rec.x;
+            bool isUsed;
+            if (positive) isUsed = lcb_used_bit(used, g);
+            else isUsed = g > T.chrStart[rec.y] ? lcb_used_bit(used, g - 1) : false;
+            alive = !isUsed && (int32_t)(positive ? T.posCh[g] : T.posRevCh[g]) == sd.ch;
+        }
+        LcbSeedOut o;
+        o.nInst = 0; o.status = alive ? (uint32_t)LCB_ST_PENDING : (uint32_t)LCB_ST_OK; o.bestScore = 0; o.arenaOff = 0; o.fpOff = 0; o.nFp = 0; o.pad = 0;
+        out[s] = o;
+    }
+    // compact the live seeds in seed order within the wave (heavy seeds come first in the sorted seed list)
+    const unsigned long long m = __ballot(alive);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(nLive, (uint32_t)__popcll(m));
+        base = lcb_rfl(base);
+        if (alive) live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = s;
+    }
 }
 
 #endif

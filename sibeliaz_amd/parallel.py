@@ -41,12 +41,14 @@ def make_allgather(group=None, tensor_device=None):
     return fn, (fn, cb)
 
 
-def make_hooks(rank=0, world=1, group=None, tensor_device=None, processor=None, round_phases=0):
+def make_hooks(rank=0, world=1, group=None, tensor_device=None, processor=None, round_phases=0, **engine):
     """Builds an api.Hooks. `processor` (optional, tests) is an object with process(seeds)->(offsets, inst), mark(ranges),
     reset() that stands in for the device."""
     keep = []
     h = Hooks()
     h.rank, h.world, h.round_phases, h.progress = rank, world, round_phases, 0
+    for k, v in engine.items():
+        setattr(h, k, int(v))
     if world > 1:
         fn, ka = make_allgather(group, tensor_device)
         h.allgather = fn

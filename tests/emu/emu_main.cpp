@@ -37,6 +37,7 @@ struct EmuCtx {
     uint32_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint2> fpArena;
     std::vector<LcbSeedOut> out;
+    std::vector<LcbSeedCtr> ctr;
     std::vector<uint4> arena;
     std::vector<LcbKSeed> ks;
     std::vector<size_t> which;
@@ -56,6 +57,7 @@ struct Emu {
     std::vector<EmuCtx> ctx;                     // one per host thread
     std::vector<uint2> fpArena;                  // merged results of the last run()
     std::vector<LcbSeedOut> out;
+    std::vector<LcbSeedCtr> octr;                // per-seed counters of the last run()
     std::vector<uint4> arena;
     lcb_counters ctr{};
     uint64_t launches = 0, criticalPushes = 0, totalPushes = 0, firstPushes = 0;   // sum over launches of the largest per-seed push count
@@ -74,12 +76,12 @@ struct Emu {
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
         const char* te = getenv("EMU_THREADS");
         int nThreads = te ? atoi(te) : omp_get_max_threads();
-        if (getenv("EMU_NW") && atoi(getenv("EMU_NW")) > 1) nThreads = 1;     // multi-wave runs keep the single-threaded schedule
         if (nThreads < 1) nThreads = 1;
         ctx.resize((size_t)nThreads);
         for (auto& c : ctx) {
             LcbWork& W = c.W;
             W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : (mode == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL); W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
+            W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr;
             LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
             c.slot.assign(L.total, 0);
             int32_t* pk = (int32_t*)(c.slot.data() + L.pKeys);
@@ -112,6 +114,8 @@ struct Emu {
         LcbWork& W = c.W;
         c.cursor[2] = c.cursor[3] = c.cursor[4] = c.cursor[5] = 0;   // reuse the arenas
         c.out.assign(c.ks.size(), LcbSeedOut{});
+        c.ctr.assign(c.ks.size(), LcbSeedCtr{});
+        W.ctr = c.ctr.data();
         W.cursorBase = c.cursor[0];
         W.arenaBase = *W.arenaCursor;
         W.fpBase = *W.fpCursor;
@@ -123,15 +127,18 @@ struct Emu {
         LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); uint2* fa = c.fpArena.data();
         const size_t arc = c.arena.size(), fac = c.fpArena.size();
         const bool noStats = getenv("EMU_NOSTATS") != nullptr;     // the shipped instantiation (checkpointed replay, no event counters)
-        if (noStats && mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, false, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats && mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, false, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats) emu_run_wave(0, [&]() { lcb_process_body<0, false, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        if (noStats && nw == 16 && mode == 1) emu_run_block(0, 16, [&]() { lcb_process_body<1, false, 16, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (noStats && nw == 8 && mode == 2) emu_run_block(0, 8, [&]() { lcb_process_body<2, false, 8, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (noStats && mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (noStats && mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (noStats) emu_run_wave(0, [&]() { lcb_process_body<0, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
         else if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
         else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
         else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else if (nw == 16 && mode == 1) emu_run_block(0, 16, [&]() { lcb_process_body<1, true, 16, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
         else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
         else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
     }
 
     // runs the process kernel over the seeds: each host thread emulates ONE wavefront over its share of the seeds
@@ -149,6 +156,7 @@ struct Emu {
             if (!grown) break;
         }
         out.assign(seeds.size(), LcbSeedOut{});
+        octr.assign(seeds.size(), LcbSeedCtr{});
         arena.clear(); fpArena.clear();
         uint64_t maxPush = 0;
         for (auto& c : ctx)
@@ -162,14 +170,21 @@ struct Emu {
                 }
                 out[c.which[j]] = o;
                 if (o.status != 0) continue;     // an overflowed attempt is re-run in a larger mode (runRetry) and counted there
-                ctr.n_walk += o.ctr[0]; ctr.n_occ += o.ctr[1]; ctr.n_compat_call += o.ctr[2]; ctr.n_compat_step += o.ctr[3];
-                ctr.n_inst_out += o.ctr[4]; ctr.n_vote += o.ctr[5]; ctr.n_push += o.ctr[6]; ctr.n_process += o.ctr[7];
-                maxPush = std::max<uint64_t>(maxPush, o.ctr[6]); totalPushes += o.ctr[6];
+                const LcbSeedCtr& k = c.ctr[j];
+                octr[c.which[j]] = k;
+                const bool noStats = getenv("EMU_NOSTATS") != nullptr;   // then k is the instrumented variant's profile: c[1] = pushes
+                if (!noStats) {
+                    ctr.n_walk += k.c[0]; ctr.n_occ += k.c[1]; ctr.n_compat_call += k.c[2]; ctr.n_compat_step += k.c[3];
+                    ctr.n_inst_out += k.c[4]; ctr.n_vote += k.c[5]; ctr.n_push += k.c[6]; ctr.n_process += k.c[7];
+                }
+                const uint64_t pushes = noStats ? k.c[1] : k.c[6];
+                maxPush = std::max<uint64_t>(maxPush, pushes); totalPushes += pushes;
             }
         launches++; criticalPushes += maxPush;
-        if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes, first job %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush, (unsigned long long)out[0].ctr[6]);
-        firstPushes += out.empty() ? 0 : out[0].ctr[6];
-        if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (size_t i = 0; i < out.size(); i++) fprintf(stderr, "   done %zu pushes %llu inst %u\n", i, (unsigned long long)out[i].ctr[6], out[i].nInst);
+        const int pc = getenv("EMU_NOSTATS") ? 1 : 6;
+        if (getenv("EMU_LAUNCH_LOG")) fprintf(stderr, "  launch %llu: %zu seeds, longest %llu pushes, first job %llu pushes\n", (unsigned long long)launches, seeds.size(), (unsigned long long)maxPush, (unsigned long long)octr[0].c[pc]);
+        firstPushes += out.empty() ? 0 : octr[0].c[pc];
+        if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (size_t i = 0; i < out.size(); i++) fprintf(stderr, "   done %zu pushes %llu inst %u\n", i, (unsigned long long)octr[i].c[pc], out[i].nInst);
     }
     // Like the product's retry chain (device.hip): seeds that overflow the LDS capacities of this mode are run again in the next
     // larger mode (small -> medium -> big), against the same `used` views.
@@ -194,6 +209,7 @@ struct Emu {
                 o.arenaOff = ao; o.fpOff = fo;
             }
             out[again[k]] = o;
+            octr[again[k]] = next->octr[k];
         }
         ctr.n_walk += next->ctr.n_walk; ctr.n_occ += next->ctr.n_occ; ctr.n_compat_call += next->ctr.n_compat_call; ctr.n_compat_step += next->ctr.n_compat_step;
         ctr.n_inst_out += next->ctr.n_inst_out; ctr.n_vote += next->ctr.n_vote; ctr.n_push += next->ctr.n_push; ctr.n_process += next->ctr.n_process;
@@ -278,6 +294,7 @@ int main(int argc, char** argv)
                 }
             }
             if (getenv("EMU_ONLY")) { const lcb_seed one = seeds[atoi(getenv("EMU_ONLY"))]; seeds.assign(1, one); }
+            if (getenv("EMU_LIMIT") && (size_t)atoi(getenv("EMU_LIMIT")) < seeds.size()) seeds.resize((size_t)atoi(getenv("EMU_LIMIT")));   // the heavy seeds come first
             std::vector<LcbKSeed> ks;
             for (auto& s : seeds) ks.push_back(LcbKSeed{s.vid, s.ch, 0u, 0u});
             emu.runRetry(ks);
@@ -289,11 +306,11 @@ int main(int argc, char** argv)
                 {
                     static orc_counters prev; static int shown = 0;
                     const uint64_t dc = octr.n_compat_call - prev.n_compat_call, ds = octr.n_compat_step - prev.n_compat_step;
-                    if ((dc != emu.out[i].ctr[2] || ds != emu.out[i].ctr[3]) && shown < 5 && getenv("EMU_CTR_DEBUG")) {
+                    if ((dc != emu.octr[i].c[2] || ds != emu.octr[i].c[3]) && shown < 5 && getenv("EMU_CTR_DEBUG")) {
                         shown++;
                         fprintf(stderr, "ctr seed %zu vid=%d ch=%c: kernel ccall=%llu cstep=%llu | oracle ccall=%llu cstep=%llu (occ k=%llu o=%llu)\n", i, seeds[i].vid,
-                                (char)seeds[i].ch, (unsigned long long)emu.out[i].ctr[2], (unsigned long long)emu.out[i].ctr[3], (unsigned long long)dc,
-                                (unsigned long long)ds, (unsigned long long)emu.out[i].ctr[1], (unsigned long long)(octr.n_occ - prev.n_occ));
+                                (char)seeds[i].ch, (unsigned long long)emu.octr[i].c[2], (unsigned long long)emu.octr[i].c[3], (unsigned long long)dc,
+                                (unsigned long long)ds, (unsigned long long)emu.octr[i].c[1], (unsigned long long)(octr.n_occ - prev.n_occ));
                     }
                     prev = octr;
                 }
@@ -339,6 +356,7 @@ int main(int argc, char** argv)
                 }
                 void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; }
                 int maxViews() const override { return views; }
+                int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
                 void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
             };
             orc_block* ob = nullptr; orc_stats st;
@@ -352,6 +370,10 @@ int main(int argc, char** argv)
                 proc.views = vp ? atoi(vp) : (R == 3 ? 0 : (R == 1 ? 2 : 64));   // no views / view starvation / plenty
                 emu.launches = emu.criticalPushes = emu.totalPushes = emu.firstPushes = 0;
                 LcbEngineConfig cfg; cfg.roundPhases = R;
+                auto envInt = [](const char* n) { const char* e = getenv(n); return e && *e ? atoi(e) : 0; };
+                cfg.roundFixed = envInt("LCB_ROUND_FIXED") != 0; cfg.maxJobs = envInt("LCB_MAX_JOBS");
+                if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F"));
+                if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;

@@ -119,6 +119,24 @@ int settleWave(int w)
         for (int i = 0; i < kWave; i++) L[i].result = m;
     } else if (kind == EMU_SHFL) {
         for (int i = 0; i < kWave; i++) L[i].result = L[L[i].arg & 63].value;
+    } else if (kind == EMU_DPP) {
+        // v_mov_b32_dpp: value = (old << 32) | src; arg = ctrl | rowMask << 12 | bankMask << 16 | boundCtrl << 20
+        for (int i = 0; i < kWave; i++) {
+            const int a = L[i].arg, ctrl = a & 0xFFF, rowMask = (a >> 12) & 0xF, bankMask = (a >> 16) & 0xF;
+            const bool boundCtrl = (a >> 20) & 1;
+            const uint32_t old = (uint32_t)(L[i].value >> 32);
+            const int row = i / 16, pos = i % 16;
+            int src = -1;
+            if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (pos >= n) src = i - n; }            // row_shr:n
+            else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; if (pos + n < 16) src = i + n; }   // row_shl:n
+            else if (ctrl == 0x142) { if (row >= 1) src = (row - 1) * 16 + 15; }                                       // row_bcast:15
+            else if (ctrl == 0x143) { if (row >= 2) src = 31; }                                                        // row_bcast:31
+            else { fprintf(stderr, "emu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+            const bool enabled = ((rowMask >> row) & 1) && ((bankMask >> (pos / 4)) & 1);
+            if (!enabled) L[i].result = old;
+            else if (src < 0) L[i].result = boundCtrl ? 0u : old;
+            else L[i].result = (uint32_t)L[src].value;
+        }
     } else {
         for (int i = 0; i < kWave; i++) L[i].result = 0;
     }

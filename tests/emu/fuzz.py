@@ -1,26 +1,24 @@
-"""TEST-ONLY randomized parity campaign (not collected by pytest): random small genome sets and parameters, the unmodified device
+"""TEST-ONLY randomized parity campaign: random small genome sets and parameters, the unmodified device
 code + the product's round engine under the wavefront emulator (emu_check) against the CPU oracle.
 
     python tests/emu/fuzz.py <seconds> [first case number]        # log: $LCB_FUZZ_DIR/fuzz.log (default /tmp/lcb_fuzz)
 
 Each case runs `find` with the shipped (non-stats) kernel instantiation and random engine knobs (round size, number of predicted
-views, F prediction), and `seeds-init` with and without event counters. Failing cases keep their inputs.
+views, F prediction, job cap), `seeds-init` with and without event counters, and one multi-wavefront variant (wide or big mode
+with helper wavefronts) on the heaviest seeds. Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
+cases inside the CPU suite; the open-ended campaign is this script.
 """
 import os, random, subprocess, sys, time
-WORK = os.environ.get("LCB_FUZZ_DIR", "/tmp/lcb_fuzz")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BIN = ROOT + "/sibeliaz_amd/bin"
 EMU = ROOT + "/tests/emu/build/emu_check"
-os.makedirs(WORK, exist_ok=True)
-t_end = time.time() + float(sys.argv[1])
-start = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-log = open(os.path.join(WORK, "fuzz.log"), "a")
-i = start
-nfail = 0
-while time.time() < t_end:
+
+
+def case_params(i, small=False):
+    """Deterministic in i: generator arguments, (k, b, m, a) and the emulator runs of case i."""
     rnd = random.Random(i)
-    strains = rnd.choice([2, 3, 5, 8, 12, 20])
-    segs = rnd.choice([2, 4, 8, 12])
+    strains = rnd.choice([2, 3, 5, 8] if small else [2, 3, 5, 8, 12, 20])
+    segs = rnd.choice([2, 4] if small else [2, 4, 8, 12])
     k = rnd.choice([11, 15, 21, 25])
     b = rnd.choice([40, 100, 200, 400])
     m = rnd.choice([30, 50, 100, 250])
@@ -30,32 +28,58 @@ while time.time() < t_end:
              "--sub", str(rnd.choice([0.005, 0.02, 0.05])), "--indel", str(rnd.choice([0, 0.002, 0.01])), "--filler-frac", str(rnd.choice([0, 0.2])),
              "--repeat-families", str(rnd.choice([0, 1, 3])), "--repeat-copies", str(rnd.choice([2, 5, 10])), "--repeat-len", str(rnd.choice([200, 800])),
              "--tandem", str(rnd.choice([0, 0.2])), "--nrun", str(rnd.choice([0, 0.1])), "--chromosomes", str(rnd.choice([1, 1, 3])), "--seed", str(1000 + i)]
-    d = os.path.join(WORK, "c%d" % i)
+    runs = [("find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_VIEWS": rnd.choice(["0", "3", "64"]),
+                      "LCB_PREDICT_F": rnd.choice(["1", "2", "3"]), "EMU_CONCURRENCY": rnd.choice(["4", "64", "16384"])}),
+            ("seeds-init", {"EMU_NOSTATS": "1"}), ("seeds-init", {}),
+            rnd.choice([("medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}),
+                        ("medium", {"EMU_NW": "8", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "4", "EMU_LIMIT": "150"})])]
+    return synth, (k, b, m, a), runs, (strains, segs)
+
+
+def run_case(i, work, small=False, timeout=900):
+    """-> (description, [(mode, env, ok (True / False / None = timeout), stderr tail)])"""
+    synth, (k, b, m, a), runs, (strains, segs) = case_params(i, small)
+    d = os.path.join(work, "c%d" % i)
     os.makedirs(d, exist_ok=True)
     fa, gr = d + "/g.fa", d + "/g.bin"
-    try:
-        subprocess.check_call([BIN + "/lcb-synth", "-o", fa] + synth, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        subprocess.check_call([BIN + "/lcb-mkgraph", "-k", str(k), "-o", gr, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    except Exception as e:
-        log.write("case %d: generation failed %s\n" % (i, e)); log.flush(); i += 1; continue
+    subprocess.check_call([BIN + "/lcb-synth", "-o", fa] + synth, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([BIN + "/lcb-mkgraph", "-k", str(k), "-o", gr, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     res = []
-    for mode, env in (("find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_VIEWS": rnd.choice(["0", "3", "64"]),
-                               "LCB_PREDICT_F": rnd.choice(["0", "2", "3"])}),
-                      ("seeds-init", {"EMU_NOSTATS": "1"}), ("seeds-init", {})):
+    for mode, env in runs:
         try:
-            r = subprocess.run([EMU, gr, fa, str(k), str(b), str(m), str(a), mode, d + "/out"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+            r = subprocess.run([EMU, gr, fa, str(k), str(b), str(m), str(a), mode, d + "/out"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=timeout)
             ok = r.returncode == 0
             tail = "" if ok else r.stderr[-400:].replace("\n", " | ")
         except subprocess.TimeoutExpired:
             ok = None; tail = "timeout"
         res.append((mode, env, ok, tail))
-    bad = [x for x in res if x[2] is False]
-    nfail += len(bad)
-    log.write("case %d strains=%d segs=%d k=%d b=%d m=%d a=%d : %s\n" % (i, strains, segs, k, b, m, a, " ".join("%s=%s" % (x[0], "ok" if x[2] else ("TIMEOUT" if x[2] is None else "FAIL")) for x in res)))
-    for x in bad:
-        log.write("   FAIL %s %s synth=%s :: %s\n" % (x[0], x[1], " ".join(synth), x[3]))
-    log.flush()
-    if not bad:
+    desc = "case %d strains=%d segs=%d k=%d b=%d m=%d a=%d" % (i, strains, segs, k, b, m, a)
+    if all(x[2] for x in res):
         subprocess.call(["rm", "-rf", d])
-    i += 1
-log.write("done: next case %d, failures %d\n" % (i, nfail)); log.flush()
+    return desc, res, synth
+
+
+def main():
+    work = os.environ.get("LCB_FUZZ_DIR", "/tmp/lcb_fuzz")
+    os.makedirs(work, exist_ok=True)
+    t_end = time.time() + float(sys.argv[1])
+    i = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    log = open(os.path.join(work, "fuzz.log"), "a")
+    nfail = 0
+    while time.time() < t_end:
+        try:
+            desc, res, synth = run_case(i, work)
+        except Exception as e:
+            log.write("case %d: generation failed %s\n" % (i, e)); log.flush(); i += 1; continue
+        bad = [x for x in res if x[2] is False]
+        nfail += len(bad)
+        log.write("%s : %s\n" % (desc, " ".join("%s=%s" % (x[0], "ok" if x[2] else ("TIMEOUT" if x[2] is None else "FAIL")) for x in res)))
+        for x in bad:
+            log.write("   FAIL %s %s synth=%s :: %s\n" % (x[0], x[1], " ".join(synth), x[3]))
+        log.flush()
+        i += 1
+    log.write("done: next case %d, failures %d\n" % (i, nfail)); log.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,12 +31,17 @@ EmuDim3 emu_block_idx();
 #define threadIdx (emu_thread_idx())
 #define blockIdx (emu_block_idx())
 
-enum EmuKind { EMU_BALLOT = 1, EMU_SHFL = 2, EMU_SYNC = 3, EMU_BARRIER = 4 };
+enum EmuKind { EMU_BALLOT = 1, EMU_SHFL = 2, EMU_SYNC = 3, EMU_BARRIER = 4, EMU_DPP = 5 };
 uint64_t emu_collective(int kind, uint64_t value, int arg, const char* file, int line);
 
 #define __ballot(p) ((unsigned long long)emu_collective(EMU_BALLOT, (p) ? 1u : 0u, 0, __FILE__, __LINE__))
 #define __shfl(v, src) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)((src) & 63), __FILE__, __LINE__))
 #define __shfl_xor(v, m) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)(((emu_thread_idx().x & 63u) ^ (uint32_t)(m)) & 63), __FILE__, __LINE__))
+// scalar broadcasts and the DPP row operations the kernel's wave-wide max/min reductions are built from
+#define __builtin_amdgcn_readfirstlane(v) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), 0, __FILE__, __LINE__))
+#define __builtin_amdgcn_readlane(v, l) ((int)emu_collective(EMU_SHFL, (uint64_t)(uint32_t)(v), (int)((l) & 63), __FILE__, __LINE__))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rowMask, bankMask, boundCtrl) \
+    ((int)emu_collective(EMU_DPP, ((uint64_t)(uint32_t)(old) << 32) | (uint64_t)(uint32_t)(src), (int)((ctrl) | ((rowMask) << 12) | ((bankMask) << 16) | ((boundCtrl) ? 1 << 20 : 0)), __FILE__, __LINE__))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)emu_collective(EMU_SYNC, 0, 0, __FILE__, __LINE__))
 #define __syncthreads() ((void)emu_collective(EMU_BARRIER, 0, 0, __FILE__, __LINE__))
@@ -56,5 +61,7 @@ static inline unsigned long long atomicAdd(unsigned long long* a, unsigned long 
 static inline unsigned long long atomicMax(unsigned long long* a, unsigned long long v) { unsigned long long old = *a; if (v > old) *a = v; return old; }
 static inline unsigned long long atomicAdd(unsigned long long* a, long long v) { unsigned long long old = *a; *a = old + (unsigned long long)v; return old; }
 static inline uint32_t atomicOr(uint32_t* a, uint32_t v) { uint32_t old = *a; *a = old | v; return old; }
+static inline uint32_t atomicMax(uint32_t* a, uint32_t v) { uint32_t old = *a; if (v > old) *a = v; return old; }
+static inline uint32_t atomicMin(uint32_t* a, uint32_t v) { uint32_t old = *a; if (v < old) *a = v; return old; }
 
 #endif

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/fullsize.json: hashes of what the UNMODIFIED reference (oracle/_ref/sibeliaz-lcb-ref, built from
+/root/reference by oracle/Makefile) writes for the BASELINE.json configurations at their stated size. Run in the build
+container only (the reference does not exist on the GPU box); the GPU tests regenerate the inputs with the same
+deterministic tools (lcb-synth, lcb-mkgraph) and compare hashes.
+
+    python tests/golden/make_fullsize.py [workdir]        # default /tmp/lcb_fullsize; ~25 min of CPU on 8 cores
+
+Only hashes, line counts and the banner figures are committed — no reference source, no genome data.
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (workload definitions are shared with bench.py)
+
+CASES = [
+    # name, bench workload (genomes + graph), abundance
+    ("config2_ecoli10_a150", "ecoli10", 150),
+    ("config3_ecoli62_a150", "ecoli62", 150),
+    ("config3_ecoli62_a868", "ecoli62", 868),       # a = 2 * N * D = 2 * 62 * 7 (reference README.md:161-175)
+]
+
+
+def sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def main():
+    work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/lcb_fullsize"
+    os.environ["LCB_BENCH_DIR"] = work
+    ref = os.path.join(ROOT, "oracle", "_ref", "sibeliaz-lcb-ref")
+    out = {}
+    for name, wl, a in CASES:
+        w = bench.ensure_workload(wl)
+        od = os.path.join(w["dir"], "ref_a%d" % a)
+        gff = os.path.join(od, "blocks_coords.gff")
+        log = os.path.join(od, "stdout.txt")
+        if not (os.path.exists(gff) and os.path.exists(log)):
+            os.makedirs(od, exist_ok=True)
+            t = time.time()
+            r = subprocess.run([ref, "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]), "-a", str(a),
+                                "-t", str(os.cpu_count() or 1), "-o", od, "--noseq"], capture_output=True, text=True, check=True)
+            open(log, "w").write(r.stdout)
+            print("%s: reference ran %.0f s" % (name, time.time() - t), flush=True)
+        banner = open(log).read()
+        out[name] = {
+            "workload": wl, "synth": w["synth"], "k": w["k"], "b": w["b"], "m": w["m"], "a": a,
+            "fasta_sha256": sha256(w["fasta"]), "graph_sha256": sha256(w["graph"]),
+            "gff_sha256": sha256(gff), "gff_lines": sum(1 for _ in open(gff)),
+            "blocks_found": int(re.search(r"Blocks found: (\d+)", banner).group(1)),
+            "coverage": re.search(r"Coverage: ([0-9.]+)", banner).group(1),
+        }
+        print(name, out[name]["gff_sha256"], out[name]["blocks_found"], flush=True)
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,21 +13,10 @@ from tests.oracle_binding import Oracle, OrcCounters
 pytestmark = pytest.mark.gpu
 
 
-def _setup(case, env=None):
-    old = {}
-    for k, v in (env or {}).items():
-        old[k] = os.environ.get(k)
-        os.environ[k] = v
-    try:
-        st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, threads=4, abundance=case.a)
-        p = sibeliaz_amd.Params.make(case.k, b=case.b, m=case.m)
-        dev = sibeliaz_amd.Device(st, p, 0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _setup(case, **device_opts):
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, threads=4, abundance=case.a)
+    p = sibeliaz_amd.Params.make(case.k, b=case.b, m=case.m)
+    dev = sibeliaz_amd.Device(st, p, 0, **device_opts)
     return st, p, dev
 
 
@@ -46,13 +35,12 @@ def _compare_all(case, st, dev, orc, seeds, what):
 
 
 def test_seeds_match_golden(built, case):
+    """The whole sorted bundle list (blocksfinder.h:461-517) against the sha256 of the REAL reference's bundle_."""
+    import hashlib
     st, p, dev = _setup(case)
     seeds = st.seeds(4)
-    lines = case.golden("bundles.sample.tsv").splitlines()[:50]
-    for i, ln in enumerate(lines):
-        vid, ch, cnt, rank, rp, rc = (int(x) for x in ln.split("\t"))
-        s = seeds[i]
-        assert (int(s["vid"]), int(s["ch"]), int(s["count"]), int(s["rank"]), int(s["resolve_pos"]), int(s["resolve_chr"])) == (vid, ch, cnt, rank, rp, rc)
+    text = "".join("%d\t%d\t%d\t%d\t%d\t%d\n" % (int(s["vid"]), int(s["ch"]), int(s["count"]), int(s["rank"]), int(s["resolve_pos"]), int(s["resolve_chr"])) for s in seeds)
+    assert hashlib.sha256(text.encode()).hexdigest() == case.meta["sha256"]["bundles.tsv"]
 
 
 def test_per_seed_parity_unused_state(built, case):
@@ -71,12 +59,41 @@ def test_per_seed_parity_final_state(built, case):
     _compare_all(case, st, dev, orc, st.seeds(4), "final state")
 
 
-def test_big_mode_parity(built, case):
-    """Forces every non-trivial seed through the overflow -> global-memory ("big") kernel variant."""
-    st, p, dev = _setup(case, {"LCB_PATH_CAP": "16"})
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_each_kernel_variant_parity(built, case, mode):
+    """Every seed through ONE kernel variant (1 compact: one wavefront per seed; 2 wide: 16 wavefronts share the votes;
+    3 big: per-path state in the global-memory workspace), checked by the per-variant seed counters."""
+    st, p, dev = _setup(case, start_mode=mode)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    seeds = st.seeds(4)
+    seeds = seeds[:900] if mode != 1 else seeds
+    _compare_all(case, st, dev, orc, seeds, "variant %d" % mode)
+    counts = dev.mode_seeds()
+    assert counts[mode - 1] >= len(seeds) and all(c == 0 for i, c in enumerate(counts) if i < mode - 1), counts
+
+
+def test_overflow_chain_reaches_big_mode(built, case):
+    """Tiny path sets in the compact AND the wide slots: every seed that pushes more than a few vertices overflows twice and
+    ends in the big (global-memory) variant; results are the oracle's."""
+    st, p, dev = _setup(case, path_cap=16, wide_path_cap=16, start_mode=1)
     orc = Oracle(case.graph, [case.fasta], case.k, case.a)
     seeds = st.seeds(4)[:600]
-    _compare_all(case, st, dev, orc, seeds, "big mode")
+    _compare_all(case, st, dev, orc, seeds, "overflow chain")
+    counts = dev.mode_seeds()
+    assert counts[0] == len(seeds) and counts[1] > 0 and counts[2] > 0 and counts[2] <= counts[1], counts
+
+
+def test_screened_launch_parity(built, case):
+    """A launch that goes through the screening kernel first (dead seeds finalised there, live ones queued) gives the same
+    per-seed results as unscreened launches, in the final `used` state where most seeds are dead."""
+    st, p, dev = _setup(case, screen_min=1, start_mode=1)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    orc.find_blocks(case.k, case.b, case.m)
+    dev.set_used(orc.used_bitmap(st.chr_start()))
+    _compare_all(case, st, dev, orc, st.seeds(4), "screened, final state")
+    orc2 = Oracle(case.graph, [case.fasta], case.k, case.a)
+    dev.reset_used()
+    _compare_all(case, st, dev, orc2, st.seeds(4), "screened, unused state")
 
 
 def test_event_counters_match_oracle(built, case):
@@ -119,31 +136,27 @@ def test_find_blocks_matches_reference(built, case, tmp_path):
     assert blocks.tobytes() == blocks2.tobytes()
 
 
-@pytest.mark.parametrize("fixed,phases", [("1", "1"), ("1", "7"), ("0", "64")])
-def test_round_engine_variants_on_gpu(built, case, fixed, phases, monkeypatch):
+@pytest.mark.parametrize("fixed,phases", [(1, 1), (1, 7), (0, 64)])
+def test_round_engine_variants_on_gpu(built, case, fixed, phases):
     """Round size must not change the result: one phase per launch (the reference's schedule), a fixed speculative round of
     7 phases, and the adaptive default all give the reference's block list."""
-    monkeypatch.setenv("LCB_ROUND_FIXED", fixed)
-    monkeypatch.setenv("LCB_ROUND_PHASES", phases)
     st, p, dev = _setup(case)
     finder = sibeliaz_amd.BlocksFinder(st, case.k)
-    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, round_fixed=fixed, round_phases=phases)
     got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
     assert got == case.golden("pretrim.tsv")
     summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
     assert finder.stats["failures"] == int(summary["failure"])
 
 
-@pytest.mark.parametrize("env", [{"LCB_VIEWS": "0"}, {"LCB_VIEWS": "2", "LCB_ROUND_FIXED": "1", "LCB_ROUND_PHASES": "64"}, {"LCB_PREDICT_F": "0"},
-                                 {"LCB_PREDICT_F": "2", "LCB_MAX_JOBS": "8"}, {"LCB_EAGER_PHASES": "0"}])
-def test_predictive_engine_knobs_on_gpu(built, case, env, monkeypatch):
+@pytest.mark.parametrize("knobs", [{"max_views": -1}, {"max_views": 2, "round_fixed": 1, "round_phases": 64}, {"predict_f": 1},
+                                   {"predict_f": 2, "max_jobs": 8}, {"eager_phases": -1}, {"max_jobs": 100000}])
+def test_predictive_engine_knobs_on_gpu(built, case, knobs):
     """Predictions only cost launches, never correctness: without predicted views, with too few of them, with other F
-    predictions, a tiny job cap or no look-ahead the block list is the reference's."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    predictions, a tiny or a huge job cap or no look-ahead the block list is the reference's."""
     st, p, dev = _setup(case)
     finder = sibeliaz_amd.BlocksFinder(st, case.k)
-    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, **knobs)
     got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
     assert got == case.golden("pretrim.tsv")
     summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
