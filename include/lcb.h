@@ -123,19 +123,20 @@ lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int devic
 typedef struct {
     uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 6 per CU */
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
-    uint32_t big_slots;      /* ... of the big (global-memory) variant; default 1 per CU */
+    uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
+    uint32_t huge_slots;     /* ... of the huge variant (all per-path state in HBM); default 1 per 4 CUs */
     uint32_t path_cap;       /* path vertex set capacity of a compact slot (power of two); default 32768 */
-    uint32_t wide_path_cap;  /* ... of a wide slot; default max(131072, path_cap) */
+    uint32_t wide_path_cap;  /* ... of a wide slot (the set lives in LDS); default and maximum 8192 */
     uint32_t max_views;      /* predicted `used` views kept behind the live bitmap; default 256 (within 2 GiB) */
     uint32_t batch;          /* seeds per launch; default 65536 */
     uint32_t wide_threshold; /* calls with at most this many seeds start in the wide variant; default 2 * wide_slots */
-    uint32_t start_mode;     /* 0 = automatic; 1 / 2 / 3 = every seed starts in the compact / wide / big variant */
+    uint32_t start_mode;     /* 0 = automatic; 1 / 2 / 3 / 4 = every seed starts in the compact / wide / big / huge variant */
     uint32_t screen_min;     /* launches of at least this many seeds are screened first; default 2048 */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
-/* Seeds handed to the compact / wide / big kernel variant since the device was created (a seed that overflows one
- * variant is counted again in the next). */
-int lcb_device_mode_seeds(lcb_device* d, int64_t counts[3]);
+/* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows
+ * one variant is counted again in the next). */
+int lcb_device_mode_seeds(lcb_device* d, int64_t counts[4]);
 void lcb_device_destroy(lcb_device* d);
 /* `used` bits (Position::used, junctionstorage.h:144) live in HBM as a bitmap over g. */
 int lcb_device_reset_used(lcb_device* d);

@@ -59,7 +59,7 @@ ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max
 
 class DeviceOpts(C.Structure):
     """lcb_device_opts: tuning knobs of a device, 0 = default."""
-    _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "path_cap", "wide_path_cap", "max_views", "batch",
+    _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
                                           "wide_threshold", "start_mode", "screen_min")]
 
 
@@ -236,8 +236,8 @@ class Device:
             raise _err(self.L)
 
     def mode_seeds(self):
-        """Seeds handed to the (compact, wide, big) kernel variants since creation."""
-        out = (C.c_int64 * 3)()
+        """Seeds handed to the (compact, wide, big, huge) kernel variants since creation."""
+        out = (C.c_int64 * 4)()
         if self.L.lcb_device_mode_seeds(self.h, out):
             raise _err(self.L)
         return tuple(int(x) for x in out)

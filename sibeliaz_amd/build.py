@@ -47,7 +47,9 @@ def build_tools():
 
 
 def hip_flags():
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-result",
+    # -disable-promote-alloca-to-lds: the compiler otherwise moves a 48-byte per-lane stack object of the process kernels into
+    # LDS (48 B x 1024 lanes = 48 KB of the wide variant's budget); LDS is what bounds the seeds in flight per CU
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-result", "-mllvm", "-disable-promote-alloca-to-lds",
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -75,7 +75,7 @@ lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int de
     return lcb_device_create_impl(g, p, device_ordinal, opts);
     LCB_CATCH(nullptr)
 }
-int lcb_device_mode_seeds(lcb_device* d, int64_t counts[3])
+int lcb_device_mode_seeds(lcb_device* d, int64_t counts[4])
 {
     LCB_TRY
     if (!d || !counts) throw LcbError("lcb_device_mode_seeds: null argument");

@@ -9,9 +9,10 @@
 //
 // A launch is (optionally) a screening kernel — one thread per seed decides whether Path::Init would create any
 // instance at all and finalises the header of the seeds for which it would not — followed by the process kernel over
-// the surviving seeds in one of three variants (lcb_kernel.h): compact (1 wavefront per seed, 6 seeds per CU: launches
+// the surviving seeds in one of four variants (lcb_kernel.h): compact (1 wavefront per seed, 6 seeds per CU: launches
 // with many seeds are throughput-bound), wide (16 wavefronts share the votes of one seed: launches with few seeds are
-// as long as their longest seed) and big (per-path state in HBM for seeds that overflow the LDS capacities).
+// as long as their longest seed), big (4096 instances: index, lists and vote table in LDS, instance fields in HBM) and
+// huge (all per-path state in HBM, capacities grown on demand) for seeds that overflow the smaller ones.
 #include <hip/hip_runtime.h>
 
 #include <time.h>
@@ -34,11 +35,12 @@
         if (e_ != hipSuccess) throw LcbError(std::string(#x) + " failed: " + hipGetErrorString(e_)); \
     } while (0)
 
-// MODE 0/1/2 = compact / wide / big (lcb_kernel.h): where the per-path instance pool and vote table live.
+// MODE 0/1/2/3 = compact / wide / big / huge (lcb_kernel.h): where the per-path instance pool and vote table live.
 // NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest share the votes.
 #define LCB_NW_COMPACT 1
 #define LCB_NW_WIDE 16
 #define LCB_NW_BIG 8
+#define LCB_NW_HUGE 8
 // PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
 template <int MODE, bool STATS, int NW, bool PROF>
 __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
@@ -104,8 +106,7 @@ struct WorkSet {
     uint8_t* base = nullptr;
     uint64_t slotBytes = 0;
     uint32_t nSlots = 0, pathCap = 0, bodyCap = 0, bestCap = 0, instCap = 0, voteCap = 0;
-    int mode = 0;          // 0 compact, 1 wide, 2 big
-    bool big = false;      // mode == 2: instance pool and vote table in the workspace
+    int mode = 0;          // 0 compact, 1 wide, 2 big, 3 huge
 };
 
 uint32_t envU32(const char* name, uint32_t dflt)
@@ -114,7 +115,7 @@ uint32_t envU32(const char* name, uint32_t dflt)
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
-const char* modeName(int m) { return m == 2 ? "big" : (m == 1 ? "wide" : "compact"); }
+const char* modeName(int m) { return m == 3 ? "huge" : (m == 2 ? "big" : (m == 1 ? "wide" : "compact")); }
 
 }  // namespace
 
@@ -133,7 +134,7 @@ struct lcb_device_impl {
     int maxViews = 0;          // predicted views allocated behind the live bitmap (view 0)
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
-    WorkSet ws[3];                               // compact, wide, big
+    WorkSet ws[4];                               // compact, wide, big, huge
     // pinned, device-mapped host buffers
     LcbKSeed* hSeeds = nullptr;
     LcbSeedOut* hOut = nullptr;
@@ -159,7 +160,7 @@ struct lcb_device_impl {
     std::vector<uint64_t> hintBits = std::vector<uint64_t>(1024, 0);   // 65 536-bit prefilter in front of modeHint (most seeds have no hint)
     double kernelMs = 0;
     int64_t launches = 0, bigRetries = 0;
-    int64_t modeSeeds[3] = {0, 0, 0};            // seeds handed to each kernel variant since creation
+    int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
     int64_t screened = 0, screenedDead = 0;
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
@@ -177,11 +178,11 @@ struct lcb_device_impl {
     void allocWork(WorkSet& w)
     {
         if (w.base) { HIP_CHECK(hipFree(w.base)); w.base = nullptr; }
-        const LcbSlotLayout L = lcb_slot_layout(w.pathCap, w.bodyCap, w.bestCap, w.big ? w.instCap : 0, w.big ? w.voteCap : 0);
+        // instCap != 0: instance fields in the slot (big, huge); voteCap != 0: index, lists and vote table too (huge)
+        const LcbSlotLayout L = lcb_slot_layout(w.pathCap, w.bodyCap, w.bestCap, w.instCap, w.voteCap);
         w.slotBytes = L.total;
         HIP_CHECK(hipMalloc((void**)&w.base, (size_t)w.slotBytes * w.nSlots));
-        hipLaunchKernelGGL(lcb_init_slots_kernel, dim3(w.nSlots), dim3(256), 0, stream, w.base, w.slotBytes, L, w.pathCap,
-                           w.big ? w.voteCap : 0u);
+        hipLaunchKernelGGL(lcb_init_slots_kernel, dim3(w.nSlots), dim3(256), 0, stream, w.base, w.slotBytes, L, w.pathCap, w.voteCap);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));
     }
@@ -219,11 +220,12 @@ struct lcb_device_impl {
             hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
             HIP_CHECK(hipGetLastError());
         }
-#define LCB_NW(MODE) (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT))
+#define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))
 #define LCB_LAUNCH(MODE, ST, PF) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
                                                   T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
 #define LCB_LAUNCH_MODE(MODE) do { if (stats) LCB_LAUNCH(MODE, true, false); else if (prof) LCB_LAUNCH(MODE, false, true); else LCB_LAUNCH(MODE, false, false); } while (0)
-        if (w.mode == 2) LCB_LAUNCH_MODE(2);
+        if (w.mode == 3) LCB_LAUNCH_MODE(3);
+        else if (w.mode == 2) LCB_LAUNCH_MODE(2);
         else if (w.mode == 1) LCB_LAUNCH_MODE(1);
         else LCB_LAUNCH_MODE(0);
 #undef LCB_LAUNCH_MODE
@@ -304,6 +306,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.compact_slots) o.compact_slots = 6 * nCu;
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
+        if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
         if (!o.path_cap) o.path_cap = 32768;
         if (!o.max_views) o.max_views = 256;
         if (!o.batch) o.batch = 65536;
@@ -342,21 +345,26 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->KP.depth = p->looking_depth;
         HIP_CHECK(hipMalloc((void**)&d->dCursor, 32));
         HIP_CHECK(hipMemset(d->dCursor, 0, 32));
-        // compact and wide: instances / vote table in LDS, path set + bodies + snapshot in a global slot
+        // compact and wide: per-path state in LDS; bodies, result snapshot, checkpoint (and the compact path set) in a global slot
         WorkSet& c = d->ws[0];
-        c.big = false; c.mode = 0; c.nSlots = o.compact_slots;
+        c.mode = 0; c.nSlots = o.compact_slots;
         c.pathCap = o.path_cap; c.bodyCap = c.pathCap / 2; c.bestCap = LcbCfg<0>::IC;
         d->allocWork(c);
         WorkSet& w = d->ws[1];
-        w.big = false; w.mode = 1; w.nSlots = o.wide_slots;
-        w.pathCap = o.wide_path_cap ? o.wide_path_cap : (o.path_cap < 131072 ? 131072 : o.path_cap); w.bodyCap = w.pathCap / 2; w.bestCap = LcbCfg<1>::IC;
-        if (w.pathCap & (w.pathCap - 1)) throw LcbError("lcb_device_opts.wide_path_cap must be a power of two");
+        w.mode = 1; w.nSlots = o.wide_slots;
+        w.pathCap = o.wide_path_cap ? o.wide_path_cap : LcbCfg<1>::PC;      // the set itself lives in LDS (PC slots); the slot keeps its insertion list
+        if (w.pathCap > LcbCfg<1>::PC || (w.pathCap & (w.pathCap - 1))) throw LcbError("lcb_device_opts.wide_path_cap must be a power of two, at most 8192");
+        w.bodyCap = w.pathCap / 2; w.bestCap = LcbCfg<1>::IC;
         d->allocWork(w);
-        // big (global-memory) mode for seeds that overflow the LDS capacities; grows on demand
+        // big: instance fields in the slot; huge: everything in the slot, grown on demand
         WorkSet& b = d->ws[2];
-        b.big = true; b.mode = 2; b.nSlots = o.big_slots;
-        b.pathCap = 262144; b.bodyCap = 131072; b.instCap = 8192; b.voteCap = 65536; b.bestCap = 8192;
+        b.mode = 2; b.nSlots = o.big_slots;
+        b.pathCap = 262144; b.bodyCap = 131072; b.instCap = LcbCfg<2>::IC; b.voteCap = 0; b.bestCap = LcbCfg<2>::IC;
         d->allocWork(b);
+        WorkSet& hg = d->ws[3];
+        hg.mode = 3; hg.nSlots = o.huge_slots;
+        hg.pathCap = 262144; hg.bodyCap = 131072; hg.instCap = 8192; hg.voteCap = 65536; hg.bestCap = 8192;
+        d->allocWork(hg);
         d->batchCap = o.batch;
         HIP_CHECK(hipMalloc((void**)&d->dLive, (size_t)d->batchCap * sizeof(uint32_t)));
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
@@ -370,7 +378,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         const char* wd = getenv("LCB_WATCHDOG_S");
         d->watchdogS = wd && *wd ? atof(wd) : 0;
         if (envU32("LCB_DEBUG", 0)) {
-            d->dbgSlots = std::max(c.nSlots, std::max(w.nSlots, b.nSlots));
+            d->dbgSlots = std::max(std::max(c.nSlots, hg.nSlots), std::max(w.nSlots, b.nSlots));
             HIP_CHECK(hipHostMalloc((void**)&d->hDbg, (size_t)d->dbgSlots * 16 * sizeof(uint32_t), hipHostMallocDefault));
         }
         d->rangeCap = 65536;
@@ -483,7 +491,7 @@ void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
 }
 
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
-void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[3]) { for (int i = 0; i < 3; i++) out[i] = h->impl->modeSeeds[i]; }
+void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = h->impl->modeSeeds[i]; }
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
@@ -512,7 +520,7 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     // first mode of every seed: the caller's choice, else wide for launches of few seeds (as long as their longest seed)
     // and compact for launches of many (throughput); a seed known to overflow a mode starts in the next
     const int base = d->o.start_mode ? (int)d->o.start_mode - 1 : (n <= (int64_t)d->o.wide_threshold ? 1 : 0);
-    std::vector<int64_t> todo[3];
+    std::vector<int64_t> todo[4];
     if (d->modeHint.empty() || d->o.start_mode) { todo[base].resize((size_t)n); for (int64_t s = 0; s < n; s++) todo[base][(size_t)s] = s; }
     else
         for (int64_t s = 0; s < n; s++) {
@@ -524,20 +532,20 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
         }
     for (int round = 0; ; round++) {
         int mode = -1;
-        for (int m = 0; m < 3; m++) if (!todo[m].empty()) { mode = m; break; }
+        for (int m = 0; m < 4; m++) if (!todo[m].empty()) { mode = m; break; }
         if (mode < 0) break;
-        if (round > 16) throw LcbError("a seed keeps overflowing the device workspaces");
+        if (round > 20) throw LcbError("a seed keeps overflowing the device workspaces");
         WorkSet& ws = d->ws[mode];
         std::vector<int64_t> list;
         list.swap(todo[mode]);
-        bool bigOverflow = false;
+        bool hugeOverflow = false;
         for (size_t at = 0; at < list.size(); at += d->batchCap) {
             const uint32_t m = (uint32_t)std::min<size_t>(list.size() - at, d->batchCap);
             for (uint32_t i = 0; i < m; i++) {
                 const int64_t s = list[at + i];
                 d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
             }
-            if (mode == 2) d->bigRetries += m;
+            if (mode >= 2) d->bigRetries += m;
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
             if (screen) d->screened += m;
@@ -574,21 +582,21 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                 } else if (o.status == LCB_ST_ARENA_OVF) {
                     todo[mode].push_back(s);                          // same mode again: the arena is emptied between launches
                 } else {
-                    const int nextMode = mode < 2 ? mode + 1 : 2;
-                    if (mode == 2) bigOverflow = true; else setHint(seeds[s], (uint8_t)nextMode);
+                    const int nextMode = mode < 3 ? mode + 1 : 3;
+                    if (mode == 3) hugeOverflow = true; else setHint(seeds[s], (uint8_t)nextMode);
                     todo[nextMode].push_back(s);
                 }
             }
         }
-        if (!todo[mode].empty() && mode < 2 && todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
-        if (bigOverflow) {
+        if (!todo[mode].empty() && mode < 3 && todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
+        if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
-            WorkSet& b = d->ws[2];
+            WorkSet& b = d->ws[3];
             if (b.instCap >= 32768) throw LcbError("a seed needs more than 32768 path instances: not supported by the device");
             d->allocArena(d->arenaCap * 4);
             b.pathCap *= 2; b.bodyCap *= 2; b.instCap *= 2; b.voteCap *= 2; b.bestCap *= 2;
             d->allocWork(b);
-        } else if (mode == 2 && !todo[2].empty()) d->allocArena(d->arenaCap * 4);
+        } else if (mode == 3 && !todo[3].empty()) d->allocArena(d->arenaCap * 4);
     }
     uint64_t total = 0;
     for (int64_t s = 0; s < n; s++) { offsets[(size_t)s] = total; total += cnt[(size_t)s]; }

@@ -29,7 +29,7 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
 void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_max_views_impl(lcb_device* d);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
-void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[3]);
+void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,

@@ -45,17 +45,21 @@
 // when the recorder is off. The recorder is what localises a hang on the device (host watchdog, device.hip).
 #define LCB_FLIGHT_RECORDER 1
 
-// Three kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
+// Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
-//   mode 0 "compact": 256 instances / 512 vote slots in 25 KB of LDS -> 6 single-wave workgroups per CU (throughput)
-//   mode 1 "wide":    1024 / 2048 in 110 KB of LDS, 16 wavefronts share the votes -> 1 workgroup per CU (latency)
-//   mode 2 "big":     instances + vote table in the global-memory workspace, capacities chosen by the host
+//   mode 0 "compact": 256 instances / 512 vote slots in 26 KB of LDS -> 6 single-wave workgroups per CU (throughput);
+//                     path vertex set in the global workspace behind an LDS Bloom filter
+//   mode 1 "wide":    1024 / 2048 and the path vertex set (8192 slots) in 140 KB of LDS, 16 wavefronts share the votes
+//                     -> 1 workgroup per CU (latency)
+//   mode 2 "big":     4096 / 4096: ordered index, lists and vote table in LDS, the instance fields in the global workspace
+//   mode 3 "huge":    everything in the global workspace, capacities chosen (and grown) by the host
+// IC instances, VC vote slots, BW Bloom words (0 = none), PC path-set slots in LDS (0 = global workspace)
 template <int MODE> struct LcbCfg;
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 512, BW = 512; };
-template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 2048; };
-template <> struct LcbCfg<2> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048; };
-#define LCB_IC_SMALL 256u
-#define LCB_IC_MEDIUM 1024u
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 512, BW = 512, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
+template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; };
+template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; };
+template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; };
+#define LCB_NONE16 0xFFFFu
 
 enum LcbStatus : uint32_t {
     LCB_ST_OK = 0,
@@ -118,7 +122,8 @@ struct LcbWork {               // per-workgroup global-memory workspace slots + 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
     uint64_t pKeys, pSlots, body, best, ck;                   // always (ck: forward-extension checkpoint, 6 words per instance)
-    uint64_t inst, ordKey, ordIdx, good, vKey, vCount, vLast, fp;   // big mode
+    uint64_t inst, fp;                                          // big and huge modes
+    uint64_t ordKey, ordIdx, good, goodPos, touch, vKey, vCount, vLast, vTouched;   // huge mode
     uint64_t total;
 };
 __host__ __device__ inline uint64_t lcb_align16(uint64_t x) { return (x + 15) & ~15ull; }
@@ -133,13 +138,17 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
     L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
     L.inst = o; o = lcb_align16(o + 9ull * 4 * instCap);
-    L.ordKey = o; o = lcb_align16(o + 2ull * 4 * instCap);
-    L.ordIdx = o; o = lcb_align16(o + 2ull * 4 * instCap);
-    L.good = o; o = lcb_align16(o + 4ull * instCap);
+    L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
+    const uint32_t idxCap = voteCap ? instCap : 0;             // the index / list / vote arrays only exist in huge mode
+    L.ordKey = o; o = lcb_align16(o + 2ull * 4 * idxCap);
+    L.ordIdx = o; o = lcb_align16(o + 2ull * 2 * idxCap);
+    L.good = o; o = lcb_align16(o + 2ull * idxCap);
+    L.goodPos = o; o = lcb_align16(o + 2ull * idxCap);
+    L.touch = o; o = lcb_align16(o + 2ull * idxCap);
     L.vKey = o; o = lcb_align16(o + 4ull * voteCap);
     L.vCount = o; o = lcb_align16(o + 4ull * voteCap);
     L.vLast = o; o = lcb_align16(o + 4ull * voteCap);
-    L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
+    L.vTouched = o; o = lcb_align16(o + 2ull * voteCap);
     L.total = lcb_align16(o);
     return L;
 }
@@ -186,7 +195,9 @@ __device__ __forceinline__ uint32_t lcb_wave_umin(uint32_t v) { return ~lcb_wave
 #define LCB_FLAG_FRONTFIN 4u
 #define LCB_FLAG_BITS 3u       // iFlags = (chromosome << 3) | flags
 
-struct LcbState {
+template <int MODE_>
+struct LcbStateT {
+    static constexpr int MODE = MODE_;
     LcbTables T;
     LcbKParams P;
     uint32_t lane;
@@ -194,8 +205,14 @@ struct LcbState {
     uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iLo, *iHi, *iFlags;
     int32_t *iFrontDist, *iBackDist;
     uint32_t* ordKey;          // instance_ ordered sets flattened: keys (flat compare position) ... [2][instCap], half `cur` is live
-    uint32_t* ordIdx;          // ... and pool indices, double buffered the same way
-    uint32_t* good;            // goodInstance_ (path.h:685), pool indices in append order
+    uint16_t* ordIdx;          // ... and pool indices, double buffered the same way
+    uint16_t* good;            // goodInstance_ (path.h:685), pool indices in append order
+    uint16_t* goodPos;         // inverse of `good`: position of an instance in the good list, or LCB_NONE16
+    // The instances the last successful push extended or created (after Init: the initial instances). Exactly these end at
+    // the path end (their end distance equals the flank, and path distances are strictly monotone), so they are the voters
+    // of the next vote (blocksfinder.h:716-717) — no scan over the instance list is needed.
+    uint16_t* touch;
+    uint32_t nTouch, nInit;
     // Footprint: per instance ever created, the range of flat positions whose `used` bit was read as 0 and could
     // have changed the result (its span plus every look-ahead window walked from its ends). A result computed
     // against an older `used` snapshot is still exact iff no bit inside these ranges has been set since
@@ -207,7 +224,8 @@ struct LcbState {
     int32_t* vKey;
     uint32_t* vCount;
     uint32_t* vLast;
-    uint32_t* vNClaimed;       // LDS counter: slots claimed in the current vote
+    uint16_t* vTouched;        // slots claimed in the current vote, in claim order
+    uint32_t* vNClaimed;       // LDS counter: number of them
     uint32_t* vOvf;            // LDS flag: a walk of the current vote could not place a vertex
     uint32_t voteCap, voteShift;
     uint32_t* scr;             // LDS scratch, 4 * 64 words
@@ -304,13 +322,15 @@ __device__ __forceinline__ int64_t lcb_wave_sum(int64_t v)
 __device__ __forceinline__ uint32_t lcb_bloom1(int32_t vid, uint32_t sh) { return ((uint32_t)vid * 2654435761u) >> sh; }
 __device__ __forceinline__ uint32_t lcb_bloom2(int32_t vid, uint32_t sh) { return ((uint32_t)vid * 0xC2B2AE35u + 0x27D4EB2Fu) >> sh; }
 
-__device__ __forceinline__ bool lcb_bloom_maybe(const LcbState& S, int32_t vid)
+template <class ST>
+__device__ __forceinline__ bool lcb_bloom_maybe(const ST& S, int32_t vid)
 {
     const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
     return ((S.bloom[a >> 5] >> (a & 31)) & (S.bloom[b >> 5] >> (b & 31)) & 1u) != 0;
 }
 
-__device__ inline bool lcb_path_probe(const LcbState& S, int32_t vid, uint32_t& probes)
+template <class ST>
+__device__ inline bool lcb_path_probe(const ST& S, int32_t vid, uint32_t& probes)
 {
     uint32_t h = lcb_hash(vid, S.pathShift);
     const uint32_t mask = S.pathCap - 1;
@@ -324,15 +344,17 @@ __device__ inline bool lcb_path_probe(const LcbState& S, int32_t vid, uint32_t& 
     return k == vid;
 }
 
-__device__ __forceinline__ bool lcb_path_contains(const LcbState& S, int32_t vid)
+template <class ST>
+__device__ __forceinline__ bool lcb_path_contains(const ST& S, int32_t vid)
 {
-    if (!lcb_bloom_maybe(S, vid)) return false;
+    if (LcbCfg<ST::MODE>::BW && !lcb_bloom_maybe(S, vid)) return false;    // (no filter in front of an LDS-resident set)
     uint32_t probes;
     return lcb_path_probe(S, vid, probes);
 }
 
 // Wave-uniform: inserts vid (not present). Lane 0 writes.
-__device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
+template <class ST>
+__device__ inline void lcb_path_insert(ST& S, int32_t vid)
 {
     if ((S.nPath + 1) * 2 > S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
     uint32_t h = lcb_hash(vid, S.pathShift);
@@ -343,21 +365,24 @@ __device__ inline void lcb_path_insert(LcbState& S, int32_t vid)
     LCB_WAVE_SYNC();               // every lane has finished probing before lane 0 publishes the key
     if (S.lane == 0) {
         S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
-        const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
-        S.bloom[a >> 5] |= 1u << (a & 31);
-        S.bloom[b >> 5] |= 1u << (b & 31);
+        if (LcbCfg<ST::MODE>::BW) {
+            const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
+            S.bloom[a >> 5] |= 1u << (a & 31);
+            S.bloom[b >> 5] |= 1u << (b & 31);
+        }
     }
     S.nPath++;
     LCB_WAVE_SYNC();
 }
 
 // Path::Clear (path.h:650-677): wave-uniform. The right-body list is kept (the replay reads it).
-template <int BW>
-__device__ inline void lcb_path_clear(LcbState& S)
+template <class ST>
+__device__ inline void lcb_path_clear(ST& S)
 {
+    constexpr uint32_t BW = LcbCfg<ST::MODE>::BW;
     for (uint32_t i = S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
-    if (S.nPath) for (uint32_t i = S.lane; i < (uint32_t)BW; i += 64) S.bloom[i] = 0;
-    S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0;
+    if (BW && S.nPath) for (uint32_t i = S.lane; i < (uint32_t)BW; i += 64) S.bloom[i] = 0;
+    S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0; S.nTouch = 0;
     S.rightFlank = 0; S.leftFlank = 0;
     LCB_WAVE_SYNC();
 }
@@ -366,19 +391,21 @@ __device__ inline void lcb_path_clear(LcbState& S)
 __device__ __forceinline__ uint32_t lcb_absdiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 
 // Instance::RealLength (path.h:165-168): |front.GetPosition() - back.GetPosition()| (k cancels).
-__device__ __forceinline__ int64_t lcb_real_length(const LcbState& S, uint32_t i)
+template <class ST>
+__device__ __forceinline__ int64_t lcb_real_length(const ST& S, uint32_t i)
 {
     return (int64_t)lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]);
 }
 
 // Rebuilds the ordered index after m inserts of one chunk. The insert list (position in the OLD order,
 // key, pool index) is in scr[0..m), scr[64..64+m), scr[128..128+m), ascending by position then key.
-__device__ inline void lcb_order_merge(LcbState& S, uint32_t m)
+template <class ST>
+__device__ inline void lcb_order_merge(ST& S, uint32_t m)
 {
     const uint32_t n = S.nInst - m;     // old element count (nInst already includes the new ones)
     const uint32_t c = S.cur, d = c ^ 1;
-    const uint32_t* ck = S.ordKey + c * S.instCap; const uint32_t* ci = S.ordIdx + c * S.instCap;
-    uint32_t* dk = S.ordKey + d * S.instCap; uint32_t* di = S.ordIdx + d * S.instCap;
+    const uint32_t* ck = S.ordKey + c * S.instCap; const uint16_t* ci = S.ordIdx + c * S.instCap;
+    uint32_t* dk = S.ordKey + d * S.instCap; uint16_t* di = S.ordIdx + d * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         uint32_t cnt = 0;
         for (uint32_t r = 0; r < m; r++) cnt += (S.scr[r] <= i) ? 1u : 0u;
@@ -388,15 +415,15 @@ __device__ inline void lcb_order_merge(LcbState& S, uint32_t m)
     if (S.lane < m) {
         const uint32_t at = S.scr[S.lane] + S.lane;
         dk[at] = S.scr[64 + S.lane];
-        di[at] = S.scr[128 + S.lane];
+        di[at] = (uint16_t)S.scr[128 + S.lane];
     }
     S.cur = d;
     LCB_WAVE_SYNC();
 }
 
 // Path::Init (path.h:33-46): one instance per unused occurrence of vid whose next character is ch.
-template <bool STATS>
-__device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
+template <bool STATS, class ST>
+__device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 {
     const LcbTables& T = S.T;
     lcb_path_insert(S, vid);          // distanceKeeper_.Set(vid, 0)
@@ -426,11 +453,14 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }        // the replay re-creates instance i at the same occurrence
             S.ordKey[S.cur * S.instCap + i] = g;   // occurrences ascend in g, so pool order == key order here
-            S.ordIdx[S.cur * S.instCap + i] = i;
+            S.ordIdx[S.cur * S.instCap + i] = (uint16_t)i;
+            S.goodPos[i] = LCB_NONE16;
+            S.touch[i] = (uint16_t)i;              // every initial instance ends at the seed vertex: they vote first
         }
         S.nInst += cnt;
         if (S.nInst > S.nFp) S.nFp = S.nInst;
     }
+    S.nTouch = S.nInst; S.nInit = S.nInst;
     LCB_WAVE_SYNC();
 }
 
@@ -439,33 +469,35 @@ __device__ inline void lcb_path_init(LcbState& S, int32_t vid, int32_t ch)
 struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
 struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 
-// The voter walks of one vote. Wave w of nWaves takes the voters with ordinal == w (mod nWaves); all waves accumulate
-// into the shared vote table with atomics, so the split needs no merging. The list is scanned 64 entries per pass.
-template <bool STATS>
-__device__ inline void lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
+// The voter walks of one vote. The voters are the instances of the touch list that are in the voting list (the good list
+// if it has two entries, else all instances; blocksfinder.h:713). Wave w of nWaves takes the voters with ordinal == w
+// (mod nWaves); all waves accumulate into the shared vote table with atomics, so the split needs no merging.
+template <bool STATS, class ST>
+__device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
                                      uint32_t waveId, uint32_t nWaves)
 {
     const LcbTables& T = S.T;
     const uint32_t vmask = S.voteCap - 1;
     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
     const uint32_t depth = (uint32_t)S.P.depth, maxBranch = (uint32_t)S.P.maxBranch;
-    // list scan state: the current chunk of 64 list entries (per-lane fields) and the voters still to hand out from it
+    // the current chunk of 64 touch-list entries (per-lane fields) and the voters still to hand out from it
+    const uint32_t nTouch = S.nTouch;
     uint32_t chunkBase = 0, ordinal = 0;
     unsigned long long pend = 0;
-    uint32_t fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
+    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
     bool scanned = false;
     auto nextVoter = [&](LcbVoter& v) -> bool {
         for (;;) {
             while (pend == 0) {
                 if (scanned) chunkBase += 64;
                 scanned = true;
-                if (chunkBase >= nList) return false;
-                const uint32_t e = chunkBase + S.lane;
+                if (chunkBase >= nTouch) return false;
+                const uint32_t t = chunkBase + S.lane;
                 bool is = false;
-                if (e < nList) {
-                    fI = useGood ? S.good[e] : e;
-                    // inst->Back().GetVertexId() == path end vertex  <=>  equal path distances (strictly monotone)
-                    is = (forward ? S.iBackDist[fI] : S.iFrontDist[fI]) == flank;
+                if (t < nTouch) {
+                    fI = S.touch[t];
+                    fE = useGood ? (uint32_t)S.goodPos[fI] : fI;          // position in the voting list (its order breaks ties)
+                    is = fE != LCB_NONE16;
                     if (is) {
                         fFl = S.iFlags[fI];
                         const uint32_t fp = S.iFrontPos[fI], bp = S.iBackPos[fI];
@@ -481,7 +513,7 @@ __device__ inline void lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bo
             pend &= pend - 1;
             const uint32_t o = ordinal++;
             if (nWaves > 1 && (o % nWaves) != waveId) continue;
-            v.e = chunkBase + b;
+            v.e = lcb_rl(fE, b);
             v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
             const uint32_t hi = lcb_rl(fHi, b);
             v.weight = lcb_rl(fW, b);
@@ -538,7 +570,10 @@ __device__ inline void lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bo
                     h = (h + 1) & vmask; probe++;
                     old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
                 }
-                if (old == LCB_EMPTY_KEY) { if (atomicAdd(S.vNClaimed, 1u) >= claimCap) *S.vOvf = 1u; }
+                if (old == LCB_EMPTY_KEY) {
+                    const uint32_t t = atomicAdd(S.vNClaimed, 1u);
+                    if (t < claimCap) S.vTouched[t] = (uint16_t)h; else *S.vOvf = 1u;
+                }
                 if (old == LCB_EMPTY_KEY || old == vid) {
                     atomicAdd(&S.vCount[h], cur.weight);
                     atomicMax(&S.vLast[h], (cur.e << 16) | d);
@@ -559,18 +594,19 @@ __device__ inline void lcb_vote_walk(LcbState& S, bool forward, bool tryUsed, bo
     }
 }
 
-// Arg-max over the slots [s0, s1) of the vote table, wave-wide: max count; ties -> smallest origin (strand, g) of the
+// Arg-max over the entries [s0, s1) of the touched list of the vote table, wave-wide: max count; ties -> smallest origin (strand, g) of the
 // last contributing instance in list order; ties -> earliest step. Equal counts are the NORMAL case (collinear voters
 // give every vertex of their common window the same total), so the tie key is always computed.
 struct LcbBest { uint32_t cnt, keyHi, keyLo; int32_t vid; uint32_t e; };
 
-__device__ inline LcbBest lcb_vote_argmax(const LcbState& S, bool forward, bool useGood, uint32_t s0, uint32_t s1)
+template <class ST>
+__device__ inline LcbBest lcb_vote_argmax(const ST& S, bool forward, bool useGood, uint32_t s0, uint32_t s1)
 {
     uint32_t bCnt = 0, bHi = 0xFFFFFFFFu, bLo = 0xFFFFFFFFu, bE = 0;
     int32_t bVid = 0;
-    for (uint32_t t = s0 + S.lane; t < s1; t += 64) {
+    for (uint32_t q = s0 + S.lane; q < s1; q += 64) {
+        const uint32_t t = S.vTouched[q];
         const int32_t key = S.vKey[t];
-        if (key == LCB_EMPTY_KEY) continue;
         const uint32_t cnt = S.vCount[t], last = S.vLast[t];
         const uint32_t e = last >> 16, d = last & 0xFFFFu;
         const uint32_t i = useGood ? S.good[e] : e;
@@ -594,27 +630,42 @@ __device__ inline LcbBest lcb_vote_argmax(const LcbState& S, bool forward, bool 
 }
 
 // Mailbox words through which wave 0 hands a vote to the helper wavefronts of its workgroup.
-enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_WORDS = 8 };
+enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_NTOUCH, LCB_MAIL_WORDS = 8 };
 enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
 
-// One wave's share of a vote after the walks: partial arg-max over its slice of the table, then (after everyone has
-// read) the clearing of that slice (blocksfinder.h:761-766).
-template <int NW>
-__device__ inline void lcb_vote_reduce_slice(LcbState& S, bool forward, bool useGood, uint32_t waveId)
+// Clears the vote-table slots named by the entries [s0, s1) of the touched list (blocksfinder.h:761-766).
+template <class ST>
+__device__ inline void lcb_vote_clear(ST& S, uint32_t s0, uint32_t s1)
 {
-    const uint32_t per = S.voteCap / NW;                       // voteCap is a power of two, a multiple of NW
-    const uint32_t s0 = waveId * per, s1 = s0 + per;
+    for (uint32_t q = s0 + S.lane; q < s1; q += 64) { const uint32_t t = S.vTouched[q]; S.vKey[t] = LCB_EMPTY_KEY; S.vCount[t] = 0; S.vLast[t] = 0; }
+}
+
+// Votes with at least this many voters are also reduced and cleared by all wavefronts of the workgroup (two more
+// barriers); smaller ones by wave 0 alone while the helpers already wait for the next vote. Decided before the walks, so
+// that every wavefront knows which protocol the vote follows.
+#ifndef LCB_VOTE_SHARE_MIN
+#define LCB_VOTE_SHARE_MIN 24u         // (the emulator tests also build with a tiny threshold to walk the shared path)
+#endif
+
+// One wave's share of a large vote after the walks: partial arg-max over its slice of the touched list, then (after
+// everyone has read) the clearing of that slice.
+template <int NW, class ST>
+__device__ inline void lcb_vote_reduce_slice(ST& S, bool forward, bool useGood, uint32_t waveId, uint32_t nTouched)
+{
+    const uint32_t per = (nTouched + NW - 1) / NW;
+    const uint32_t s0 = waveId * per < nTouched ? waveId * per : nTouched, s1 = s0 + per < nTouched ? s0 + per : nTouched;
     const LcbBest b = lcb_vote_argmax(S, forward, useGood, s0, s1);
     if (S.lane == 0) {
         uint32_t* p = S.part + 8 * waveId;
         p[0] = b.cnt; p[1] = b.keyHi; p[2] = b.keyLo; p[3] = (uint32_t)b.vid; p[4] = b.e;
     }
     __syncthreads();                                           // C: every slice has been read, partials are visible
-    for (uint32_t t = s0 + S.lane; t < s1; t += 64) { S.vKey[t] = LCB_EMPTY_KEY; S.vCount[t] = 0; S.vLast[t] = 0; }
+    lcb_vote_clear(S, s0, s1);
+    __syncthreads();                                           // D: the table is clean before wave 0 votes again (possibly on its own)
 }
 
-template <bool STATS, bool PROF, int NW>
-__device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint32_t& originInst)
+template <bool STATS, bool PROF, int NW, class ST>
+__device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& originInst)
 {
     const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
     const uint32_t nList = useGood ? S.nGood : S.nInst;
@@ -622,48 +673,56 @@ __device__ inline int32_t lcb_vote(LcbState& S, bool forward, bool tryUsed, uint
     if (STATS && S.lane == 0) S.cVote++;
     if (PROF) S.pfVote++;
     originInst = 0;
-    if (nList == 0) return 0;                                      // nobody votes: nothing to walk, nothing to clear
+    if (nList == 0 || S.nTouch == 0) return 0;                     // nobody votes: nothing to walk, nothing to clear
+    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
     LcbBest b;
-    bool ovfAny;
-    if (NW > 1) {
-        // wake the helper wavefronts: every wave walks its share of the voters, reduces and clears its slice of the table
+    uint32_t nTouched;
+    if (NW > 1 && S.nTouch > 1) {
+        // wake the helper wavefronts: every wave walks its share of the voters
         if (S.lane == 0) {
-            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u);
-            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank;
+            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u);
+            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
         lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, NW);
         __syncthreads();                                           // B: all walks done
-        ovfAny = lcb_rfl(*S.vOvf) != 0;
-        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; }
-        lcb_vote_reduce_slice<NW>(S, forward, useGood, 0);        // contains barrier C
-        if (STATS && S.lane == 0) *S.mailWalk = 0;
-        if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
-        // final reduction over the NW partial results
-        uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0;
-        if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; }
-        b.cnt = lcb_wave_umax(pc);
-        bool c = pc == b.cnt && b.cnt != 0;
-        b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
-        b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
-        const unsigned long long m = __ballot(c);
-        const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
-        b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
-        b.e = lcb_rl(pe, w);
+        nTouched = lcb_rfl(*S.vNClaimed);
+        if (nTouched > claimCap) nTouched = claimCap;
+        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
+        if (S.nTouch >= LCB_VOTE_SHARE_MIN) {
+            lcb_vote_reduce_slice<NW>(S, forward, useGood, 0, nTouched);      // contains barriers C and D
+            // final reduction over the NW partial results
+            uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0;
+            if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; }
+            b.cnt = lcb_wave_umax(pc);
+            bool c = pc == b.cnt && b.cnt != 0;
+            b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
+            b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
+            const unsigned long long m = __ballot(c);
+            const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+            b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
+            b.e = lcb_rl(pe, w);
+        } else {
+            b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
+            LCB_WAVE_SYNC();
+            lcb_vote_clear(S, 0, nTouched);
+        }
     } else {
         lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
         LCB_WAVE_SYNC();
-        ovfAny = lcb_rfl(*S.vOvf) != 0;
-        b = lcb_vote_argmax(S, forward, useGood, 0, S.voteCap);
+        nTouched = lcb_rfl(*S.vNClaimed);
+        if (nTouched > claimCap) nTouched = claimCap;
+        b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
         LCB_WAVE_SYNC();
-        for (uint32_t t = S.lane; t < S.voteCap; t += 64) { S.vKey[t] = LCB_EMPTY_KEY; S.vCount[t] = 0; S.vLast[t] = 0; }
-        if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
-        LCB_WAVE_SYNC();
+        lcb_vote_clear(S, 0, nTouched);
     }
+    const bool ovfAny = lcb_rfl(*S.vOvf) != 0;
+    if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
+    LCB_WAVE_SYNC();
     if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
     if (b.cnt == 0) return 0;
-    originInst = useGood ? lcb_rfl(S.good[b.e]) : b.e;
+    originInst = useGood ? lcb_rfl((uint32_t)S.good[b.e]) : b.e;
     return b.vid;
 }
 
@@ -728,8 +787,8 @@ struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posI
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
 // rec0: the occurrence records o0 + lane of the pushed vertex, already loaded by the caller.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
-template <bool BACK, bool STATS, bool PROF>
-__device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, const uint4& rec0)
+template <bool BACK, bool STATS, bool PROF, class ST>
+__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
@@ -737,7 +796,7 @@ __device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, cons
     const uint32_t o0 = E.o0, o1 = E.o1;
     // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
     LcbOcc occ = lcb_finish_occ(T, rec0, o0 + S.lane < o1);
-    bool inPath = lcb_bloom_maybe(S, vertex);
+    bool inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
     if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
     if (inPath) return false;
     const uint32_t length = lcb_absdiff(E.posN, E.posIt);
@@ -749,12 +808,13 @@ __device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, cons
     if (S.status) return false;
 
     const int64_t B = S.P.maxBranch;
+    uint32_t nTouch = 0;                                             // instances this push extends or creates
     for (uint32_t base = o0; base < o1; base += 64) {
         const uint32_t j = base + S.lane;
         const bool active = j < o1;
         const uint32_t n = S.nInst;
         const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-        const uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
+        const uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         bool positive = false, usedS = false, usesP = false;
@@ -881,11 +941,17 @@ __device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, cons
             becameGood = before < (int64_t)S.P.minBlock && lcb_real_length(S, cand) >= (int64_t)S.P.minBlock;
         }
         const unsigned long long insM = __ballot(ins);
+        const unsigned long long extM = __ballot(ext);
         const unsigned long long goodM = __ballot(becameGood);
         const uint32_t m = (uint32_t)__popcll(insM);
         if (S.nInst + m > S.instCap) { S.status = LCB_ST_INST_OVF; return true; }
-        if (becameGood) S.good[S.nGood + (uint32_t)__popcll(goodM & ((1ull << S.lane) - 1))] = cand;
+        if (becameGood) {
+            const uint32_t at = S.nGood + (uint32_t)__popcll(goodM & ((1ull << S.lane) - 1));
+            S.good[at] = (uint16_t)cand; S.goodPos[cand] = (uint16_t)at;
+        }
         S.nGood += (uint32_t)__popcll(goodM);
+        if (ext) S.touch[nTouch + (uint32_t)__popcll(extM & ((1ull << S.lane) - 1))] = (uint16_t)cand;
+        nTouch += (uint32_t)__popcll(extM);
         if (ins) {
             const uint32_t r = (uint32_t)__popcll(insM & ((1ull << S.lane) - 1));
             const uint32_t i = S.nInst + r;
@@ -895,7 +961,10 @@ __device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, cons
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
+            S.goodPos[i] = LCB_NONE16;
+            S.touch[nTouch + r] = (uint16_t)i;
         }
+        nTouch += m;
         S.nInst += m;
         if (S.nInst > S.nFp) S.nFp = S.nInst;
         LCB_WAVE_SYNC();
@@ -912,13 +981,15 @@ __device__ inline bool lcb_push(LcbState& S, const LcbEdge& E, bool record, cons
         S.nLeft++;
         S.leftFlank = distance;
     }
+    S.nTouch = nTouch;
     if (STATS && S.lane == 0) S.cPush++;
     if (PROF) { S.pfPush++; if (S.nInst > S.pfMaxInst) S.pfMaxInst = S.nInst; }
     return true;
 }
 
 // Path::Score (path.h:604-628)
-__device__ inline int64_t lcb_score(const LcbState& S)
+template <class ST>
+__device__ inline int64_t lcb_score(const ST& S)
 {
     int64_t sum = 0;
     bool bad = false;
@@ -936,7 +1007,8 @@ __device__ inline int64_t lcb_score(const LcbState& S)
 }
 
 // bestInstance <- goodInstance_ (blocksfinder.h:820-824,883-887)
-__device__ inline void lcb_snapshot(LcbState& S)
+template <class ST>
+__device__ inline void lcb_snapshot(ST& S)
 {
     if (S.nGood > S.bestCap) { S.status = LCB_ST_BEST_OVF; return; }
     for (uint32_t e = S.lane; e < S.nGood; e += 64) {
@@ -953,13 +1025,14 @@ __device__ inline void lcb_snapshot(LcbState& S)
 // the ordered index of existing instances; the best-scoring point only moves forward. A checkpoint taken at a best point
 // therefore stays a valid restart for the replay whatever follows.
 #define LCB_CK_EVERY 32u
-__device__ inline void lcb_checkpoint(LcbState& S)
+template <class ST>
+__device__ inline void lcb_checkpoint(ST& S)
 {
     const uint32_t n = S.nInst, cap = S.bestCap;
     if (n > cap) return;
     uint32_t* c = S.ck;
     const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-    const uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    const uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         c[i] = S.iBackG[i]; c[cap + i] = S.iBackPos[i]; c[2 * cap + i] = (uint32_t)S.iBackDist[i]; c[3 * cap + i] = S.iFlags[i];
         c[4 * cap + i] = oKey[i]; c[5 * cap + i] = oIdx[i];
@@ -969,20 +1042,22 @@ __device__ inline void lcb_checkpoint(LcbState& S)
 
 // Back to the checkpoint: the state after ckN forward pushes (Front fields, chromosome data and the right-body list are
 // untouched by forward pushes; the Bloom filter and the footprints keep their supersets).
-__device__ inline void lcb_restore_checkpoint(LcbState& S)
+template <class ST>
+__device__ inline void lcb_restore_checkpoint(ST& S)
 {
     LCB_WAVE_SYNC();
     for (uint32_t i = S.ckPath + S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
+    for (uint32_t e = S.ckGood + S.lane; e < S.nGood; e += 64) S.goodPos[S.good[e]] = LCB_NONE16;   // they became good after the checkpoint
     const uint32_t n = S.ckInst, cap = S.bestCap;
     const uint32_t* c = S.ck;
     uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-    uint32_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         S.iBackG[i] = c[i]; S.iBackPos[i] = c[cap + i]; S.iBackDist[i] = (int32_t)c[2 * cap + i]; S.iFlags[i] = c[3 * cap + i];
-        oKey[i] = c[4 * cap + i]; oIdx[i] = c[5 * cap + i];
+        oKey[i] = c[4 * cap + i]; oIdx[i] = (uint16_t)c[5 * cap + i];
     }
     S.nPath = S.ckPath; S.nInst = n; S.nGood = S.ckGood; S.nRight = S.ckN; S.nLeft = 0;
-    S.rightFlank = S.ckFlank; S.leftFlank = 0;
+    S.rightFlank = S.ckFlank; S.leftFlank = 0; S.nTouch = 0;        // (no vote follows before the next push or the backward phase)
     LCB_WAVE_SYNC();
 }
 
@@ -994,8 +1069,8 @@ struct LcbEdgeBatch { uint32_t gIt, itPos, posIt, posN, o0, o1; int32_t idIt, id
 // Edges along a chromosome walk: edge l goes from position g + dir*l to g + dir*(l+1) (ExtendPathForward/Backward,
 // blocksfinder.h:789-802,852-865). Returns the number of edges up to the first position whose vertex is `next`
 // (64 if it is further away; the caller then asks for the following batch).
-template <bool FORWARD>
-__device__ inline uint32_t lcb_batch_from_walk(const LcbState& S, uint32_t g, int dir, bool positive, uint32_t lo, uint32_t hi, int32_t next, LcbEdgeBatch& b)
+template <bool FORWARD, class ST>
+__device__ inline uint32_t lcb_batch_from_walk(const ST& S, uint32_t g, int dir, bool positive, uint32_t lo, uint32_t hi, int32_t next, LcbEdgeBatch& b)
 {
     const LcbTables& T = S.T;
     const int64_t q0 = (int64_t)g + (int64_t)dir * (int64_t)S.lane, q1 = q0 + dir;
@@ -1023,7 +1098,8 @@ __device__ inline uint32_t lcb_batch_from_walk(const LcbState& S, uint32_t g, in
 }
 
 // Edges of the recorded right body [from, from + 64) for the replay (blocksfinder.h:271-284).
-__device__ inline void lcb_batch_from_body(const LcbState& S, uint32_t from, uint32_t n, LcbEdgeBatch& b)
+template <class ST>
+__device__ inline void lcb_batch_from_body(const ST& S, uint32_t from, uint32_t n, LcbEdgeBatch& b)
 {
     const LcbTables& T = S.T;
     b.gIt = 0; b.itPos = 0; b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.o1 = 0;
@@ -1047,8 +1123,8 @@ __device__ __forceinline__ LcbEdge lcb_edge_of(const LcbEdgeBatch& b, uint32_t l
 }
 
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
-template <bool FORWARD, bool STATS, bool PROF, int NW>
-__device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
+template <bool FORWARD, bool STATS, bool PROF, int NW, class ST>
+__device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
 {
     const LcbTables& T = S.T;
     uint32_t oi = 0;
@@ -1105,10 +1181,9 @@ __device__ inline bool lcb_extend(LcbState& S, uint32_t& bestRightSize, int64_t&
 }
 
 // ProcessVertex::Process (blocksfinder.h:228-310)
-template <int MODE, bool STATS, bool PROF, int NW>
-__device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
+template <int MODE, bool STATS, bool PROF, int NW, class ST>
+__device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
-    constexpr int BW = (int)LcbCfg<MODE>::BW;
     int64_t score = 0, bestScore = 0;
     S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0;
     LCB_MARK(S, 2, 1);
@@ -1137,7 +1212,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
             lcb_restore_checkpoint(S);    // the state after ckN pushes; stats mode replays from Init like the reference (event counts)
             from = S.ckN;
         } else {
-            lcb_path_clear<BW>(S);        // keeps the body list, resets everything else
+            lcb_path_clear(S);        // keeps the body list, resets everything else
             lcb_path_init<STATS>(S, vid, ch);
         }
         while (from < nEdge && !S.status) {
@@ -1157,6 +1232,11 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
     }
     LCB_MARK(S, 2, 4);
     if (!S.status && !dead) {
+        // The first backward vote: the instances whose FRONT is the seed vertex (front distance 0 = left flank) are the
+        // initial ones, pool entries [0, nInit) — back pushes leave fronts alone and create instances at distance > 0.
+        for (uint32_t i = S.lane; i < S.nInit; i += 64) S.touch[i] = (uint16_t)i;
+        S.nTouch = S.nInit;
+        LCB_WAVE_SYNC();
         for (;;) {                                                   // blocksfinder.h:292-306 (stray ';' at :297, Q1)
             bool ret = true;
             const int64_t prevLength = (int64_t)S.rightFlank - S.leftFlank;
@@ -1168,7 +1248,7 @@ __device__ inline void lcb_process_seed(LcbState& S, int32_t vid, int32_t ch, in
         }
     }
     LCB_MARK(S, 2, 5);
-    lcb_path_clear<BW>(S);            // Path::Clear (blocksfinder.h:308)
+    lcb_path_clear(S);            // Path::Clear (blocksfinder.h:308)
     bestScoreOut = bestScore;
 }
 
@@ -1196,18 +1276,23 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                                         const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
                                         uint2* fpArena, unsigned long long fpCap)
 {
-    constexpr bool BIG = MODE == 2;
-    constexpr uint32_t IC = LcbCfg<MODE>::IC, VC = LcbCfg<MODE>::VC, BW = LcbCfg<MODE>::BW;
-    __shared__ uint32_t sInst[9 * IC];
-    __shared__ uint32_t sOrdKey[2 * IC];
-    __shared__ uint32_t sOrdIdx[2 * IC];
-    __shared__ uint32_t sGood[IC];
-    __shared__ uint32_t sFp[2 * IC];
-    __shared__ int32_t sVKey[VC];
-    __shared__ uint32_t sVCount[VC];
-    __shared__ uint32_t sVLast[VC];
-    __shared__ uint32_t sBloom[BW];
-    __shared__ uint32_t sScr[4 * 64];
+    typedef LcbCfg<MODE> Cfg;
+    constexpr bool INST_LDS = Cfg::INST_LDS, IDX_LDS = Cfg::IDX_LDS;
+    constexpr uint32_t IC = Cfg::IC, VC = Cfg::VC, BW = Cfg::BW, PC = Cfg::PC;
+    __shared__ uint32_t sInst[INST_LDS ? 9 * IC : 1];
+    __shared__ uint32_t sFp[INST_LDS ? 2 * IC : 1];
+    __shared__ uint32_t sOrdKey[IDX_LDS ? 2 * IC : 1];
+    __shared__ uint16_t sOrdIdx[IDX_LDS ? 2 * IC : 1];
+    __shared__ uint16_t sGood[IDX_LDS ? IC : 1];
+    __shared__ uint16_t sGoodPos[IDX_LDS ? IC : 1];
+    __shared__ uint16_t sTouch[IDX_LDS ? IC : 1];
+    __shared__ int32_t sVKey[IDX_LDS ? VC : 1];
+    __shared__ uint32_t sVCount[IDX_LDS ? VC : 1];
+    __shared__ uint32_t sVLast[IDX_LDS ? VC : 1];
+    __shared__ uint16_t sVTouched[IDX_LDS ? VC : 1];
+    __shared__ uint32_t sBloom[BW ? BW : 1];
+    __shared__ int32_t sPath[PC ? PC : 1];
+    __shared__ uint32_t sScr[3 * 64];
     __shared__ uint32_t sMisc[4];
     __shared__ uint32_t sMail[LCB_MAIL_WORDS];
     __shared__ uint32_t sPart[8 * NW];
@@ -1219,55 +1304,55 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.live = W.live; sArgs.nSeeds = W.live ? *W.nLive : nSeeds;
     }
 
-    LcbState S;
+    LcbStateT<MODE> S;
     S.T = T; S.P = P;
     S.lane = threadIdx.x & 63u;
     uint8_t* slot = W.base + (uint64_t)blockIdx.x * W.slotBytes;
-    const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, BIG ? W.instCap : 0, BIG ? W.voteCap : 0);
-    S.pKeys = (int32_t*)(slot + L.pKeys);
+    const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, INST_LDS ? 0 : W.instCap, IDX_LDS ? 0 : W.voteCap);
     S.pSlots = (uint32_t*)(slot + L.pSlots);
-    S.pathCap = W.pathCap; S.pathShift = 32u - (uint32_t)__ffs((int)W.pathCap) + 1u;
+    if (PC) { S.pKeys = sPath; S.pathCap = W.pathCap < PC ? W.pathCap : PC; for (uint32_t h = threadIdx.x; h < PC; h += 64 * NW) sPath[h] = LCB_EMPTY_KEY; }   // (a smaller capacity only in tests)
+    else { S.pKeys = (int32_t*)(slot + L.pKeys); S.pathCap = W.pathCap; }
+    S.pathShift = 32u - (uint32_t)__ffs((int)S.pathCap) + 1u;
     S.body = (unsigned long long*)(slot + L.body); S.bodyCap = W.bodyCap;
     S.best = (uint4*)(slot + L.best); S.bestCap = W.bestCap;
     S.ck = (uint32_t*)(slot + L.ck); S.ckN = S.ckInst = S.ckGood = S.ckPath = 0; S.ckFlank = 0;
     uint32_t* instBase;
-    if (BIG) {
-        instBase = (uint32_t*)(slot + L.inst); S.instCap = W.instCap;
-        S.ordKey = (uint32_t*)(slot + L.ordKey);
-        S.ordIdx = (uint32_t*)(slot + L.ordIdx);
-        S.good = (uint32_t*)(slot + L.good);
-        S.fpLo = (uint32_t*)(slot + L.fp); S.fpHi = S.fpLo + W.instCap;
-        S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
-        S.vLast = (uint32_t*)(slot + L.vLast);
-        S.voteCap = W.voteCap;
-    } else {
-        instBase = sInst; S.instCap = IC;
-        S.ordKey = sOrdKey;
-        S.ordIdx = sOrdIdx;
-        S.good = sGood;
-        S.fpLo = sFp; S.fpHi = sFp + IC;
-        S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast;
+    uint32_t instStride;                                           // words between the instance field arrays
+    if (INST_LDS) { instBase = sInst; instStride = IC; S.fpLo = sFp; S.fpHi = sFp + IC; }
+    else { instBase = (uint32_t*)(slot + L.inst); instStride = W.instCap; S.fpLo = (uint32_t*)(slot + L.fp); S.fpHi = S.fpLo + W.instCap; }
+    if (IDX_LDS) {
+        S.instCap = IC;
+        S.ordKey = sOrdKey; S.ordIdx = sOrdIdx; S.good = sGood; S.goodPos = sGoodPos; S.touch = sTouch;
+        S.vKey = sVKey; S.vCount = sVCount; S.vLast = sVLast; S.vTouched = sVTouched;
         S.voteCap = VC;
         for (uint32_t h = threadIdx.x; h < VC; h += 64 * NW) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
+    } else {
+        S.instCap = W.instCap;
+        S.ordKey = (uint32_t*)(slot + L.ordKey); S.ordIdx = (uint16_t*)(slot + L.ordIdx);
+        S.good = (uint16_t*)(slot + L.good); S.goodPos = (uint16_t*)(slot + L.goodPos); S.touch = (uint16_t*)(slot + L.touch);
+        S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
+        S.vLast = (uint32_t*)(slot + L.vLast); S.vTouched = (uint16_t*)(slot + L.vTouched);
+        S.voteCap = W.voteCap;
     }
     S.bloom = sBloom;
-    S.bloomShift = 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u;
+    S.bloomShift = BW ? 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u : 0u;
     for (uint32_t h = threadIdx.x; h < BW; h += 64 * NW) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
-    S.iFrontG = instBase; S.iBackG = instBase + S.instCap; S.iFrontPos = instBase + 2 * S.instCap;
-    S.iBackPos = instBase + 3 * S.instCap; S.iLo = instBase + 4 * S.instCap;
-    S.iHi = instBase + 5 * S.instCap; S.iFlags = instBase + 6 * S.instCap;
-    S.iFrontDist = (int32_t*)(instBase + 7 * S.instCap); S.iBackDist = (int32_t*)(instBase + 8 * S.instCap);
+    S.iFrontG = instBase; S.iBackG = instBase + instStride; S.iFrontPos = instBase + 2 * instStride;
+    S.iBackPos = instBase + 3 * instStride; S.iLo = instBase + 4 * instStride;
+    S.iHi = instBase + 5 * instStride; S.iFlags = instBase + 6 * instStride;
+    S.iFrontDist = (int32_t*)(instBase + 7 * instStride); S.iBackDist = (int32_t*)(instBase + 8 * instStride);
     S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
     S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
-    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0;
+    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
     S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;
+    S.nFp = 0;
     LCB_WAVE_SYNC();
     if (NW > 1) {
         __syncthreads();           // the LDS tables and sArgs above are initialised
@@ -1279,6 +1364,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 if (lcb_rfl(S.mail[LCB_MAIL_CMD]) == LCB_CMD_EXIT) return;
                 S.T.used = sArgs.usedView;
                 const uint32_t flags = lcb_rfl(S.mail[LCB_MAIL_FLAGS]);
+                S.nTouch = lcb_rfl(S.mail[LCB_MAIL_NTOUCH]);
                 S.cWalk = 0;
                 lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
                                      (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW);
@@ -1287,7 +1373,13 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                     if (S.lane == 0 && w) atomicAdd(S.mailWalk, w);
                 }
                 __syncthreads();                                   // B
-                lcb_vote_reduce_slice<NW>(S, (flags & 1u) != 0, (flags & 4u) != 0, waveId);   // contains barrier C
+                if (flags & 8u) {
+                    // a vote with many voters is reduced and cleared by everyone (wave 0 resets the counter only after barrier D)
+                    uint32_t nTouched = lcb_rfl(*S.vNClaimed);
+                    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
+                    if (nTouched > claimCap) nTouched = claimCap;
+                    lcb_vote_reduce_slice<NW>(S, (flags & 1u) != 0, (flags & 4u) != 0, waveId, nTouched);   // contains barriers C and D
+                }
             }
         }
     } else LCB_WAVE_SYNC();
@@ -1341,24 +1433,22 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
             else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
         }
-        uint64_t c[6];
+        // (no local arrays here: the compiler would move them to LDS, 48 B x every lane of the workgroup)
+        uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
         if (STATS) {
-            c[0] = (uint64_t)lcb_wave_sum((int64_t)S.cWalk); c[1] = (uint64_t)lcb_wave_sum((int64_t)S.cOcc);
-            c[2] = (uint64_t)lcb_wave_sum((int64_t)S.cCompatCall); c[3] = (uint64_t)lcb_wave_sum((int64_t)S.cCompatStep);
-            c[4] = (uint64_t)lcb_wave_sum((int64_t)S.cVote); c[5] = (uint64_t)lcb_wave_sum((int64_t)S.cPush);
+            c0 = (uint64_t)lcb_wave_sum((int64_t)S.cWalk); c1 = (uint64_t)lcb_wave_sum((int64_t)S.cOcc);
+            c2 = (uint64_t)lcb_wave_sum((int64_t)S.cCompatCall); c3 = (uint64_t)lcb_wave_sum((int64_t)S.cCompatStep);
+            c4 = (uint64_t)lcb_wave_sum((int64_t)S.cVote); c5 = (uint64_t)lcb_wave_sum((int64_t)S.cPush);
         }
         if (S.lane == 0) {
-            LcbSeedOut o;
-            o.nInst = n;   // kept on ARENA_OVF so the host can track the allocator
-            o.status = S.status; o.bestScore = bestScore; o.arenaOff = off;
-            o.fpOff = fpo; o.nFp = nfp; o.pad = 0;
-            sArgs.out[s] = o;
+            LcbSeedOut* o = sArgs.out + s;
+            o->nInst = n;   // kept on ARENA_OVF so the host can track the allocator
+            o->status = S.status; o->bestScore = bestScore; o->arenaOff = off;
+            o->fpOff = fpo; o->nFp = nfp; o->pad = 0;
             if ((STATS || PROF) && sArgs.ctr) {
-                LcbSeedCtr k;
-                for (int q = 0; q < 8; q++) k.c[q] = 0;
-                if (!STATS && PROF) { k.c[0] = ticks; k.c[1] = S.pfPush; k.c[2] = S.pfVote; k.c[3] = S.pfMaxProbe; k.c[4] = S.pfMaxInst; k.c[5] = S.pfTVote; k.c[6] = S.pfTPush; k.c[7] = S.pfTScore; }
-                if (STATS) { k.c[0] = c[0]; k.c[1] = c[1]; k.c[2] = c[2]; k.c[3] = c[3]; k.c[4] = o.nInst; k.c[5] = c[4]; k.c[6] = c[5]; k.c[7] = 1; }
-                sArgs.ctr[s] = k;
+                uint64_t* k = sArgs.ctr[s].c;
+                if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }
+                else { k[0] = ticks; k[1] = S.pfPush; k[2] = S.pfVote; k[3] = S.pfMaxProbe; k[4] = S.pfMaxInst; k[5] = S.pfTVote; k[6] = S.pfTPush; k[7] = S.pfTScore; }
             }
         }
         LCB_MARK(S, 2, 6);

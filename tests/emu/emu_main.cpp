@@ -62,7 +62,7 @@ struct Emu {
     lcb_counters ctr{};
     uint64_t launches = 0, criticalPushes = 0, totalPushes = 0, firstPushes = 0;   // sum over launches of the largest per-seed push count
 
-    Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode == 2)
+    Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode >= 2)
     {
         chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
         usedWords = g->nPos() / 32 + 2;
@@ -80,13 +80,16 @@ struct Emu {
         ctx.resize((size_t)nThreads);
         for (auto& c : ctx) {
             LcbWork& W = c.W;
-            W.pathCap = 65536; W.bodyCap = 32768; W.bestCap = big ? 8192 : (mode == 1 ? LCB_IC_MEDIUM : LCB_IC_SMALL); W.instCap = big ? 8192 : 0; W.voteCap = big ? 65536 : 0;
+            // capacities as the product's device.hip chooses them per kernel variant (compact / wide / big / huge)
+            W.pathCap = 65536; W.bodyCap = 32768;
+            W.bestCap = mode == 0 ? LcbCfg<0>::IC : (mode == 1 ? LcbCfg<1>::IC : (mode == 2 ? LcbCfg<2>::IC : 8192));
+            W.instCap = mode == 2 ? LcbCfg<2>::IC : (mode == 3 ? 8192 : 0); W.voteCap = mode == 3 ? 65536 : 0;
             W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr;
             LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
             c.slot.assign(L.total, 0);
             int32_t* pk = (int32_t*)(c.slot.data() + L.pKeys);
             for (uint32_t i = 0; i < W.pathCap; i++) pk[i] = LCB_EMPTY_KEY;
-            if (big) { int32_t* vk = (int32_t*)(c.slot.data() + L.vKey); for (uint32_t i = 0; i < W.voteCap; i++) vk[i] = LCB_EMPTY_KEY; }
+            if (mode == 3) { int32_t* vk = (int32_t*)(c.slot.data() + L.vKey); for (uint32_t i = 0; i < W.voteCap; i++) vk[i] = LCB_EMPTY_KEY; }
             W.base = c.slot.data(); W.slotBytes = L.total;
             W.dbg = nullptr; W.cursor = &c.cursor[0]; W.arenaCursor = (unsigned long long*)&c.cursor[2];
             c.arena.resize(1 << 18);
@@ -127,18 +130,28 @@ struct Emu {
         LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); uint2* fa = c.fpArena.data();
         const size_t arc = c.arena.size(), fac = c.fpArena.size();
         const bool noStats = getenv("EMU_NOSTATS") != nullptr;     // the shipped instantiation (checkpointed replay, no event counters)
-        if (noStats && nw == 16 && mode == 1) emu_run_block(0, 16, [&]() { lcb_process_body<1, false, 16, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats && nw == 8 && mode == 2) emu_run_block(0, 8, [&]() { lcb_process_body<2, false, 8, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats && mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats && mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (noStats) emu_run_wave(0, [&]() { lcb_process_body<0, false, 1, true>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (nw == 4 && mode == 0) emu_run_block(0, 4, [&]() { lcb_process_body<0, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (nw == 4 && mode == 2) emu_run_block(0, 4, [&]() { lcb_process_body<2, true, 4, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (nw == 8 && mode == 1) emu_run_block(0, 8, [&]() { lcb_process_body<1, true, 8, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (nw == 16 && mode == 1) emu_run_block(0, 16, [&]() { lcb_process_body<1, true, 16, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (mode == 2) emu_run_wave(0, [&]() { lcb_process_body<2, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else if (mode == 1) emu_run_wave(0, [&]() { lcb_process_body<1, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
-        else emu_run_wave(0, [&]() { lcb_process_body<0, true, 1, false>(T, KP, sp, n, W, op, ar, arc, fa, fac); });
+#define EMU_RUN(M, ST, NW_, PF) do { if ((NW_) == 1) emu_run_wave(0, [&]() { lcb_process_body<M, ST, 1, PF>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); \
+                                       else emu_run_block(0, NW_, [&]() { lcb_process_body<M, ST, NW_, PF>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); } while (0)
+        // non-stats = the shipped code path (checkpointed replay, dead-seed early-out); the instrumented variant supplies push counts
+        if (noStats && mode == 0 && nw == 1) EMU_RUN(0, false, 1, true);
+        else if (noStats && mode == 0 && nw == 2) EMU_RUN(0, false, 2, true);
+        else if (noStats && mode == 1 && nw == 1) EMU_RUN(1, false, 1, true);
+        else if (noStats && mode == 1 && nw == 16) EMU_RUN(1, false, 16, true);
+        else if (noStats && mode == 2 && nw == 1) EMU_RUN(2, false, 1, true);
+        else if (noStats && mode == 2 && nw == 8) EMU_RUN(2, false, 8, true);
+        else if (noStats && mode == 3 && nw == 1) EMU_RUN(3, false, 1, true);
+        else if (noStats && mode == 3 && nw == 8) EMU_RUN(3, false, 8, true);
+        else if (!noStats && mode == 0 && nw == 1) EMU_RUN(0, true, 1, false);
+        else if (!noStats && mode == 0 && nw == 4) EMU_RUN(0, true, 4, false);
+        else if (!noStats && mode == 1 && nw == 1) EMU_RUN(1, true, 1, false);
+        else if (!noStats && mode == 1 && nw == 8) EMU_RUN(1, true, 8, false);
+        else if (!noStats && mode == 1 && nw == 16) EMU_RUN(1, true, 16, false);
+        else if (!noStats && mode == 2 && nw == 1) EMU_RUN(2, true, 1, false);
+        else if (!noStats && mode == 2 && nw == 4) EMU_RUN(2, true, 4, false);
+        else if (!noStats && mode == 3 && nw == 1) EMU_RUN(3, true, 1, false);
+        else if (!noStats && mode == 3 && nw == 4) EMU_RUN(3, true, 4, false);
+        else { fprintf(stderr, "emu: no instantiation for mode %d, EMU_NW=%d, %s\n", mode, nw, noStats ? "no stats" : "stats"); exit(2); }
+#undef EMU_RUN
     }
 
     // runs the process kernel over the seeds: each host thread emulates ONE wavefront over its share of the seeds
@@ -194,7 +207,7 @@ struct Emu {
         run(seeds);
         std::vector<size_t> again;
         for (size_t i = 0; i < out.size(); i++) if (out[i].status >= LCB_ST_INST_OVF && out[i].status <= LCB_ST_BEST_OVF) again.push_back(i);
-        if (again.empty() || mode >= 2) return;
+        if (again.empty() || mode >= 3) return;
         if (!next) next.reset(new Emu(g, p, mode + 1));
         next->used = used; next->T.used = next->used.data(); next->nViewsAlloc = nViewsAlloc;
         std::vector<LcbKSeed> sub;
@@ -279,8 +292,8 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < id.size(); i++)
                 if (g->posId[g->chrStart[c] + i] != id[i] || g->posPos[g->chrStart[c] + i] != pos[i]) { fprintf(stderr, "FAIL: table differs\n"); return 1; }
         }
-        Emu emu(g, p, mode == "big" ? 2 : (mode == "medium" ? 1 : 0));
-        if (mode == "seeds-init" || mode == "seeds-final" || mode == "big" || mode == "medium") {
+        Emu emu(g, p, mode == "huge" ? 3 : (mode == "big" ? 2 : (mode == "medium" ? 1 : 0)));
+        if (mode == "seeds-init" || mode == "seeds-final" || mode == "big" || mode == "medium" || mode == "huge") {
             orc_counters octr; memset(&octr, 0, sizeof(octr));
             if (mode == "seeds-final") {
                 orc_block* ob = nullptr; orc_stats st;

@@ -59,10 +59,11 @@ def test_per_seed_parity_final_state(built, case):
     _compare_all(case, st, dev, orc, st.seeds(4), "final state")
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_each_kernel_variant_parity(built, case, mode):
     """Every seed through ONE kernel variant (1 compact: one wavefront per seed; 2 wide: 16 wavefronts share the votes;
-    3 big: per-path state in the global-memory workspace), checked by the per-variant seed counters."""
+    3 big: index and vote table in LDS, instance fields in HBM; 4 huge: all per-path state in the global-memory workspace),
+    checked by the per-variant seed counters."""
     st, p, dev = _setup(case, start_mode=mode)
     orc = Oracle(case.graph, [case.fasta], case.k, case.a)
     seeds = st.seeds(4)
@@ -74,7 +75,7 @@ def test_each_kernel_variant_parity(built, case, mode):
 
 def test_overflow_chain_reaches_big_mode(built, case):
     """Tiny path sets in the compact AND the wide slots: every seed that pushes more than a few vertices overflows twice and
-    ends in the big (global-memory) variant; results are the oracle's."""
+    ends in the big variant; results are the oracle's."""
     st, p, dev = _setup(case, path_cap=16, wide_path_cap=16, start_mode=1)
     orc = Oracle(case.graph, [case.fasta], case.k, case.a)
     seeds = st.seeds(4)[:600]

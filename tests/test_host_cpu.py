@@ -129,11 +129,12 @@ def test_cli_usage_errors(built, case, tmp_path):
 
 
 EMU = os.path.join(ROOT, "tests", "emu", "build", "emu_check")
+EMU_SHARE = os.path.join(ROOT, "tests", "emu", "build", "emu_check_share8")   # tiny LCB_VOTE_SHARE_MIN: all-waves reduce/clear path
 
 
 @pytest.fixture(scope="session")
 def emu_built():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "all"])
     return EMU
 
 
@@ -141,15 +142,25 @@ def emu_built():
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
                                             # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
                                             ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1"}),
+                                            # every kernel variant: wide (LDS path set), big (index in LDS, fields in the workspace), huge (all in the workspace)
+                                            ("twogenomes", "medium", {}), ("twogenomes", "big", {}), ("inv_k25", "big", {"EMU_NOSTATS": "1"}),
+                                            ("twogenomes", "huge", {}), ("inv_k25", "huge", {"EMU_NOSTATS": "1"}),
+                                            # helper wavefronts: the heaviest seeds with 16 / 8 / 4 wavefronts per workgroup, both vote protocols
+                                            ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200"}),
+                                            ("inv_k25", "medium", {"EMU_NW": "16", "EMU_LIMIT": "120", "EMU_SHARE": "1"}),
+                                            ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SHARE": "1"}),
+                                            ("inv_k25", "huge", {"EMU_NW": "4", "EMU_LIMIT": "200"}),
+                                            ("collinear6", "seeds-init", {"EMU_NW": "4", "EMU_LIMIT": "100", "EMU_SHARE": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
-                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "0", "LCB_MAX_JOBS": "8"}),
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
 def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode, env, tmp_path):
     """The unmodified device code of lcb_kernel.h on the CPU wavefront emulator (tests/emu) vs the oracle: per-seed results,
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
     from tests.conftest import Case
     c = Case(name, case_dir)
-    r = subprocess.run([emu_built, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
+    exe = EMU_SHARE if env.get("EMU_SHARE") else emu_built
+    r = subprocess.run([exe, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
                        env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
     if mode == "find":
