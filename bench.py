@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — seed vertices/sec through the MI355X block finder (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ecoli10]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ecoli62|ecoli10|...]
 
 A "step" is one full pass of the hot path over the workload's sorted seed list: BlocksFinder::FindBlocks' phase loop
-(every seed through the per-seed HIP kernel, ordered commit, GPU re-processing of conflicts) with the junction tables
-already resident in HBM. value = seeds / step time (whole job over all GPUs). Workload (configs[1] of BASELINE.json):
-"10 E. coli strains (~50 Mbp), k=15, a=150" restated as the synthetic pangenome of SURVEY.md §8d (no genomes and no
-network here): generated by lcb-synth (seed 1001) + lcb-mkgraph, untimed.
+(every seed through the per-seed HIP kernels, ordered commit, GPU re-processing of conflicts) with the junction tables
+already resident in HBM. value = seeds / step time (whole job over all GPUs).
+
+Workload at N = 1: the largest single-GPU configuration of BASELINE.json, configs[2] "62 E. coli strains, k=15", restated
+as the synthetic pangenome of SURVEY.md §8d at its stated size (62 strains, 281 Mbp, lcb-synth seed 1002 + lcb-mkgraph,
+untimed; there are no genomes and no network here). `--workload ecoli10` is configs[1] (10 strains, 45 Mbp).
 
 The JSON line also carries
-  roofline      algorithmic bytes (SURVEY.md §8d formula over reference-semantics event counters, counted by the
-                kernel itself in a separate stats-mode pass) / hipEvent-timed kernel time, against the 8 TB/s HBM peak;
-  cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container)
-                timed on this box's host cores on the same workload, banner to banner, and an md5 check that its
-                blocks_coords.gff equals ours.
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); see sibeliaz_amd/parallel.py.
+  roofline      the process kernels (lcb_process_kernel, all variants): ALGORITHMIC bytes per launch (SURVEY.md §8d formula
+                over the reference-semantics event counters, counted by the kernels themselves in one untimed stats-mode pass of
+                the engine) / average launch duration, measured in this run with HIP events on the kernels' stream; against the
+                8 TB/s HBM peak, with this GPU's measured STREAM-triad rate beside it. `traffic` (PMC) is not measured inside
+                this run: null here, the rocprofv3 --pmc summaries are committed under profiles/.
+  cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container) timed
+                on this box's host cores on a BOUNDED sample of the same workload (same generator and parameters, 1/10 of
+                the ancestor's segments; 1/40 for the single-thread run): -t 1, -t 32 (the cap of the reference's wrapper
+                script, sibeliaz:139) and -t 64, median of 3, banner to banner; plus an md5 check of its GFF against ours
+                on the sample. `--full-cpu-baseline` times it on the whole workload instead (minutes).
+  wall_clock    metric part 2: the whole sibeliaz-lcb process (load, seeds, upload, phase loop, GFF) on the workload.
+For N > 1 launch with torch.distributed.run (one rank per GPU): torch only ships the RCCL unique id and takes the
+max of the step times; the all-gathers of the engine are ncclAllGather calls inside the C++ library (csrc/comm.hip).
 """
 import argparse
 import hashlib
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -29,33 +39,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "sibeliaz_amd", "bin")
 
+_COMMON = ("--keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 --indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 "
+           "--repeat-families 3 --repeat-copies 10 --repeat-len 800 --seg-min 500 --seg-max 8000 ")
+
+
+def _wl(strains, segments, seed, desc, k=15, b=200, m=50, a=150):
+    return dict(synth="--strains %d --segments %d %s--seed %d" % (strains, segments, _COMMON, seed), k=k, b=b, m=m, a=a, desc=desc)
+
+
 WORKLOADS = {
-    # SURVEY.md §8d config 2
-    "ecoli10": dict(synth="--strains 10 --segments 1200 --seg-min 500 --seg-max 8000 --keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 "
-                          "--indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 3 --repeat-copies 10 "
-                          "--repeat-len 800 --seed 1001", k=15, b=200, m=50, a=150,
-                    desc="10 synthetic E. coli-like strains (~45 Mbp), k=15, b=200, m=50, a=150"),
     # SURVEY.md §8d config 3 at its stated size: 62 strains x ~4.5 Mbp = 281 Mbp, seed 1002
-    "ecoli62": dict(synth="--strains 62 --segments 1200 --seg-min 500 --seg-max 8000 --keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 "
-                          "--indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 3 --repeat-copies 10 "
-                          "--repeat-len 800 --seed 1002", k=15, b=200, m=50, a=150,
-                    desc="62 synthetic E. coli-like strains (~281 Mbp), k=15, b=200, m=50, a=150"),
-    # SURVEY.md §8d config 3 shape (62 strains, seed 1002), scaled to ~32 Mbp so the reference finishes in about a minute
-    "ecoli62_small": dict(synth="--strains 62 --segments 120 --seg-min 500 --seg-max 8000 --keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 "
-                                "--indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 3 --repeat-copies 10 "
-                                "--repeat-len 800 --seed 1002", k=15, b=200, m=50, a=150,
-                          desc="62 synthetic strains (~32 Mbp), k=15, b=200, m=50, a=150"),
-    # same genomes, other parameters (k=25, b=400, m=100): a second full-size md5 check against the reference
-    "ecoli10_k25": dict(synth="--strains 10 --segments 1200 --seg-min 500 --seg-max 8000 --keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 "
-                              "--indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 3 --repeat-copies 10 "
-                              "--repeat-len 800 --seed 1001", k=25, b=400, m=100, a=150,
-                        desc="10 synthetic E. coli-like strains (~45 Mbp), k=25, b=400, m=100, a=150"),
-    # small variant for quick checks
-    "ecoli10_small": dict(synth="--strains 10 --segments 120 --seg-min 500 --seg-max 8000 --keep 0.8 --swap 0.05 --invert 0.10 --sub 0.02 "
-                                "--indel 0.002 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 3 --repeat-copies 10 "
-                                "--repeat-len 800 --seed 1001", k=15, b=200, m=50, a=150,
-                          desc="10 synthetic strains (~4.5 Mbp), k=15, b=200, m=50, a=150"),
+    "ecoli62": _wl(62, 1200, 1002, "62 synthetic E. coli-like strains (281 Mbp), k=15, b=200, m=50, a=150 [BASELINE configs[2]; SURVEY.md §8d config 3, lcb-synth seed 1002]"),
+    # bounded samples of it for the CPU baseline: same generator and parameters, 1/10 and 1/40 of the ancestor's segments
+    "ecoli62_small": _wl(62, 120, 1002, "62 synthetic strains (32 Mbp: config 3 with 1/10 of the segments), k=15, b=200, m=50, a=150"),
+    "ecoli62_tiny": _wl(62, 30, 1002, "62 synthetic strains (8 Mbp: config 3 with 1/40 of the segments), k=15, b=200, m=50, a=150"),
+    # SURVEY.md §8d config 2
+    "ecoli10": _wl(10, 1200, 1001, "10 synthetic E. coli-like strains (45 Mbp), k=15, b=200, m=50, a=150 [BASELINE configs[1]; SURVEY.md §8d config 2, lcb-synth seed 1001]"),
+    "ecoli10_small": _wl(10, 120, 1001, "10 synthetic strains (4.5 Mbp: config 2 with 1/10 of the segments), k=15, b=200, m=50, a=150"),
+    "ecoli10_tiny": _wl(10, 30, 1001, "10 synthetic strains (1.1 Mbp), k=15, b=200, m=50, a=150"),
+    # same genomes as config 2, other parameters (k=25, b=400, m=100)
+    "ecoli10_k25": _wl(10, 1200, 1001, "10 synthetic E. coli-like strains (45 Mbp), k=25, b=400, m=100, a=150", k=25, b=400, m=100),
 }
+SAMPLES = {"ecoli62": ("ecoli62_small", "ecoli62_tiny"), "ecoli10": ("ecoli10", "ecoli10_small"), "ecoli10_k25": ("ecoli10_k25", "ecoli10_small")}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
@@ -74,7 +79,7 @@ def ensure_workload(name):
         subprocess.check_call([os.path.join(BIN, "lcb-mkgraph"), "-k", str(w["k"]), "-o", gr, fa], stderr=subprocess.DEVNULL)
         open(gr + ".ok", "w").write("ok")
         log("bench: generated workload %s in %.1fs" % (name, time.time() - t))
-    return dict(w, fasta=fa, graph=gr, dir=d)
+    return dict(w, name=name, fasta=fa, graph=gr, dir=d)
 
 
 def md5(path):
@@ -85,48 +90,83 @@ def md5(path):
     return h.hexdigest()
 
 
-def cpu_baseline(w, n_seeds, our_gff):
-    """The unmodified reference on this box's host cores, same workload, banner-to-banner analyze time."""
+def run_reference(w, threads, tag):
+    """One run of the unmodified reference: (analyze seconds banner to banner, whole-process seconds, gff path) or None."""
     ref = os.path.join(ROOT, "oracle", "_ref", "sibeliaz-lcb-ref")
-    cores = min(64, os.cpu_count() or 1)
-    out = os.path.join(w["dir"], "ref_out")
-    if os.path.exists(ref):
-        cmd = [ref, "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]), "-a", str(w["a"]), "-t", str(cores),
-               "-o", out, "--noseq"]
-        t0 = time.time()
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=0)
-        marks = {}
-        buf = ""
-        while True:
-            ch = p.stdout.read(1)
-            if not ch:
-                break
-            buf += ch
-            if ch == "\n":
-                for key in ("Analyzing the graph...", "Generating the output..."):
-                    if key in buf and key not in marks:
-                        marks[key] = time.time()
-                buf = ""
-        p.wait()
-        wall = time.time() - t0
-        if p.returncode != 0 or len(marks) < 2:
-            return None
-        analyze = marks["Generating the output..."] - marks["Analyzing the graph..."]
-        same = our_gff is not None and md5(os.path.join(out, "blocks_coords.gff")) == md5(our_gff)
-        return {"value": n_seeds / analyze, "unit": "seeds/s", "cores": cores, "kind": "reference",
-                "sample": "full workload (%s), reference sibeliaz-lcb -t %d, 'Analyzing' to 'Generating' banner %.2fs (includes its serial seed "
-                          "enumeration), whole process %.2fs" % (w["desc"], cores, analyze, wall),
-                "analyze_s": analyze, "wall_s": wall, "gff_md5_equal": bool(same)}
-    port = os.path.join(ROOT, "oracle", "lcb_oracle")
-    if os.path.exists(port):
-        r = subprocess.run([port, "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]), "-a", str(w["a"]),
-                            "-o", out], capture_output=True, text=True)
-        for tok in r.stderr.split():
-            if tok.startswith("seeds_per_s="):
-                same = our_gff is not None and md5(os.path.join(out, "blocks_coords.gff")) == md5(our_gff)
-                return {"value": float(tok.split("=")[1]), "unit": "seeds/s", "cores": 1, "kind": "port",
-                        "sample": "full workload (%s), oracle/lcb_oracle single thread" % w["desc"], "gff_md5_equal": bool(same)}
-    return None
+    if not os.path.exists(ref):
+        return None
+    out = os.path.join(w["dir"], "ref_out_%s" % tag)
+    cmd = [ref, "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]), "-a", str(w["a"]), "-t", str(threads),
+           "-o", out, "--noseq"]
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=0)
+    marks, buf = {}, ""
+    while True:
+        ch = p.stdout.read(1)
+        if not ch:
+            break
+        buf += ch
+        if ch == "\n":
+            for key in ("Analyzing the graph...", "Generating the output..."):
+                if key in buf and key not in marks:
+                    marks[key] = time.time()
+            buf = ""
+    p.wait()
+    wall = time.time() - t0
+    if p.returncode != 0 or len(marks) < 2:
+        return None
+    return marks["Generating the output..."] - marks["Analyzing the graph..."], wall, os.path.join(out, "blocks_coords.gff")
+
+
+def n_seeds_of(w, threads):
+    import sibeliaz_amd
+    st = sibeliaz_amd.JunctionStorage(w["graph"], [w["fasta"]], w["k"], threads=threads, abundance=w["a"])
+    n = len(st.seeds(threads))
+    st.close()
+    return n
+
+
+def our_gff(w, threads, dev_ordinal=0):
+    import sibeliaz_amd
+    st = sibeliaz_amd.JunctionStorage(w["graph"], [w["fasta"]], w["k"], threads=threads, abundance=w["a"])
+    p = sibeliaz_amd.Params.make(w["k"], b=w["b"], m=w["m"])
+    dev = sibeliaz_amd.Device(st, p, dev_ordinal)
+    f = sibeliaz_amd.BlocksFinder(st, w["k"])
+    f.FindBlocks(w["m"], w["b"], device=dev, threads=threads)
+    out = os.path.join(w["dir"], "gpu_out")
+    f.GenerateOutput(out)
+    dev.close()
+    st.close()
+    return os.path.join(out, "blocks_coords.gff")
+
+
+def cpu_baseline(workload, threads, full):
+    """SURVEY.md §8d protocol on a bounded sample: -t 1 / -t 32 / -t 64, median of 3, analyze time banner to banner."""
+    host = os.cpu_count() or 1
+    big_name, tiny_name = (workload, SAMPLES[workload][0]) if full else SAMPLES[workload]
+    big, tiny = ensure_workload(big_name), ensure_workload(tiny_name)
+    s_big, s_tiny = n_seeds_of(big, threads), n_seeds_of(tiny, threads)
+    per_t = {}
+    gff_ref = None
+    for t, w, s in ((1, tiny, s_tiny), (min(32, host), big, s_big), (min(64, host), big, s_big)):
+        runs = []
+        for rep in range(1 if (full and t > 1) else 3):
+            r = run_reference(w, t, "t%d" % t)
+            if r is None:
+                return None
+            runs.append(r)
+            if w is big:
+                gff_ref = r[2]
+        an = statistics.median(x[0] for x in runs)
+        per_t[str(t)] = {"seeds_per_s": s / an, "analyze_s_median": an, "wall_s_median": statistics.median(x[1] for x in runs), "runs": len(runs),
+                         "sample": w["desc"], "sample_seeds": s}
+    same = md5(gff_ref) == md5(our_gff(big, threads)) if gff_ref else False
+    top = per_t[str(min(64, host))]
+    return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": min(64, host), "kind": "reference",
+            "sample": "%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %d, median of %d run(s), 'Analyzing' to 'Generating' banner "
+                      "%.2f s (includes its serial seed enumeration); host has %d hardware threads" % (big["desc"], min(64, host), top["runs"], top["analyze_s_median"], host),
+            "threads": per_t, "gff_md5_equal_on_sample": bool(same),
+            "note": "-t 1 is timed on the smaller sample named in threads['1']; the reference's own wrapper caps -t at 32 (sibeliaz:139)"}
 
 
 def algorithmic_bytes(c):
@@ -137,11 +177,13 @@ def algorithmic_bytes(c):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ecoli10")
+    ap.add_argument("--workload", default="ecoli62")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true", help="time the reference on the whole workload (minutes) instead of the bounded sample")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     args = ap.parse_args()
 
@@ -154,28 +196,18 @@ def main():
             sys.exit(2)
 
     import sibeliaz_amd
-    from sibeliaz_amd import parallel
 
     dist = torch = None
-    tdev = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        backend = os.environ.get("LCB_BENCH_BACKEND", "nccl")      # "gloo" lets the multi-rank path be exercised on a 1-GPU box
-        if os.environ.get("LCB_BENCH_SAME_GPU"):
-            local_rank = 0
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            tdev = torch.device("cuda", local_rank)
-        else:
-            dist.init_process_group(backend)
-            tdev = torch.device("cpu")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if rank == 0:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "sibeliaz_amd", "build.py"), "tools", "lib"], stdout=subprocess.DEVNULL)
-        w = ensure_workload(args.workload)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "sibeliaz_amd", "build.py"), "tools", "lib", "cli"], stdout=subprocess.DEVNULL)
+        ensure_workload(args.workload)
     if world > 1:
         dist.barrier()
     w = ensure_workload(args.workload)
@@ -187,18 +219,24 @@ def main():
     seeds = storage.seeds(args.threads)
     t_seeds = time.time() - t
     params = sibeliaz_amd.Params.make(w["k"], b=w["b"], m=w["m"])
+    t = time.time()
     dev = sibeliaz_amd.Device(storage, params, local_rank)          # tables now resident in HBM
+    t_upload = time.time() - t
     S = len(seeds)
-    log("bench[%d]: P=%d V=%d S=%d load %.2fs seeds %.2fs" % (rank, storage.n_positions(), storage.GetVerticesNumber(), S, t_load, t_seeds))
+    log("bench[%d]: P=%d V=%d S=%d load %.2fs seeds %.2fs upload %.2fs" % (rank, storage.n_positions(), storage.GetVerticesNumber(), S, t_load, t_seeds, t_upload))
+
+    comm = None
+    if world > 1:
+        # the only use of torch in the multi-rank path: ship rank 0's RCCL unique id; the engine's all-gathers are native
+        box = [sibeliaz_amd.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = sibeliaz_amd.Comm(dev, box[0], rank, world)
 
     finder = sibeliaz_amd.BlocksFinder(storage, w["k"])
 
     def step():
-        if world == 1:
-            finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds)
-            return finder.blocks, dict(finder.stats)
-        blocks, st = parallel.find_blocks_distributed(finder, w["m"], w["b"], seeds, dev, tensor_device=tdev)
-        return blocks, dict(st)
+        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm)
+        return finder.blocks, dict(finder.stats)
 
     def sync():
         if world > 1:
@@ -211,20 +249,19 @@ def main():
     sync()
     t0 = time.time()
     last = None
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, process_ms, plan_ms = 0.0, 0, 0.0, 0.0
     for _ in range(args.steps):
         last = step()
         kernel_ms += last[1]["kernel_ms"]    # the native engine reports (and resets) this rank's hipEvent totals per call
         launches += last[1]["launches"]
+        process_ms += last[1]["process_ms"]
+        plan_ms += last[1]["plan_ms"]
     sync()
     elapsed = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        ksum = torch.tensor([kernel_ms, float(launches)], dtype=torch.float64, device=tdev)
-        dist.all_reduce(ksum, op=dist.ReduceOp.MAX)
-        kernel_ms, launches = float(ksum[0].item()), int(ksum[1].item())
+        tmax = torch.tensor([elapsed, kernel_ms, float(launches)], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, kernel_ms, launches = float(tmax[0].item()), float(tmax[1].item()), int(tmax[2].item())
 
     if rank == 0:
         blocks, st = last
@@ -235,68 +272,69 @@ def main():
         finder.params = params
         finder.GenerateOutput(out_dir, blocks=blocks, blocks_found=int(st["blocks_found"]))
         gff = os.path.join(out_dir, "blocks_coords.gff")
-        # algorithmic bytes: one untimed pass in stats mode (event counters are a property of input + parameters)
+        # algorithmic bytes: one untimed pass of the engine in stats mode; the engine sums the event counters of exactly the
+        # Process() calls the reference makes (phase-start result of every seed + re-processing of every conflict)
         ctr_file = os.path.join(w["dir"], "counters.json")
-        if args.no_roofline:
-            ctr = {k: 0 for k in sibeliaz_amd.api.COUNTER_NAMES}
-        elif os.path.exists(ctr_file):
-            ctr = json.load(open(ctr_file))
-        else:
-            dev.set_stats_mode(True)
-            committer = sibeliaz_amd.Committer(storage, params)
-            dev.reset_used()
-            ctr = {k: 0 for k in sibeliaz_amd.api.COUNTER_NAMES}
-
-            def redo(seed):
-                marks = committer.take_marks()
-                if len(marks):
-                    dev.mark_used(marks)
-                _, inst, _, c = dev.process_seeds(seed, counters=True)
-                for k in ctr:
-                    ctr[k] += c[k]
-                return inst
-
-            for at in range(0, S, 256):
-                off, inst, _, c = dev.process_seeds(seeds[at:at + 256], counters=True)
-                for k in ctr:
-                    ctr[k] += c[k]
-                committer.commit_phase(seeds[at:at + 256], off, inst, redo)
-                marks = committer.take_marks()
-                if len(marks):
-                    dev.mark_used(marks)
-            dev.set_stats_mode(False)
-            json.dump(ctr, open(ctr_file, "w"))
-        abytes = algorithmic_bytes(ctr)
-        # HBM traffic is a PMC measurement (separate rocprofv3 passes, scripts/gpu_pmc.sh); the latest committed summary is quoted
-        traffic = None
-        for tfile in (os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")):
-            if os.path.exists(tfile) and args.workload == "ecoli10":
-                # bytes per pass from the PMC passes, over the launches of THIS run's passes
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_pass") / max(1.0, launches / float(args.steps))
-                break
+        ctr = None
+        if not args.no_roofline:
+            if os.path.exists(ctr_file):
+                ctr = json.load(open(ctr_file))
+            else:
+                t = time.time()
+                dev.set_stats_mode(True)
+                finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, count_events=1)
+                dev.set_stats_mode(False)
+                ctr = {k: int(finder.stats["ev_" + k]) for k in sibeliaz_amd.api.COUNTER_NAMES}
+                json.dump(ctr, open(ctr_file, "w"))
+                dev.kernel_time()
+                log("bench: stats-mode pass %.1fs: %s" % (time.time() - t, ctr))
+        abytes = algorithmic_bytes(ctr) if ctr else 0
         kernel_s_per_step = kernel_ms / 1000.0 / args.steps
+        lps = launches / float(args.steps)
         achieved = abytes / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+        triad = dev.hbm_triad()
         line = {
             "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": w["desc"] + (" [SURVEY.md §8d config 2, lcb-synth seed 1001]" if args.workload == "ecoli10" else " [lcb-synth: " + w["synth"] + "]"), "seeds": S, "junction_occurrences": storage.n_positions(),
-                       "vertices": storage.GetVerticesNumber(), "phase_size": 256, "parallelism": "1 seed per wavefront (+15 vote helper wavefronts); speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint validation; %d GPU(s)" % world,
+            "config": {"workload": w["desc"], "lcb_synth": w["synth"], "seeds": S, "junction_occurrences": storage.n_positions(),
+                       "vertices": storage.GetVerticesNumber(), "phase_size": 256,
+                       "parallelism": "one seed per workgroup: compact variant 1 wavefront x 6 per CU for launches of many seeds, wide variant 16 wavefronts sharing the votes "
+                                      "for launches of few; speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint "
+                                      "validation; %d GPU(s)%s" % (world, ", every launch dealt to the ranks, ncclAllGather of results" if world > 1 else ""),
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
-                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lcb_process_kernel", "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps,
-                         "launches_per_step": launches / args.steps, "bytes_per_seed": abytes / S,
-                         "algorithmic_bytes_per_launch": abytes / max(1.0, launches / args.steps)},
+                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]),
+                       "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())),
+                       "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
+                                            "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
+                       "untimed_s": {"load_graph": t_load, "enumerate_seeds": t_seeds, "create_device_upload_tables": t_upload}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "lcb_process_kernel (all variants)", "launches_per_step": lps,
+                         "algorithmic_bytes_per_launch": abytes / max(1.0, lps), "avg_launch_ms": kernel_ms / max(1, launches),
+                         "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps, "bytes_per_seed": abytes / S,
+                         "peak_measured_stream_triad": triad, "frac_of_measured_peak": achieved / triad if triad > 0 else None,
+                         "event_counts": ctr,
+                         "note": "latency-bound integer walk: a launch is as long as its longest seed; n_compat_step of the counting pass is an upper bound within 1% "
+                                 "(speculative results walk older bitmaps), everything else is exact"},
         }
+        dev.close()
+        if world == 1 and not args.no_cli:
+            # metric part 2: wall-clock of the whole drop-in process to blocks_coords.gff
+            cli_out = os.path.join(w["dir"], "cli_out")
+            t = time.time()
+            r = subprocess.run([os.path.join(BIN, "sibeliaz-lcb"), "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]),
+                                "-a", str(w["a"]), "-t", str(args.threads), "-o", cli_out, "--noseq"], capture_output=True, text=True)
+            line["wall_clock"] = {"sibeliaz_lcb_process_s": time.time() - t, "rc": r.returncode, "threads": args.threads,
+                                  "gff_md5_equal_to_timed_run": r.returncode == 0 and md5(os.path.join(cli_out, "blocks_coords.gff")) == md5(gff)}
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(w, S, gff)
+            cb = cpu_baseline(args.workload, args.threads, args.full_cpu_baseline)
             if cb:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:
+        comm.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -91,6 +91,8 @@ typedef struct {
     int64_t over_predicted;     /* validations that failed because a predicted mark did not come true */
     double process_ms;          /* wall time inside launches + result gathering (kernel_ms is the device part of it) */
     double plan_ms;             /* wall time of the dry runs */
+    lcb_counters events;        /* lcb_hooks.count_events: the reference-semantics event counts of the whole FindBlocks (phase-start
+                                   Process() of every seed + the re-Process() of every commit conflict), else zero */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -153,6 +155,8 @@ int lcb_device_set_stats_mode(lcb_device* d, int on);
  * capacity is then in offsets[n]). best_score and ctr may be NULL. */
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets,
                       lcb_instance* inst, uint64_t inst_cap, int64_t* best_score, lcb_counters* ctr);
+/* Measured HBM rate of this GPU: STREAM triad over three arrays of `bytes` each, GB/s (the roofline's measured peak). */
+int lcb_device_hbm_triad(lcb_device* d, uint64_t bytes, int reps, double* gb_per_s);
 /* hipEvent-timed duration (ms) and launch count of kernels since the last call (reset on read). */
 int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches);
 
@@ -205,9 +209,28 @@ typedef struct {
     int32_t max_jobs;           /* a dry run stops planning beyond this many jobs; default: the device's seeds in flight */
     int32_t predict_f;          /* how a dry run predicts the re-processed result of a conflicting seed: 1 nothing,
                                    2 the still-free instances of its phase-start result, 3 (default) a stale re-processed result if any, else as 2 */
+    int32_t exchange_always;    /* 1: a single rank still packs / all-gathers / unpacks every launch (tests of the exchange path) */
+    int32_t count_events;       /* 1: fill lcb_stats.events (the device must be in stats mode; one rank) */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
+
+/* ---- multi-GPU: launches of the round engine dealt to one rank per MI355X, per-seed results and footprints all-gathered
+ * with RCCL (ncclAllGather over xGMI) from the C++ host; every rank runs the identical ordered commit and returns the same
+ * blocks. The reference has no counterpart (OpenMP only); tables and the `used` bitmap are replicated per GPU. */
+typedef struct lcb_comm lcb_comm;
+#define LCB_COMM_ID_BYTES 128
+/* One process per GPU: rank 0 calls lcb_comm_unique_id and ships the bytes to the other ranks (MPI, torch.distributed,
+ * a file ...); then every rank creates its communicator on its device (collective: ncclCommInitRank). */
+int lcb_comm_unique_id(unsigned char id[LCB_COMM_ID_BYTES]);
+lcb_comm* lcb_comm_create(lcb_device* d, const unsigned char id[LCB_COMM_ID_BYTES], int rank, int world);
+void lcb_comm_destroy(lcb_comm* c);
+/* lcb_find_blocks_ex on rank c->rank of c->world; hooks (may be NULL) only supplies the engine tuning fields. */
+int lcb_find_blocks_comm(const lcb_graph* g, lcb_device* d, lcb_comm* c, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
+                         const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
+/* One process, one host thread + device per listed GPU (what `sibeliaz-lcb` does with LCB_GPUS=N). */
+int lcb_find_blocks_gpus(const lcb_graph* g, const int* device_ordinals, int n_devices, const lcb_params* p, const lcb_device_opts* opts,
+                         const lcb_seed* seeds, int64_t n_seeds, const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
 
 /* ---- GenerateOutput (blocksfinder.h:605-670): trimming, blocks_coords.gff (blocksfinder.cpp:141-174) and,
  * if gen_seq, the <out_dir>/<i>.tmp chunk files (blocksfinder.h:533-582). */

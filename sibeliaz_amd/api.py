@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
-                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)]
+                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -51,10 +51,10 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32)]
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events")
 
 
 class DeviceOpts(C.Structure):
@@ -78,10 +78,10 @@ EXPORTS = [
     "lcb_last_error", "lcb_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
     "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
     "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
-    "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
+    "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
     "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
-    "lcb_generate_output",
+    "lcb_generate_output", "lcb_comm_unique_id", "lcb_comm_create", "lcb_comm_destroy", "lcb_find_blocks_comm", "lcb_find_blocks_gpus",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library():
     L.lcb_device_set_used.argtypes = [vp, vp, i64]
     L.lcb_device_set_stats_mode.argtypes = [vp, C.c_int]
     L.lcb_process_seeds.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, C.POINTER(Counters)]
+    L.lcb_device_hbm_triad.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.lcb_device_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.lcb_committer_create.restype = vp
     L.lcb_committer_create.argtypes = [vp, C.POINTER(Params)]
@@ -146,6 +147,13 @@ def load_library():
     L.lcb_committer_used_words.argtypes = [vp, C.POINTER(i64)]
     L.lcb_find_blocks.argtypes = [vp, vp, C.POINTER(Params), vp, i64, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
     L.lcb_find_blocks_ex.argtypes = [vp, vp, C.POINTER(Params), vp, i64, C.POINTER(Hooks), C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
+    L.lcb_comm_unique_id.argtypes = [vp]
+    L.lcb_comm_create.restype = vp
+    L.lcb_comm_create.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.lcb_comm_destroy.argtypes = [vp]
+    L.lcb_find_blocks_comm.argtypes = [vp, vp, vp, C.POINTER(Params), vp, i64, C.POINTER(Hooks), C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
+    L.lcb_find_blocks_gpus.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.POINTER(Params), C.POINTER(DeviceOpts), vp, i64, C.POINTER(Hooks),
+                                       C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats)]
     L.lcb_generate_output.argtypes = [vp, i64, vp, i64, i64, C.c_char_p, C.c_int, i64, C.POINTER(i64), C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -286,10 +294,44 @@ class Device:
             raise _err(self.L)
         return offsets, inst[: int(offsets[n])], score, (ctr.as_dict() if counters else None)
 
+    def hbm_triad(self, nbytes=1 << 30, reps=5):
+        """Measured HBM rate (STREAM triad, GB/s)."""
+        v = C.c_double()
+        if self.L.lcb_device_hbm_triad(self.h, nbytes, reps, C.byref(v)):
+            raise _err(self.L)
+        return v.value
+
     def kernel_time(self):
         ms, n = C.c_double(), C.c_int64()
         self.L.lcb_device_kernel_time(self.h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+
+class Comm:
+    """RCCL communicator of one rank (lcb_comm): the round engine's all-gather runs natively over it (ncclAllGather)."""
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = (C.c_ubyte * 128)()
+        if L.lcb_comm_unique_id(buf):
+            raise _err(L)
+        return bytes(buf)
+
+    def __init__(self, device, unique_id, rank, world):
+        self.L = load_library()
+        self.rank, self.world = rank, world
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self.h = self.L.lcb_comm_create(device.h, buf, rank, world)
+        if not self.h:
+            raise _err(self.L)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcb_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class Committer:
@@ -371,8 +413,32 @@ class BlocksFinder:
         self.stats = None
         self.params = None
 
+    def FindBlocksGpus(self, minBlockSize, maxBranchSize, ordinals, seeds=None, threads=1, device_opts=None, **engine):
+        """FindBlocks on several GPUs from this process (one host thread per GPU, RCCL all-gather between them)."""
+        p = Params(self.k, minBlockSize, maxBranchSize, maxBranchSize, 8, 256)
+        self.params = p
+        hooks = Hooks()
+        hooks.world = 1
+        for k, v in engine.items():
+            if k not in ENGINE_KNOBS:
+                raise TypeError("unknown engine knob %r" % k)
+            setattr(hooks, k, int(v))
+        o = DeviceOpts()
+        for k, v in (device_opts or {}).items():
+            setattr(o, k, int(v))
+        s = self.storage.seeds(threads) if seeds is None else np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        ords = (C.c_int * len(ordinals))(*ordinals)
+        out, n, st = C.c_void_p(), C.c_int64(), Stats()
+        if self.L.lcb_find_blocks_gpus(self.storage.h, ords, len(ordinals), C.byref(p), C.byref(o), s.ctypes.data, len(s), C.byref(hooks),
+                                       C.byref(out), C.byref(n), C.byref(st)):
+            raise _err(self.L)
+        self.blocks = _np_from(out.value, n.value, BLOCK_DTYPE)
+        self.L.lcb_free(out)
+        self.stats = {f: getattr(st, f) for f, _ in Stats._fields_}
+        return self.blocks
+
     def FindBlocks(self, minBlockSize, maxBranchSize, maxFlankingSize=None, lookingDepth=8, sampleSize=0, threads=1, device=None,
-                   seeds=None, hooks=None, **engine):
+                   seeds=None, hooks=None, comm=None, **engine):
         """hooks: an api.Hooks (multi-rank all-gather and/or callback engine); device may be None only with callback hooks.
         engine: tuning knobs of the round engine (ENGINE_KNOBS), e.g. round_phases=7, round_fixed=1, max_views=-1."""
         if engine:
@@ -391,8 +457,12 @@ class BlocksFinder:
         try:
             s = self.storage.seeds(threads) if seeds is None else np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
             out, n, st = C.c_void_p(), C.c_int64(), Stats()
-            rc = self.L.lcb_find_blocks_ex(self.storage.h, dev.h if dev is not None else None, C.byref(p), s.ctypes.data, len(s),
-                                           C.byref(hooks) if hooks is not None else None, C.byref(out), C.byref(n), C.byref(st))
+            if comm is not None:     # native multi-rank path: RCCL all-gather inside the C++ engine
+                rc = self.L.lcb_find_blocks_comm(self.storage.h, dev.h, comm.h, C.byref(p), s.ctypes.data, len(s),
+                                                 C.byref(hooks) if hooks is not None else None, C.byref(out), C.byref(n), C.byref(st))
+            else:
+                rc = self.L.lcb_find_blocks_ex(self.storage.h, dev.h if dev is not None else None, C.byref(p), s.ctypes.data, len(s),
+                                               C.byref(hooks) if hooks is not None else None, C.byref(out), C.byref(n), C.byref(st))
             if rc:
                 raise _err(self.L)
             self.blocks = _np_from(out.value, n.value, BLOCK_DTYPE)

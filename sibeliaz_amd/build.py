@@ -21,7 +21,7 @@ BIN = os.path.join(PKG, "bin")
 LIB = os.path.join(PKG, "libsibeliaz_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-LIB_SRC = ["graph.cpp", "bundles.cpp", "commit.cpp", "engine.cpp", "output.cpp", "capi.cpp", "device.hip"]
+LIB_SRC = ["graph.cpp", "bundles.cpp", "commit.cpp", "engine.cpp", "output.cpp", "capi.cpp", "comm.hip", "device.hip"]
 LIB_HDR = ["lcb_host.h", "lcb_kernel.h", "lcb_device.h"]
 
 
@@ -53,11 +53,12 @@ def hip_flags():
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
-def build_lib():
+def build_lib(out=LIB, defines=()):
+    """defines: extra -D macros (experiment variants: python sibeliaz_amd/build.py variant <name> <-D...>)."""
     srcs = [os.path.join(CSRC, s) for s in LIB_SRC]
     deps = srcs + [os.path.join(CSRC, h) for h in LIB_HDR] + [os.path.join(ROOT, "include", "lcb.h")]
-    if _newer(deps, LIB):
-        cmd = [HIPCC] + hip_flags() + ["-shared", "-o", LIB]
+    if _newer(deps, out):
+        cmd = [HIPCC] + hip_flags() + list(defines) + ["-shared", "-o", out, "-ldl"]
         for s in srcs:
             if s.endswith(".hip"):
                 cmd += ["-x", "hip", s]
@@ -82,6 +83,9 @@ def build_oracle():
 
 
 def main(argv):
+    if argv and argv[0] == "variant":      # experiment builds: libsibeliaz_amd_<name>.so with extra macros; use with LCB_LIB=<path>
+        build_lib(os.path.join(PKG, "libsibeliaz_amd_%s.so" % argv[1]), argv[2:])
+        return
     targets = argv or ["all"]
     for t in targets:
         if t == "tools":

@@ -20,6 +20,27 @@ void lcb_set_error(const std::string& msg) { g_error = msg; }
     catch (std::exception & e) { g_error = e.what(); return ret; } \
     catch (...) { g_error = "unknown error"; return ret; }
 
+namespace {
+LcbEngineConfig tuningOf(const lcb_hooks* hooks)
+{
+    LcbEngineConfig cfg;
+    if (hooks) {
+        cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
+        cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0;
+    }
+    return cfg;
+}
+int giveBlocks(std::vector<lcb_block>& v, lcb_block** blocks, int64_t* n_blocks)
+{
+    *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));
+    if (!*blocks) throw LcbError("out of memory");
+    if (!v.empty()) memcpy(*blocks, v.data(), v.size() * sizeof(lcb_block));
+    *n_blocks = (int64_t)v.size();
+    return LCB_OK;
+}
+}  // namespace
+
 #define LCB_NEED(cond, what) do { if (!(cond)) throw LcbError(std::string(what) + ": null argument"); } while (0)
 
 extern "C" {
@@ -88,6 +109,14 @@ int lcb_device_reset_used(lcb_device* d) { LCB_TRY LCB_NEED(d, "lcb_device_reset
 int lcb_device_mark_used(lcb_device* d, const uint64_t* ranges, int64_t n) { LCB_TRY LCB_NEED(d && (ranges || n == 0), "lcb_device_mark_used"); lcb_device_mark_used_impl(d, ranges, n); return LCB_OK; LCB_CATCH(LCB_ERR) }
 int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words) { LCB_TRY LCB_NEED(d && words, "lcb_device_set_used"); lcb_device_set_used_impl(d, words, n_words); return LCB_OK; LCB_CATCH(LCB_ERR) }
 int lcb_device_set_stats_mode(lcb_device* d, int on) { LCB_TRY LCB_NEED(d, "lcb_device_set_stats_mode"); lcb_device_set_stats_impl(d, on != 0); return LCB_OK; LCB_CATCH(LCB_ERR) }
+int lcb_device_hbm_triad(lcb_device* d, uint64_t bytes, int reps, double* gb_per_s)
+{
+    LCB_TRY
+    LCB_NEED(d && gb_per_s, "lcb_device_hbm_triad");
+    *gb_per_s = lcb_device_hbm_triad_impl(d, bytes, reps > 0 ? reps : 1);
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
 int lcb_device_kernel_time(lcb_device* d, double* ms, int64_t* launches) { LCB_TRY LCB_NEED(d, "lcb_device_kernel_time"); lcb_device_kernel_time_impl(d, ms, launches); return LCB_OK; LCB_CATCH(LCB_ERR) }
 
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
@@ -177,7 +206,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -192,7 +221,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
             stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-            stats->process_ms = es.processMs; stats->plan_ms = es.planMs;
+            stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));
@@ -217,6 +246,38 @@ int lcb_find_blocks(const lcb_graph* g, lcb_device* d, const lcb_params* p, cons
     if (!v.empty()) memcpy(*blocks, v.data(), v.size() * sizeof(lcb_block));
     *n_blocks = (int64_t)v.size();
     return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
+int lcb_comm_unique_id(unsigned char id[LCB_COMM_ID_BYTES]) { LCB_TRY LCB_NEED(id, "lcb_comm_unique_id"); lcb_comm_unique_id_impl(id); return LCB_OK; LCB_CATCH(LCB_ERR) }
+lcb_comm* lcb_comm_create(lcb_device* d, const unsigned char id[LCB_COMM_ID_BYTES], int rank, int world)
+{
+    LCB_TRY
+    LCB_NEED(d && id, "lcb_comm_create");
+    return lcb_comm_create_impl(lcb_device_ordinal_impl(d), id, rank, world);
+    LCB_CATCH(nullptr)
+}
+void lcb_comm_destroy(lcb_comm* c) { lcb_comm_destroy_impl(c); }
+int lcb_find_blocks_comm(const lcb_graph* g, lcb_device* d, lcb_comm* c, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
+                         const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
+{
+    LCB_TRY
+    LCB_NEED(g && d && c && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks_comm");
+    LcbEngineConfig cfg = tuningOf(hooks);
+    lcb_comm_fill_config(c, cfg);
+    std::vector<lcb_block> v;
+    lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
+    return giveBlocks(v, blocks, n_blocks);
+    LCB_CATCH(LCB_ERR)
+}
+int lcb_find_blocks_gpus(const lcb_graph* g, const int* device_ordinals, int n_devices, const lcb_params* p, const lcb_device_opts* opts,
+                         const lcb_seed* seeds, int64_t n_seeds, const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
+{
+    LCB_TRY
+    LCB_NEED(g && device_ordinals && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks_gpus");
+    std::vector<lcb_block> v;
+    lcb_find_blocks_gpus_impl(g, device_ordinals, n_devices, p, opts, seeds, n_seeds, tuningOf(hooks), v, stats);
+    return giveBlocks(v, blocks, n_blocks);
     LCB_CATCH(LCB_ERR)
 }
 

@@ -37,9 +37,13 @@
 
 // MODE 0/1/2/3 = compact / wide / big / huge (lcb_kernel.h): where the per-path instance pool and vote table live.
 // NW wavefronts per workgroup: wave 0 runs the per-seed algorithm, the rest share the votes.
-#define LCB_NW_COMPACT 1
+#ifndef LCB_NW_WIDE
 #define LCB_NW_WIDE 16
+#endif
+#ifndef LCB_NW_BIG
 #define LCB_NW_BIG 8
+#endif
+#define LCB_NW_COMPACT 1
 #define LCB_NW_HUGE 8
 // PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
 template <int MODE, bool STATS, int NW, bool PROF>
@@ -97,6 +101,15 @@ __global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, size_t st
             if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
             atomicOr(&u[w], m);
         }
+    }
+}
+
+// STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
+__global__ __launch_bounds__(256) void lcb_triad_kernel(float4* a, const float4* b, const float4* c, float s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = b[i], y = c[i];
+        a[i] = float4{x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w};
     }
 }
 
@@ -162,6 +175,7 @@ struct lcb_device_impl {
     int64_t launches = 0, bigRetries = 0;
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
     int64_t screened = 0, screenedDead = 0;
+    int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
 
@@ -395,6 +409,13 @@ void lcb_device_destroy_impl(lcb_device* h)
     if (!h) return;
     lcb_device_impl* d = h->impl;
     if (d) {
+        if (getenv("LCB_VERBOSE")) {
+            fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
+                    (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
+            for (int m = 0; m < 4; m++)
+                fprintf(stderr, "   overflows out of %-7s: instances %lld vote table %lld path %lld snapshot %lld\n", modeName(m), (long long)d->overflow[m][LCB_ST_INST_OVF],
+                        (long long)d->overflow[m][LCB_ST_VOTE_OVF], (long long)d->overflow[m][LCB_ST_PATH_OVF], (long long)d->overflow[m][LCB_ST_BEST_OVF]);
+        }
         (void)hipSetDevice(d->ordinal);
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (void* p : d->owned) (void)hipFree(p);
@@ -478,7 +499,32 @@ void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* m
     markRanges(d, nMarks, [&](int64_t k) { return LcbMarkRange{marks[k].lo, marks[k].hi, marks[k].firstView, (uint32_t)nViews}; });
 }
 
+// Three arrays of `bytes` each, `reps` timed sweeps after one warm-up; returns GB/s (3 x bytes per sweep: two reads, one write).
+double lcb_device_hbm_triad_impl(lcb_device* h, uint64_t bytes, int reps)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    const size_t n = (size_t)(bytes / sizeof(float4));
+    float4 *a = nullptr, *b = nullptr, *c = nullptr;
+    HIP_CHECK(hipMalloc((void**)&a, n * sizeof(float4)));
+    HIP_CHECK(hipMalloc((void**)&b, n * sizeof(float4)));
+    HIP_CHECK(hipMalloc((void**)&c, n * sizeof(float4)));
+    HIP_CHECK(hipMemsetAsync(b, 0, n * sizeof(float4), d->stream));
+    HIP_CHECK(hipMemsetAsync(c, 0, n * sizeof(float4), d->stream));
+    float ms = 0;
+    for (int r = 0; r <= reps; r++) {
+        if (r == 1) HIP_CHECK(hipEventRecord(d->ev0, d->stream));
+        hipLaunchKernelGGL(lcb_triad_kernel, dim3(256 * 32), dim3(256), 0, d->stream, a, b, c, 3.0f, n);
+    }
+    HIP_CHECK(hipEventRecord(d->ev1, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    HIP_CHECK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+    return ms > 0 ? 3.0 * (double)(n * sizeof(float4)) * reps / (ms * 1e-3) / 1e9 : 0.0;
+}
+
 int lcb_device_max_views_impl(lcb_device* h) { return h->impl->maxViews; }
+int lcb_device_ordinal_impl(lcb_device* h) { return h->impl->ordinal; }
 int lcb_device_concurrency_impl(lcb_device* h) { return (int)h->impl->ws[0].nSlots; }
 
 void lcb_device_set_stats_impl(lcb_device* h, bool on) { h->impl->stats = on; }
@@ -495,8 +541,9 @@ void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[4]) { for (int i = 0;
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view)
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr)
 {
+    if (perSeedCtr) perSeedCtr->assign((size_t)n, lcb_counters{});
     lcb_device_impl* d = h->impl;
     d->use();
     offsets.assign((size_t)n + 1, 0);
@@ -570,6 +617,12 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                         fpFlat.resize(f0 + o.nFp);
                         for (uint32_t e = 0; e < o.nFp; e++) fpFlat[f0 + e] = lcb_fp{src[e].x, src[e].y};
                     }
+                    if (perSeedCtr && d->stats) {
+                        const LcbSeedCtr& k = d->hCtr[i];
+                        lcb_counters& q = (*perSeedCtr)[(size_t)s];
+                        q.n_walk = k.c[0]; q.n_occ = k.c[1]; q.n_compat_call = k.c[2]; q.n_compat_step = k.c[3];
+                        q.n_inst_out = k.c[4]; q.n_vote = k.c[5]; q.n_push = k.c[6]; q.n_process = k.c[7];
+                    }
                     if (ctr) {
                         const LcbSeedCtr& k = d->hCtr[i];
                         ctr->n_walk += k.c[0]; ctr->n_occ += k.c[1]; ctr->n_compat_call += k.c[2]; ctr->n_compat_step += k.c[3];
@@ -582,6 +635,7 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
                 } else if (o.status == LCB_ST_ARENA_OVF) {
                     todo[mode].push_back(s);                          // same mode again: the arena is emptied between launches
                 } else {
+                    if (o.status < 8) d->overflow[mode][o.status]++;
                     const int nextMode = mode < 3 ? mode + 1 : 3;
                     if (mode == 3) hugeOverflow = true; else setHint(seeds[s], (uint8_t)nextMode);
                     todo[nextMode].push_back(s);
@@ -625,7 +679,7 @@ struct DeviceProcessor : LcbProcessor {
     void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
                  std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
-        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view);
+        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view, ctrSink);
     }
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
     int concurrency() const override { return lcb_device_concurrency_impl(dev); }
@@ -654,6 +708,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-        stats->process_ms = es.processMs; stats->plan_ms = es.planMs;
+        stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
     }
 }

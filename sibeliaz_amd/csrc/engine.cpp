@@ -22,9 +22,9 @@
 // Neighbouring blocks, which invalidate each other one after the other, are thereby recomputed in ONE launch instead of
 // a chain of launches; a result whose prediction did not come true fails (1) or (2) and is simply computed again at the
 // next stop, where the first missing result always runs against the live state itself, so the loop makes progress.
-// With world > 1 the round's speculative launch is dealt round-robin to the ranks and the per-seed results + footprints
-// are all-gathered; every rank then runs the identical commit (job launches are repeated on every rank), so all ranks
-// hold the same `used` state and block list without further traffic.
+// With world > 1 every launch — a round's speculative launch and every job launch — is dealt round-robin to the ranks and
+// the per-seed results + footprints are all-gathered; every rank then runs the identical dry runs and commit, so all
+// ranks hold the same `used` state and block list without further traffic.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -86,7 +86,14 @@ struct Results {                       // per-seed results of one process() call
     std::vector<uint64_t> off, fpOff;
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
+    std::vector<lcb_counters> ctr;     // countEvents only
 };
+
+inline void addCounters(lcb_counters& a, const lcb_counters& b)
+{
+    a.n_walk += b.n_walk; a.n_occ += b.n_occ; a.n_compat_call += b.n_compat_call; a.n_compat_step += b.n_compat_step;
+    a.n_inst_out += b.n_inst_out; a.n_vote += b.n_vote; a.n_push += b.n_push; a.n_process += b.n_process;
+}
 
 // A computed result together with the state it was computed against: the live state at launch `epoch` plus the
 // predicted marks of `view` (-1 = none).
@@ -96,6 +103,7 @@ struct Cand {
     bool viewOk = false;               // every predicted mark of the view is known to have come true
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
+    lcb_counters ctr{};
 };
 
 void pack(const Results& r, int64_t n, std::vector<unsigned char>& buf)
@@ -142,6 +150,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                                                                     // 1 nothing, 2 the still-free instances of E, 3 a stale F if there is one, else as 2
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
+    if (rank < 0 || rank >= world) throw LcbError("bad rank");
+    if (cfg.countEvents && world > 1) throw LcbError("event counting runs on one rank");
 
     lcb_committer com(g, *p);
     proc.reset();
@@ -175,58 +185,87 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<uint32_t> e0Checked;                // per seed: epochs already checked for its round-launch result
     std::vector<RangeSet> viewSets;                 // predicted mark sets of this round's views
 
+    // Runs ProcessVertex::Process for n seeds (seed i against view[i]) on ALL ranks: seed i goes to rank i % world, the
+    // per-seed results and footprints are all-gathered (sizes first, then the padded payload), so every rank ends with the
+    // same `out`. The size exchange also carries an error flag and a tag of the call (launch ordinal, n, caller's tag): a rank
+    // that failed, or ranks that disagree about what they are computing (different LCB knobs, diverged state), stop ALL ranks
+    // with an error instead of leaving the others blocked in the next collective.
+    uint64_t launchOrdinal = 0;
+    std::vector<lcb_seed> shareSeeds;
+    std::vector<uint32_t> shareView;
+    auto processSharded = [&](const lcb_seed* sd, const uint32_t* view, int64_t n, Results& out, uint64_t tag) {
+        launchOrdinal++;
+        if (world == 1 && !(cfg.exchangeAlways && cfg.allgather)) {
+            const auto tp = std::chrono::steady_clock::now();
+            proc.ctrSink = cfg.countEvents ? &out.ctr : nullptr;
+            proc.process(sd, view, n, out.off, out.inst, out.fpOff, out.fp);
+            proc.ctrSink = nullptr;
+            if (cfg.countEvents && (int64_t)out.ctr.size() != n) throw LcbError("the processor does not count events (stats mode off?)");
+            st.processMs += msSince(tp);
+            return;
+        }
+        shareSeeds.clear(); shareView.clear();
+        for (int64_t i = rank; i < n; i += world) { shareSeeds.push_back(sd[i]); if (view) shareView.push_back(view[i]); }
+        uint64_t failed = 0;
+        std::string what;
+        try {
+            const auto tp = std::chrono::steady_clock::now();
+            proc.process(shareSeeds.data(), view ? shareView.data() : nullptr, (int64_t)shareSeeds.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
+            st.processMs += msSince(tp);
+            pack(mine, (int64_t)shareSeeds.size(), sendBuf);
+        } catch (std::exception& e) { failed = 1; what = e.what(); sendBuf.clear(); }
+        uint64_t head[4] = {sendBuf.size(), failed, launchOrdinal, ((uint64_t)n << 20) ^ tag};
+        std::vector<uint64_t> heads((size_t)world * 4);
+        if (cfg.allgather(cfg.allgatherUser, head, sizeof(head), heads.data())) throw LcbError("all-gather failed");
+        uint64_t maxBytes = 0;
+        for (int r = 0; r < world; r++) {
+            if (heads[4 * r + 1]) throw LcbError(r == rank ? "rank " + std::to_string(r) + " failed: " + what : "rank " + std::to_string(r) + " failed; stopping all ranks");
+            if (heads[4 * r + 2] != head[2] || heads[4 * r + 3] != head[3])
+                throw LcbError("ranks disagree about the launch they are in (are the engine and device options identical on every rank?)");
+            maxBytes = std::max(maxBytes, heads[4 * r]);
+        }
+        sendBuf.resize((size_t)maxBytes);
+        recvBuf.resize((size_t)maxBytes * world);
+        if (maxBytes && cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
+        st.exchanges++;
+        // seed i came from rank i % world, local index i / world
+        out.off.assign((size_t)n + 1, 0); out.fpOff.assign((size_t)n + 1, 0);
+        std::vector<const unsigned char*> base((size_t)world);
+        std::vector<uint64_t> instAt((size_t)world, 0), fpAt((size_t)world, 0), nLocal((size_t)world), instTot((size_t)world, 0);
+        for (int r = 0; r < world; r++) {
+            base[r] = recvBuf.data() + (size_t)r * maxBytes;
+            nLocal[r] = n > r ? (uint64_t)((n - r + world - 1) / world) : 0;
+            const uint32_t* h = (const uint32_t*)base[r];
+            for (uint64_t j = 0; j < nLocal[r]; j++) instTot[r] += h[2 * j];
+        }
+        uint64_t ti = 0, tf = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t* h = (const uint32_t*)base[i % world];
+            out.off[i] = ti; out.fpOff[i] = tf;
+            ti += h[2 * (i / world)]; tf += h[2 * (i / world) + 1];
+        }
+        out.off[n] = ti; out.fpOff[n] = tf;
+        out.inst.resize(ti); out.fp.resize(tf);
+        for (int64_t i = 0; i < n; i++) {
+            const int r = (int)(i % world);
+            const uint32_t* h = (const uint32_t*)base[r];
+            const uint32_t ci = h[2 * (i / world)], cf = h[2 * (i / world) + 1];
+            const unsigned char* instBase = base[r] + nLocal[r] * 8;
+            const unsigned char* fpBase = instBase + instTot[r] * sizeof(lcb_instance);
+            if (ci) memcpy(&out.inst[out.off[i]], instBase + instAt[r] * sizeof(lcb_instance), ci * sizeof(lcb_instance));
+            if (cf) memcpy(&out.fp[out.fpOff[i]], fpBase + fpAt[r] * sizeof(lcb_fp), cf * sizeof(lcb_fp));
+            instAt[r] += ci; fpAt[r] += cf;
+        }
+    };
+
     for (int64_t pos = 0; pos < nSeeds;) {
         const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
         flush();                                    // processor state == live state at the start of phase `pos`
         epochMarks.assign(1, RangeSet());
         st.rounds++;
-        // ---- speculative launch of the whole round (this rank's share) -------------------------------------------
-        sub.clear();
-        for (int64_t i = rank; i < nRound; i += world) sub.push_back(seeds[pos + i]);
-        { const auto tp = std::chrono::steady_clock::now();
-          proc.process(sub.data(), nullptr, (int64_t)sub.size(), mine.off, mine.inst, mine.fpOff, mine.fp);
-          st.processMs += msSince(tp); }
-        if (world == 1) round = mine;
-        else {
-            // all-gather: sizes first, then the padded payload
-            pack(mine, (int64_t)sub.size(), sendBuf);
-            uint64_t myBytes = sendBuf.size();
-            std::vector<uint64_t> sizes((size_t)world);
-            if (cfg.allgather(cfg.allgatherUser, &myBytes, sizeof(uint64_t), sizes.data())) throw LcbError("all-gather failed");
-            const uint64_t maxBytes = *std::max_element(sizes.begin(), sizes.end());
-            sendBuf.resize((size_t)maxBytes);
-            recvBuf.resize((size_t)maxBytes * world);
-            if (cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
-            st.exchanges++;
-            // seed i of the round came from rank i % world, local index i / world
-            round.off.assign((size_t)nRound + 1, 0); round.fpOff.assign((size_t)nRound + 1, 0);
-            std::vector<const unsigned char*> base((size_t)world);
-            std::vector<uint64_t> instAt((size_t)world, 0), fpAt((size_t)world, 0), nLocal((size_t)world), instTot((size_t)world, 0);
-            for (int r = 0; r < world; r++) {
-                base[r] = recvBuf.data() + (size_t)r * maxBytes;
-                nLocal[r] = (uint64_t)((nRound - r + world - 1) / world);
-                const uint32_t* head = (const uint32_t*)base[r];
-                for (uint64_t j = 0; j < nLocal[r]; j++) instTot[r] += head[2 * j];
-            }
-            uint64_t ti = 0, tf = 0;
-            for (int64_t i = 0; i < nRound; i++) {
-                const uint32_t* head = (const uint32_t*)base[i % world];
-                round.off[i] = ti; round.fpOff[i] = tf;
-                ti += head[2 * (i / world)]; tf += head[2 * (i / world) + 1];
-            }
-            round.off[nRound] = ti; round.fpOff[nRound] = tf;
-            round.inst.resize(ti); round.fp.resize(tf);
-            for (int64_t i = 0; i < nRound; i++) {
-                const int r = (int)(i % world);
-                const uint32_t* head = (const uint32_t*)base[r];
-                const uint32_t ci = head[2 * (i / world)], cf = head[2 * (i / world) + 1];
-                const unsigned char* instBase = base[r] + nLocal[r] * 8;
-                const unsigned char* fpBase = instBase + instTot[r] * sizeof(lcb_instance);
-                if (ci) memcpy(&round.inst[round.off[i]], instBase + instAt[r] * sizeof(lcb_instance), ci * sizeof(lcb_instance));
-                if (cf) memcpy(&round.fp[round.fpOff[i]], fpBase + fpAt[r] * sizeof(lcb_fp), cf * sizeof(lcb_fp));
-                instAt[r] += ci; fpAt[r] += cf;
-            }
-        }
+        // ---- speculative launch of the whole round (dealt to the ranks) ---------------------------------------------
+        sub.assign(seeds + pos, seeds + pos + nRound);
+        processSharded(sub.data(), nullptr, nRound, round, (uint64_t)pos);
         cands.clear(); viewSets.clear();
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
@@ -386,8 +425,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             st.planMs += msSince(tPlan);
             const auto tProc = std::chrono::steady_clock::now();
             if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }
-            proc.process(sub.data(), subView.data(), (int64_t)sub.size(), tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
-            st.processMs += msSince(tProc);
+            (void)tProc;
+            // every rank plans the same jobs (same state, same results); the jobs of one launch are independent given their
+            // views, so they are dealt to the ranks like a round's seeds and gathered the same way
+            processSharded(sub.data(), subView.data(), (int64_t)sub.size(), tmp, (uint64_t)(pos + stopAt));
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
             if (midPhase) st.conflictLaunches++;
             if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views\n";
@@ -402,6 +443,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 c.epoch = epoch; c.view = jb.set; c.checkedTo = (uint32_t)epoch; c.viewOk = jb.set < 0;
                 c.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
                 c.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
+                if (cfg.countEvents) c.ctr = tmp.ctr[k];
             }
         };
 
@@ -420,6 +462,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 if (cfg.progress && (pos + i) % portion == 0) std::cout << '.' << std::flush;
                 const lcb_instance* r; uint64_t cnt;
                 eInst(i, r, cnt);
+                // the phase-start result of seed i is exact now: its events are the ones the reference's Process() call has
+                if (cfg.countEvents) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
                 if (cnt <= 1) continue;                                                  // blocksfinder.h:375
                 if (!com.conflicts(r, cnt)) { com.finalize(r, cnt); takeMarks(); if (eIdx[(size_t)i] >= 0) st.jobsUsed++; continue; }
                 st.failures++;                                                           // blocksfinder.h:406
@@ -432,6 +476,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 }
                 const Cand& c = cands[(size_t)fIdx[(size_t)i]];
                 st.jobsUsed++;
+                if (cfg.countEvents) addCounters(st.events, c.ctr);                      // the re-processing (blocksfinder.h:407) is a second Process() call
                 if (debug) {
                     uint64_t eb = 0, fb = 0;
                     for (uint64_t k = 0; k < cnt; k++) { uint64_t lo, hi; instRange(g, r[k], lo, hi); eb += hi - lo; }

@@ -24,15 +24,27 @@ void lcb_device_set_stats_impl(lcb_device* d, bool on);
 void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
                              std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr,
-                             const uint32_t* view = nullptr);   // view[i]: `used` view of seed i (null = the live state)
+                             const uint32_t* view = nullptr,    // view[i]: `used` view of seed i (null = the live state)
+                             std::vector<lcb_counters>* perSeedCtr = nullptr);   // stats mode: the counters of every seed
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
 void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_max_views_impl(lcb_device* d);
+double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
                           const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);
+
+// comm.hip — RCCL all-gather between the ranks of the round engine
+struct lcb_comm;
+void lcb_comm_unique_id_impl(unsigned char* id128);
+lcb_comm* lcb_comm_create_impl(int ordinal, const unsigned char* id128, int rank, int world);
+void lcb_comm_destroy_impl(lcb_comm* c);
+void lcb_comm_fill_config(lcb_comm* c, LcbEngineConfig& cfg);
+int lcb_device_ordinal_impl(lcb_device* d);
+void lcb_find_blocks_gpus_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts,
+                               const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);
 
 #endif

@@ -81,6 +81,9 @@ struct LcbProcessor {
                          std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) = 0;
     virtual void mark(const uint64_t* ranges, int64_t n) = 0;
     virtual void reset() = 0;
+    // when set, process() also stores the reference-semantics event counters of every seed here (a processor that can
+    // count them: the device in stats mode; others leave it empty)
+    std::vector<lcb_counters>* ctrSink = nullptr;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
     virtual int maxViews() const { return 0; }
     // seeds the processor works on at the same time: a dry run plans about this many jobs per launch (more only queue up)
@@ -102,6 +105,8 @@ struct LcbEngineConfig {
     int maxViews = 0;         // predicted views per job launch (0 = all the processor has, -1 = none)
     int maxJobs = 0;          // a dry run stops planning beyond this many jobs (0 = the processor's concurrency)
     int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
+    bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
+    bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
 };
 
 struct LcbEngineStats {
@@ -113,6 +118,7 @@ struct LcbEngineStats {
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     double wallMs = 0;
     double processMs = 0, planMs = 0;   // wall time inside the processor (launches + result gathering) / inside the dry runs
+    lcb_counters events{};              // countEvents: totals over the phase-start result of every seed + the re-processed result of every conflict
 };
 
 void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds, LcbProcessor& proc,

@@ -162,6 +162,18 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");    \
     } while (0)
 
+// The same for data that lives in LDS and is only touched by this wavefront between two workgroup barriers: LDS operations
+// of one wavefront execute in issue order, so only the compiler has to be kept from moving them; unlike the fence above
+// this does not wait for the global loads in flight (prefetched occurrence records, `used` words), which is the point.
+#define LCB_WAVE_SYNC_LDS()                                       \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+// per kernel variant: the light form where the protected state is LDS-resident, the full fence otherwise
+#define LCB_SYNC_IF(ldsResident) do { if (ldsResident) LCB_WAVE_SYNC_LDS(); else LCB_WAVE_SYNC(); } while (0)
+
 // Flight recorder: lane 0 stores progress words the host watchdog can read while the kernel is running.
 #define LCB_MARK(S, slot, value)                                                         \
     do {                                                                                 \
@@ -305,14 +317,19 @@ __device__ inline uint32_t lcb_range_walk_steps(const uint32_t* used, uint32_t a
 
 __device__ __forceinline__ uint32_t lcb_bcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); }
 
-__device__ __forceinline__ int64_t lcb_wave_sum(int64_t v)
+// Wave-wide sum of a 64-bit value (same DPP ladder as lcb_wave_umax, both halves moved together); wave-uniform result.
+#define LCB_DPP_ADD64(v, ctrl, rowMask)                                                                             \
+    do {                                                                                                            \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v), ctrl, rowMask, 0xf, false); \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((v) >> 32), ctrl, rowMask, 0xf, false); \
+        (v) += ((uint64_t)hi_ << 32) | lo_;                                                                         \
+    } while (0)
+__device__ __forceinline__ int64_t lcb_wave_sum(int64_t x)
 {
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), o);
-        v += (int64_t)(((uint64_t)hi << 32) | lo);
-    }
-    return v;
+    uint64_t v = (uint64_t)x;
+    LCB_DPP_ADD64(v, 0x111, 0xf); LCB_DPP_ADD64(v, 0x112, 0xf); LCB_DPP_ADD64(v, 0x114, 0xf); LCB_DPP_ADD64(v, 0x118, 0xf);
+    LCB_DPP_ADD64(v, 0x142, 0xa); LCB_DPP_ADD64(v, 0x143, 0xc);
+    return (int64_t)(((uint64_t)lcb_rl((uint32_t)(v >> 32), 63) << 32) | lcb_rl((uint32_t)v, 63));
 }
 
 // ---- path vertex set (DistanceKeeper::IsSet / Set / Unset, distancekeeper.h:17-35) --------------
@@ -362,7 +379,8 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
     uint32_t probe = 0;
     while (S.pKeys[h] != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; }
     if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
-    LCB_WAVE_SYNC();               // every lane has finished probing before lane 0 publishes the key
+    constexpr bool PL = LcbCfg<ST::MODE>::PC != 0;
+    LCB_SYNC_IF(PL);               // every lane has finished probing before lane 0 publishes the key
     if (S.lane == 0) {
         S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
         if (LcbCfg<ST::MODE>::BW) {
@@ -372,7 +390,7 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
         }
     }
     S.nPath++;
-    LCB_WAVE_SYNC();
+    LCB_SYNC_IF(PL);
 }
 
 // Path::Clear (path.h:650-677): wave-uniform. The right-body list is kept (the replay reads it).
@@ -418,7 +436,7 @@ __device__ inline void lcb_order_merge(ST& S, uint32_t m)
         di[at] = (uint16_t)S.scr[128 + S.lane];
     }
     S.cur = d;
-    LCB_WAVE_SYNC();
+    LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
 }
 
 // Path::Init (path.h:33-46): one instance per unused occurrence of vid whose next character is ch.
@@ -705,21 +723,21 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
             b.e = lcb_rl(pe, w);
         } else {
             b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
-            LCB_WAVE_SYNC();
+            LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
             lcb_vote_clear(S, 0, nTouched);
         }
     } else {
         lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
-        LCB_WAVE_SYNC();
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
         nTouched = lcb_rfl(*S.vNClaimed);
         if (nTouched > claimCap) nTouched = claimCap;
         b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
-        LCB_WAVE_SYNC();
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
         lcb_vote_clear(S, 0, nTouched);
     }
     const bool ovfAny = lcb_rfl(*S.vOvf) != 0;
     if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
-    LCB_WAVE_SYNC();
+    LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
     if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
     if (b.cnt == 0) return 0;
     originInst = useGood ? lcb_rfl((uint32_t)S.good[b.e]) : b.e;
@@ -728,7 +746,7 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
 
 // One occurrence of the pushed vertex: its record plus the three `used` words around it, so that IsUsed and (almost
 // always) the Compatible gap test need no further global loads.
-struct LcbOcc { uint4 rec; uint32_t lo, wbase, uw0, uw1, uw2; };
+struct LcbOcc { uint4 rec; uint32_t lo, hi, wbase, uw0, uw1, uw2; };
 
 __device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, uint32_t j, bool active)
 {
@@ -740,9 +758,9 @@ __device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, uint32_t j, bo
 __device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const uint4& rec, bool active)
 {
     LcbOcc o;
-    o.rec = rec; o.lo = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
+    o.rec = rec; o.lo = 0; o.hi = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
     if (active) {
-        o.lo = T.chrStart[rec.y];
+        o.lo = T.chrStart[rec.y]; o.hi = T.chrStart[rec.y + 1];
         const uint32_t wi = rec.x >> 5;
         o.wbase = wi ? wi - 1 : 0;
         o.uw0 = T.used[o.wbase]; o.uw1 = T.used[o.wbase + 1]; o.uw2 = T.used[o.wbase + 2];
@@ -822,10 +840,9 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         if (active) {
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
-            lo = occ.lo;
             positive = ((int32_t)occ.rec.w == vertex);               // JunctionIterator::IsPositiveStrand
-            usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
-            // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g
+            // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g (LDS work first: the chromosome bounds and `used`
+            // words of the occurrence are still in flight)
             uint32_t a = 0, b = n;
             while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
             u = a;
@@ -879,6 +896,8 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                         if (cd == distance) compat = false;
                     }
                 }
+                lo = occ.lo;
+                usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
                 if (compat) {
                     const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
                     act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
@@ -957,7 +976,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             const uint32_t i = S.nInst + r;
             S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
             S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iLo[i] = lo;
-            S.iHi[i] = T.chrStart[chr + 1];
+            S.iHi[i] = occ.hi;
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
@@ -967,7 +986,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         nTouch += m;
         S.nInst += m;
         if (S.nInst > S.nFp) S.nFp = S.nInst;
-        LCB_WAVE_SYNC();
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::INST_LDS && LcbCfg<ST::MODE>::IDX_LDS);
         if (m) lcb_order_merge(S, m);
     }
     if (BACK) {

@@ -124,12 +124,25 @@ int main(int argc, char** argv)
         p.looking_depth = 8; p.phase_size = 256;
         const int64_t nSeeds = lcb_enumerate_seeds(g, (int)a.t, &seeds);
         if (nSeeds < 0) { fail(); break; }
+        // GPU selection comes from the environment, never from argv (the wrapper's command line, sibeliaz:146, stays as it is):
+        // LCB_GPUS=N uses HIP devices 0..N-1 (as filtered by HIP_VISIBLE_DEVICES), LCB_DEVICE=i uses device i; default one GPU.
         const char* devEnv = getenv("LCB_DEVICE");
-        dev = lcb_device_create(g, &p, devEnv && *devEnv ? atoi(devEnv) : 0);
-        if (!dev) { fail(); break; }
+        const char* gpusEnv = getenv("LCB_GPUS");
+        const int nGpus = gpusEnv && *gpusEnv ? atoi(gpusEnv) : 1;
         int64_t nBlocks = 0;
         lcb_stats st;
-        if (lcb_find_blocks(g, dev, &p, seeds, nSeeds, 1, &blocks, &nBlocks, &st) != LCB_OK) { fail(); break; }
+        if (nGpus > 1) {
+            std::vector<int> ord;
+            for (int i = 0; i < nGpus; i++) ord.push_back(i);
+            lcb_hooks hk;
+            memset(&hk, 0, sizeof(hk));
+            hk.world = 1; hk.progress = 1;
+            if (lcb_find_blocks_gpus(g, ord.data(), nGpus, &p, nullptr, seeds, nSeeds, &hk, &blocks, &nBlocks, &st) != LCB_OK) { fail(); break; }
+        } else {
+            dev = lcb_device_create(g, &p, devEnv && *devEnv ? atoi(devEnv) : 0);
+            if (!dev) { fail(); break; }
+            if (lcb_find_blocks(g, dev, &p, seeds, nSeeds, 1, &blocks, &nBlocks, &st) != LCB_OK) { fail(); break; }
+        }
         if (getenv("LCB_VERBOSE"))
             std::cerr << "lcb: seeds=" << st.seeds << " blocks=" << st.blocks_found << " conflicts=" << st.failures << " launches=" << st.launches
                       << " big_retries=" << st.big_retries << " kernel_ms=" << st.kernel_ms << " loop_ms=" << st.wall_ms << " | rounds=" << st.rounds
@@ -143,8 +156,8 @@ int main(int argc, char** argv)
         const int orc = lcb_generate_output(g, a.m, blocks, nBlocks, st.blocks_found, a.outDir.c_str(), a.noSeq ? 0 : 1, a.chunks, &nTrimmed, &coverage);
         char buf[64];
         snprintf(buf, sizeof(buf), "%.2f", coverage);
-        std::cout << "Blocks found: " << nTrimmed << std::endl << "Coverage: " << buf << std::endl;
         if (orc != LCB_OK) { fail(); break; }
+        std::cout << "Blocks found: " << nTrimmed << std::endl << "Coverage: " << buf << std::endl;
     } while (false);
     lcb_free(blocks);
     lcb_free(seeds);

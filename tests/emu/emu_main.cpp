@@ -15,7 +15,10 @@
 
 #include <omp.h>
 #include <algorithm>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "emu_runtime.h"
 #include "lcb_host.h"
@@ -230,6 +233,67 @@ struct Emu {
     }
 };
 
+struct EmuProcessor : LcbProcessor {
+    Emu* emu;
+    int views = 0;
+    void process(const lcb_seed* sd, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        std::vector<LcbKSeed> ks;
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t v = view ? view[i] : 0u;
+            if ((int)v > emu->nViewsAlloc) throw LcbError("seed names a view that was not built");
+            ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, v, 0u});
+        }
+        if (n) emu->runRetry(ks);
+        off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
+        for (int64_t i = 0; i < n; i++) {
+            const LcbSeedOut& o = emu->out[(size_t)i];
+            if (o.status) throw LcbError("emulated kernel overflow");
+            off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
+            for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
+            for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
+        }
+        off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
+        if (ctrSink) {       // stats-mode kernels: the per-seed event counters (engine's countEvents)
+            ctrSink->assign((size_t)n, lcb_counters{});
+            for (int64_t i = 0; i < n && !getenv("EMU_NOSTATS"); i++) {
+                const LcbSeedCtr& k = emu->octr[(size_t)i]; lcb_counters& q = (*ctrSink)[(size_t)i];
+                q.n_walk = k.c[0]; q.n_occ = k.c[1]; q.n_compat_call = k.c[2]; q.n_compat_step = k.c[3]; q.n_inst_out = k.c[4]; q.n_vote = k.c[5]; q.n_push = k.c[6]; q.n_process = k.c[7];
+            }
+        }
+    }
+    void mark(const uint64_t* r, int64_t n) override
+    {
+        for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
+    }
+    void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; }
+    int maxViews() const override { return views; }
+    int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
+    void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
+};
+
+// In-process all-gather between the rank threads of the `find-ranks` mode (stands in for ncclAllGather / gloo).
+struct EmuExchange {
+    std::mutex m; std::condition_variable cv;
+    int world = 1, arrived = 0; uint64_t gen = 0;
+    std::vector<unsigned char> buf;
+    void barrier(std::unique_lock<std::mutex>& lk) { const uint64_t g = gen; if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+struct EmuRankLink { EmuExchange* ex; int rank; };
+int emuAllgather(void* user, const void* send, uint64_t bytes, void* recv)
+{
+    EmuRankLink* l = (EmuRankLink*)user;
+    std::unique_lock<std::mutex> lk(l->ex->m);
+    if (l->ex->buf.size() < bytes * l->ex->world) l->ex->buf.resize(bytes * l->ex->world);
+    l->ex->barrier(lk);                                   // everyone has sized the buffer
+    memcpy(l->ex->buf.data() + bytes * l->rank, send, bytes);
+    l->ex->barrier(lk);                                   // everyone has written
+    memcpy(recv, l->ex->buf.data(), bytes * l->ex->world);
+    l->ex->barrier(lk);                                   // everyone has read
+    return 0;
+}
+
 int compareSeed(int64_t idx, const lcb_seed& sd, const LcbSeedOut& o, const uint4* arena, const orc_inst* ref, int64_t nRef, int64_t refScore)
 {
     bool ok = o.status == 0 && (int64_t)o.nInst == nRef && o.bestScore == refScore;
@@ -340,40 +404,9 @@ int main(int argc, char** argv)
                          emu.ctr.n_compat_step != octr.n_compat_step || emu.ctr.n_inst_out != octr.n_inst_out)) { fprintf(stderr, "FAIL: event counters differ\n"); bad++; }
         } else if (mode == "find") {
             // the product's speculative round engine (engine.cpp) over the emulated kernel, for several round sizes
-            struct EmuProcessor : LcbProcessor {
-                Emu* emu;
-                int views = 0;
-                void process(const lcb_seed* sd, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
-                             std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
-                {
-                    std::vector<LcbKSeed> ks;
-                    for (int64_t i = 0; i < n; i++) {
-                        const uint32_t v = view ? view[i] : 0u;
-                        if ((int)v > emu->nViewsAlloc) throw LcbError("seed names a view that was not built");
-                        ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, v, 0u});
-                    }
-                    if (n) emu->runRetry(ks);
-                    off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
-                    for (int64_t i = 0; i < n; i++) {
-                        const LcbSeedOut& o = emu->out[(size_t)i];
-                        if (o.status) throw LcbError("emulated kernel overflow");
-                        off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
-                        for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
-                        for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
-                    }
-                    off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
-                }
-                void mark(const uint64_t* r, int64_t n) override
-                {
-                    for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
-                }
-                void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; }
-                int maxViews() const override { return views; }
-                int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
-                void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
-            };
             orc_block* ob = nullptr; orc_stats st;
-            const int64_t nb = orc_find_blocks(og, &op, &ob, &st, nullptr);
+            orc_counters fctr; memset(&fctr, 0, sizeof(fctr));
+            const int64_t nb = orc_find_blocks(og, &op, &ob, &st, &fctr);
             std::vector<lcb_block> blocks;
             const char* rp = getenv("EMU_ROUNDS");
             std::vector<int> rounds = rp ? std::vector<int>{atoi(rp)} : std::vector<int>{1, 3, 64};
@@ -387,6 +420,7 @@ int main(int argc, char** argv)
                 cfg.roundFixed = envInt("LCB_ROUND_FIXED") != 0; cfg.maxJobs = envInt("LCB_MAX_JOBS");
                 if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F"));
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
+                cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -400,6 +434,21 @@ int main(int argc, char** argv)
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);
+                if (cfg.countEvents) {
+                    const lcb_counters& e = es.events;
+                    // n_compat_step counts the steps of Compatible's `used` walk up to the first used bit; a speculative result that is
+                    // exact (no bit of its footprint changed) may still have walked an incompatible gap against an older bitmap, where
+                    // the first used bit sits further away: same outcome, a few more steps. Everything else is equal by construction.
+                    const double dstep = (double)e.n_compat_step - (double)fctr.n_compat_step;
+                    const bool same = e.n_walk == fctr.n_walk && e.n_occ == fctr.n_occ && e.n_compat_call == fctr.n_compat_call &&
+                                      dstep >= 0 && dstep <= 1e-2 * (double)fctr.n_compat_step + 8 &&
+                                      e.n_inst_out == fctr.n_inst_out && e.n_vote == fctr.n_vote && e.n_push == fctr.n_push && e.n_process == fctr.n_process;
+                    fprintf(stderr, "       events walk=%llu occ=%llu ccall=%llu cstep=%llu inst=%llu process=%llu | oracle walk=%llu occ=%llu ccall=%llu cstep=%llu inst=%llu process=%llu %s\n",
+                            (unsigned long long)e.n_walk, (unsigned long long)e.n_occ, (unsigned long long)e.n_compat_call, (unsigned long long)e.n_compat_step, (unsigned long long)e.n_inst_out,
+                            (unsigned long long)e.n_process, (unsigned long long)fctr.n_walk, (unsigned long long)fctr.n_occ, (unsigned long long)fctr.n_compat_call,
+                            (unsigned long long)fctr.n_compat_step, (unsigned long long)fctr.n_inst_out, (unsigned long long)fctr.n_process, same ? "equal" : "DIFFERENT");
+                    if (!same) { fprintf(stderr, "FAIL: the engine's event totals differ from the oracle's FindBlocks\n"); diffs++; }
+                }
                 bad += diffs;
             }
             int64_t nTrim = 0; double cov = 0;
@@ -409,6 +458,45 @@ int main(int argc, char** argv)
             const int64_t ont = orc_generate_output(og, p.min_block, ob, nb, st.blocks_found, od2.c_str(), &ocov, err, sizeof(err));
             if (ont != nTrim) { fprintf(stderr, "FAIL: trimmed %lld vs %lld\n", (long long)nTrim, (long long)ont); bad++; }
             printf("Blocks found: %lld\nCoverage: %.2f\n", (long long)nTrim, cov);
+        } else if (mode == "find-ranks") {
+            // The multi-rank engine with REAL footprints and predicted views: EMU_RANKS rank threads, each with its own emulated
+            // device (its own `used` views), launches dealt to the ranks, results all-gathered in process, identical commit.
+            orc_block* ob = nullptr; orc_stats st;
+            const int64_t nb = orc_find_blocks(og, &op, &ob, &st, nullptr);
+            const int world = getenv("EMU_RANKS") ? atoi(getenv("EMU_RANKS")) : 2;
+            const int R = getenv("EMU_ROUNDS") ? atoi(getenv("EMU_ROUNDS")) : 64;
+            EmuExchange ex; ex.world = world;
+            std::vector<std::vector<lcb_block>> blocksOf((size_t)world);
+            std::vector<LcbEngineStats> statsOf((size_t)world);
+            std::vector<std::string> errOf((size_t)world);
+            std::vector<std::unique_ptr<Emu>> emus;
+            for (int r = 0; r < world; r++) emus.emplace_back(new Emu(g, p, 0));
+            std::vector<std::thread> th;
+            for (int r = 0; r < world; r++)
+                th.emplace_back([&, r]() {
+                    try {
+                        EmuProcessor proc; proc.emu = emus[(size_t)r].get();
+                        proc.views = getenv("EMU_VIEWS") ? atoi(getenv("EMU_VIEWS")) : 64;
+                        EmuRankLink link{&ex, r};
+                        LcbEngineConfig cfg; cfg.roundPhases = R; cfg.rank = r; cfg.world = world;
+                        cfg.allgather = emuAllgather; cfg.allgatherUser = &link;
+                        lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocksOf[(size_t)r], &statsOf[(size_t)r]);
+                    } catch (std::exception& e) { errOf[(size_t)r] = e.what(); }
+                });
+            for (auto& t : th) t.join();
+            for (int r = 0; r < world; r++) {
+                if (!errOf[(size_t)r].empty()) { fprintf(stderr, "rank %d: error: %s\n", r, errOf[(size_t)r].c_str()); bad++; continue; }
+                const auto& blocks = blocksOf[(size_t)r]; const auto& es = statsOf[(size_t)r];
+                int diffs = 0;
+                if (nb != (int64_t)blocks.size() || st.blocks_found != es.blocksFound || st.failures != es.failures) diffs++;
+                for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
+                    if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
+                fprintf(stderr, "find-ranks rank %d/%d: blocks %zu/%lld failures %lld/%lld rounds %lld job launches %lld (%lld jobs, %lld used) views %lld exchanges %lld diffs %d\n", r, world,
+                        blocks.size(), (long long)nb, (long long)es.failures, (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches,
+                        (long long)es.recomputedSeeds, (long long)es.jobsUsed, (long long)es.viewsBuilt, (long long)es.exchanges, diffs);
+                if (es.exchanges == 0) { fprintf(stderr, "FAIL: no exchange happened\n"); bad++; }
+                bad += diffs;
+            }
         } else { fprintf(stderr, "unknown mode\n"); return 2; }
         return bad ? 1 : 0;
     } catch (std::exception& e) {
