@@ -123,7 +123,7 @@ void lcb_free(void* p);
 lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int device_ordinal);
 /* Tuning knobs of a device; a zero field means "default". Results never depend on them (tests sweep them). */
 typedef struct {
-    uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 6 per CU */
+    uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 5 per CU */
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
     uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
     uint32_t huge_slots;     /* ... of the huge variant (all per-path state in HBM); default 1 per 4 CUs */

@@ -43,7 +43,7 @@ def build_tools():
         s = os.path.join(CSRC, "tools", src)
         o = os.path.join(BIN, name)
         if _newer([s], o):
-            _run(["g++", "-O2", "-std=c++17", "-o", o, s])
+            _run(["g++", "-O2", "-std=c++17", "-fopenmp", "-o", o, s])
 
 
 def hip_flags():

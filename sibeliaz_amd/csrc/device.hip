@@ -9,7 +9,7 @@
 //
 // A launch is (optionally) a screening kernel — one thread per seed decides whether Path::Init would create any
 // instance at all and finalises the header of the seeds for which it would not — followed by the process kernel over
-// the surviving seeds in one of four variants (lcb_kernel.h): compact (1 wavefront per seed, 6 seeds per CU: launches
+// the surviving seeds in one of four variants (lcb_kernel.h): compact (1 wavefront per seed, 5 seeds per CU: launches
 // with many seeds are throughput-bound), wide (16 wavefronts share the votes of one seed: launches with few seeds are
 // as long as their longest seed), big (4096 instances: index, lists and vote table in LDS, instance fields in HBM) and
 // huge (all per-path state in HBM, capacities grown on demand) for seeds that overflow the smaller ones.
@@ -73,35 +73,49 @@ __global__ __launch_bounds__(256) void lcb_init_slots_kernel(uint8_t* base, uint
     for (uint32_t i = threadIdx.x; i < voteCap; i += blockDim.x) { vKey[i] = LCB_EMPTY_KEY; vCount[i] = 0; vLast[i] = 0; }
 }
 
-// Predicted views 1..nViews of the `used` bitmap start as copies of the live state (view 0); stride is a multiple of 4 words.
-__global__ __launch_bounds__(256) void lcb_copy_views_kernel(uint32_t* used, uint32_t strideWords, uint32_t nViews)
-{
-    const uint4* src = (const uint4*)used;
-    const uint32_t n4 = strideWords / 4;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        const uint4 v = src[i];
-        for (uint32_t w = 1; w <= nViews; w++) ((uint4*)(used + (size_t)w * strideWords))[i] = v;
-    }
-}
-
-// MarkUsed over [lo, hi) (junctionstorage.h:285-295) in the views firstView .. lastView: one workgroup per range.
-struct LcbMarkRange { uint64_t lo, hi; uint32_t firstView, lastView; };
-__global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, size_t strideWords, const LcbMarkRange* ranges, uint32_t n)
+// MarkUsed over [lo, hi) (junctionstorage.h:285-295) in the live bitmap: one workgroup per range.
+struct LcbMarkRange { uint64_t lo, hi; };
+__global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const LcbMarkRange* ranges, uint32_t n)
 {
     const uint32_t r = blockIdx.x;
     if (r >= n) return;
     const uint64_t lo = ranges[r].lo, hi = ranges[r].hi;
     if (hi <= lo) return;
     const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
-    for (uint32_t v = ranges[r].firstView; v <= ranges[r].lastView; v++) {
-        uint32_t* u = used + (size_t)v * strideWords;
-        for (uint64_t w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
+    for (uint64_t w = w0 + threadIdx.x; w <= w1; w += blockDim.x) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
+        if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+        atomicOr(&used[w], m);
+    }
+}
+
+// Predicted views are copy-on-write over 4-KB pages of the live bitmap: one workgroup builds one private page — the live
+// page plus the predicted marks of its view that fall into it — and points the view's page table at it. Only pages that a
+// predicted mark touches exist; everything else reads through to the live state (lcb_uword, lcb_kernel.h).
+static_assert(LCB_PAGE_SHIFT == 10u, "lcb_build_view_pages_kernel copies one page as 256 threads x 16 bytes");
+struct LcbViewPage { uint32_t view, page, poolPage, pieceBegin, pieceEnd; };   // pieces [pieceBegin, pieceEnd) of the launch's piece list
+struct LcbViewPiece { uint32_t lo, hi; };                                      // bit range inside the page, [lo, hi)
+__global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(const uint32_t* live, uint32_t* pool, uint32_t* viewTab, uint32_t nPages,
+                                                                   const LcbViewPage* entries, const LcbViewPiece* pieces)
+{
+    const LcbViewPage e = entries[blockIdx.x];
+    const uint4* src = (const uint4*)(live + ((size_t)e.page << LCB_PAGE_SHIFT));
+    uint32_t* dstW = pool + ((size_t)e.poolPage << LCB_PAGE_SHIFT);
+    ((uint4*)dstW)[threadIdx.x] = src[threadIdx.x];            // 256 threads x 16 B = one page
+    __syncthreads();
+    for (uint32_t q = e.pieceBegin; q < e.pieceEnd; q++) {
+        const uint32_t lo = pieces[q].lo, hi = pieces[q].hi;   // hi > lo
+        const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+        for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 256) {
             uint32_t m = 0xFFFFFFFFu;
             if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
             if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
-            atomicOr(&u[w], m);
+            dstW[w] |= m;                                       // pieces of one entry are applied one after the other
         }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) viewTab[(size_t)e.view * nPages + e.page] = 0x80000000u | e.poolPage;
 }
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
@@ -142,9 +156,16 @@ struct lcb_device_impl {
     LcbTables T{};
     LcbKParams KP{};
     std::vector<void*> owned;
-    uint32_t* dUsed = nullptr;
-    size_t usedWords = 0;      // words of one view (a multiple of 4)
-    int maxViews = 0;          // predicted views allocated behind the live bitmap (view 0)
+    uint32_t* dUsed = nullptr;                   // the live bitmap
+    size_t usedWords = 0;                        // its words (a multiple of the page size)
+    uint32_t nPages = 0;
+    int maxViews = 0;                            // predicted views (page tables) available per launch
+    uint32_t* dViewTab = nullptr;                // [(maxViews + 1) * nPages]: 0 = the live page, else 0x80000000 | pool page
+    uint32_t* dPool = nullptr;                   // private pages of the predicted views of the current launch
+    uint32_t poolPages = 0;
+    int lastViews = 0;                           // views whose tables hold entries from the previous build
+    LcbViewPage* dEntries = nullptr; LcbViewPiece* dPieces = nullptr;
+    size_t entryCap = 0, pieceCap = 0;
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
     WorkSet ws[4];                               // compact, wide, big, huge
@@ -174,7 +195,7 @@ struct lcb_device_impl {
     double kernelMs = 0;
     int64_t launches = 0, bigRetries = 0;
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
-    int64_t screened = 0, screenedDead = 0;
+    int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
     int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
@@ -316,8 +337,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, ordinal));
         const uint32_t nCu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        // defaults: compact 6 workgroups per CU (LDS-bound), wide 1 per CU, big 1 per CU
-        if (!o.compact_slots) o.compact_slots = 6 * nCu;
+        // defaults: compact 5 workgroups per CU (LDS-bound), wide 1 per CU, big 1 per CU
+        if (!o.compact_slots) o.compact_slots = 5 * nCu;
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
@@ -348,12 +369,18 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             }
             d->T.occRec = d->upload(rec.data(), rec.size());
         }
-        d->usedWords = ((size_t)(P / 32 + 2) + 3) & ~(size_t)3;
-        // predicted `used` views for the engine's dry-run launches: at most max_views, within 2 GiB
-        d->maxViews = (int)std::min<uint64_t>(o.max_views, (2ull << 30) / (d->usedWords * 4));
-        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4 * (size_t)(d->maxViews + 1)));
+        const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT;
+        d->usedWords = ((size_t)(P / 32 + 2) + pageWords - 1) & ~(pageWords - 1);
+        d->nPages = (uint32_t)(d->usedWords >> LCB_PAGE_SHIFT);
+        // predicted `used` views for the engine's dry-run launches: a page table per view, private pages from a pool that grows on demand
+        d->maxViews = (int)o.max_views;
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
-        d->T.used = d->dUsed; d->T.usedStride = (uint32_t)d->usedWords;
+        HIP_CHECK(hipMalloc((void**)&d->dViewTab, (size_t)(d->maxViews + 1) * d->nPages * 4));
+        HIP_CHECK(hipMemset(d->dViewTab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
+        d->poolPages = 4096;
+        HIP_CHECK(hipMalloc((void**)&d->dPool, (size_t)d->poolPages * pageWords * 4));
+        d->T.used = d->dUsed; d->T.viewTab = d->dViewTab; d->T.viewPool = d->dPool; d->T.nPages = d->nPages;
         d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
@@ -412,6 +439,7 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (getenv("LCB_VERBOSE")) {
             fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
+            fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->poolPages);
             for (int m = 0; m < 4; m++)
                 fprintf(stderr, "   overflows out of %-7s: instances %lld vote table %lld path %lld snapshot %lld\n", modeName(m), (long long)d->overflow[m][LCB_ST_INST_OVF],
                         (long long)d->overflow[m][LCB_ST_VOTE_OVF], (long long)d->overflow[m][LCB_ST_PATH_OVF], (long long)d->overflow[m][LCB_ST_BEST_OVF]);
@@ -420,6 +448,10 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (void* p : d->owned) (void)hipFree(p);
         if (d->dUsed) (void)hipFree(d->dUsed);
+        if (d->dViewTab) (void)hipFree(d->dViewTab);
+        if (d->dPool) (void)hipFree(d->dPool);
+        if (d->dEntries) (void)hipFree(d->dEntries);
+        if (d->dPieces) (void)hipFree(d->dPieces);
         if (d->dCursor) (void)hipFree(d->dCursor);
         if (d->dLive) (void)hipFree(d->dLive);
         for (auto& w : d->ws) if (w.base) (void)hipFree(w.base);
@@ -443,6 +475,7 @@ void lcb_device_reset_used_impl(lcb_device* h)
 {
     lcb_device_impl* d = h->impl;
     d->use();
+    if (d->lastViews) { HIP_CHECK(hipMemsetAsync(d->dViewTab + d->nPages, 0, (size_t)d->lastViews * d->nPages * 4, d->stream)); d->lastViews = 0; }
     d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
     std::fill(d->hintBits.begin(), d->hintBits.end(), 0ull);
     HIP_CHECK(hipMemsetAsync(d->dUsed, 0, d->usedWords * 4, d->stream));
@@ -457,46 +490,75 @@ void lcb_device_set_used_impl(lcb_device* h, const uint32_t* words, int64_t nWor
     HIP_CHECK(hipMemcpy(d->dUsed, words, (size_t)nWords * 4, hipMemcpyHostToDevice));
 }
 
-namespace {
-// Applies ranges [lo, hi) to the views firstView..lastView of each entry, rangeCap entries per kernel; the pinned staging
-// buffer is reused, so each kernel is waited for.
-template <class F>
-void markRanges(lcb_device_impl* d, int64_t n, F fill)
-{
-    for (int64_t done = 0; done < n;) {
-        const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
-        for (uint32_t i = 0; i < m; i++) d->hRanges[i] = fill(done + i);
-        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->usedWords, d->hRanges, m);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        done += m;
-    }
-}
-}  // namespace
-
 void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
 {
     lcb_device_impl* d = h->impl;
     d->use();
     const uint64_t P = d->g->nPos();
     for (int64_t i = 0; i < n; i++) if (ranges[2 * i + 1] > P) throw LcbError("used range beyond the position table");
-    markRanges(d, n, [&](int64_t i) { return LcbMarkRange{ranges[2 * i], ranges[2 * i + 1], 0u, 0u}; });
+    for (int64_t done = 0; done < n;) {
+        const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
+        for (uint32_t i = 0; i < m; i++) d->hRanges[i] = LcbMarkRange{ranges[2 * (done + i)], ranges[2 * (done + i) + 1]};
+        hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));   // the pinned staging buffer is reused
+        done += m;
+    }
 }
 
+// Predicted views 1..nViews = live state + the marks with firstView <= v (engine.cpp): views are nested, so a page that a
+// mark of view v touches is private in the views v..nViews, each with the marks up to its own index.
 void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* marks, int64_t nMarks)
 {
     lcb_device_impl* d = h->impl;
     d->use();
     if (nViews < 0 || nViews > d->maxViews) throw LcbError("more predicted views requested than the device holds");
-    if (nViews == 0) return;
-    const uint32_t n4 = (uint32_t)(d->usedWords / 4);
-    hipLaunchKernelGGL(lcb_copy_views_kernel, dim3(std::min<uint32_t>((n4 + 255) / 256, 2048u)), dim3(256), 0, d->stream, d->dUsed,
-                       (uint32_t)d->usedWords, (uint32_t)nViews);
-    HIP_CHECK(hipGetLastError());
-    // a mark of view v is set in the views v..nViews (the kernel loops over them)
+    if (d->lastViews) HIP_CHECK(hipMemsetAsync(d->dViewTab + d->nPages, 0, (size_t)d->lastViews * d->nPages * 4, d->stream));
+    d->lastViews = nViews;
+    if (nViews == 0 || nMarks == 0) return;
     const uint64_t P = d->g->nPos();
-    for (int64_t k = 0; k < nMarks; k++) if (marks[k].hi > P || marks[k].firstView < 1) throw LcbError("bad predicted mark");
-    markRanges(d, nMarks, [&](int64_t k) { return LcbMarkRange{marks[k].lo, marks[k].hi, marks[k].firstView, (uint32_t)nViews}; });
+    const uint32_t pageBits = 32u << LCB_PAGE_SHIFT;
+    struct Piece { uint32_t page, firstView, lo, hi; };
+    std::vector<Piece> pc;
+    for (int64_t k = 0; k < nMarks; k++) {
+        if (marks[k].hi > P || marks[k].firstView < 1 || marks[k].hi <= marks[k].lo) throw LcbError("bad predicted mark");
+        for (uint64_t a = marks[k].lo; a < marks[k].hi;) {
+            const uint32_t page = (uint32_t)(a / pageBits);
+            const uint64_t end = std::min<uint64_t>(marks[k].hi, (uint64_t)(page + 1) * pageBits);
+            pc.push_back(Piece{page, marks[k].firstView, (uint32_t)(a - (uint64_t)page * pageBits), (uint32_t)(end - (uint64_t)page * pageBits)});
+            a = end;
+        }
+    }
+    std::sort(pc.begin(), pc.end(), [](const Piece& x, const Piece& y) { return x.page != y.page ? x.page < y.page : x.firstView < y.firstView; });
+    std::vector<LcbViewPiece> pieces(pc.size());
+    for (size_t i = 0; i < pc.size(); i++) pieces[i] = LcbViewPiece{pc[i].lo, pc[i].hi};
+    std::vector<LcbViewPage> entries;
+    for (size_t i = 0; i < pc.size();) {
+        size_t j = i;
+        while (j < pc.size() && pc[j].page == pc[i].page) j++;
+        size_t upTo = i;                                    // pieces [i, upTo) have firstView <= v
+        for (uint32_t v = pc[i].firstView; v <= (uint32_t)nViews; v++) {
+            while (upTo < j && pc[upTo].firstView <= v) upTo++;
+            entries.push_back(LcbViewPage{v, pc[i].page, (uint32_t)entries.size(), (uint32_t)i, (uint32_t)upTo});
+        }
+        i = j;
+    }
+    if (entries.size() > d->poolPages) {
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        HIP_CHECK(hipFree(d->dPool)); d->dPool = nullptr;
+        while (d->poolPages < entries.size()) d->poolPages *= 2;
+        HIP_CHECK(hipMalloc((void**)&d->dPool, ((size_t)d->poolPages << LCB_PAGE_SHIFT) * 4));
+        d->T.viewPool = d->dPool;
+    }
+    if (entries.size() > d->entryCap) { if (d->dEntries) HIP_CHECK(hipFree(d->dEntries)); d->entryCap = entries.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dEntries, d->entryCap * sizeof(LcbViewPage))); }
+    if (pieces.size() > d->pieceCap) { if (d->dPieces) HIP_CHECK(hipFree(d->dPieces)); d->pieceCap = pieces.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dPieces, d->pieceCap * sizeof(LcbViewPiece))); }
+    HIP_CHECK(hipMemcpyAsync(d->dEntries, entries.data(), entries.size() * sizeof(LcbViewPage), hipMemcpyHostToDevice, d->stream));
+    HIP_CHECK(hipMemcpyAsync(d->dPieces, pieces.data(), pieces.size() * sizeof(LcbViewPiece), hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(lcb_build_view_pages_kernel, dim3((uint32_t)entries.size()), dim3(256), 0, d->stream, d->dUsed, d->dPool, d->dViewTab, d->nPages,
+                       d->dEntries, d->dPieces);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(d->stream));             // the host vectors above are the copy sources
+    d->viewPagesBuilt += (int64_t)entries.size();
 }
 
 // Three arrays of `bytes` each, `reps` timed sweeps after one warm-up; returns GB/s (3 x bytes per sweep: two reads, one write).

@@ -47,7 +47,8 @@
 
 // Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
-//   mode 0 "compact": 256 instances / 512 vote slots in 26 KB of LDS -> 6 single-wave workgroups per CU (throughput);
+//   mode 0 "compact": 256 instances / 1024 vote slots in 32 KB of LDS -> 5 single-wave workgroups per CU (throughput; with 512
+//                     vote slots 5 % of the seeds of the 62-strain workload overflowed into the wide variant's 256 slots);
 //                     path vertex set in the global workspace behind an LDS Bloom filter
 //   mode 1 "wide":    1024 / 2048 and the path vertex set (8192 slots) in 140 KB of LDS, 16 wavefronts share the votes
 //                     -> 1 workgroup per CU (latency)
@@ -55,7 +56,7 @@
 //   mode 3 "huge":    everything in the global workspace, capacities chosen (and grown) by the host
 // IC instances, VC vote slots, BW Bloom words (0 = none), PC path-set slots in LDS (0 = global workspace)
 template <int MODE> struct LcbCfg;
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 512, BW = 512, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; };
 template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; };
@@ -80,10 +81,20 @@ struct LcbTables {
     const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
     const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
     const uint4* occRec;        // [nPos]  per occurrence, ascending in g: {g, chr, Position::pos, Position::id} (one 16-B load)
-    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx); view v of it starts at used + v * usedStride
-    uint32_t usedStride;        // words between consecutive `used` views (view 0 = the live state, views 1.. = predicted states)
+    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx) — the LIVE state (view 0)
+    // Predicted views 1.. of it (engine.cpp) are copy-on-write at a granularity of 4-KB pages (1024 words, 32768 positions):
+    // viewTab[v * nPages + page] is 0 if view v shares the live page, else 0x80000000 | index of its private page in viewPool.
+    const uint32_t* viewTab;
+    const uint32_t* viewPool;
+    uint32_t nPages;
     uint32_t nChr, nVertex, nPos;
 };
+
+// The `used` state one seed reads: the live bitmap, or a predicted view of it through that view's page table.
+struct LcbUsed { const uint32_t* live; const uint32_t* tab; const uint32_t* pool; };
+#ifndef LCB_PAGE_SHIFT
+#define LCB_PAGE_SHIFT 10u       // words per page = 1024 (the emulator tests also build with tiny pages, so that views span many)
+#endif
 
 struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
 struct LcbKSeed { int32_t vid; int32_t ch; uint32_t view; uint32_t pad; };   // view: which `used` view this seed reads
@@ -211,6 +222,7 @@ template <int MODE_>
 struct LcbStateT {
     static constexpr int MODE = MODE_;
     LcbTables T;
+    LcbUsed U;                 // the `used` state this seed reads
     LcbKParams P;
     uint32_t lane;
     // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
@@ -274,16 +286,34 @@ __device__ __forceinline__ uint32_t lcb_hash(int32_t vid, uint32_t shift)
     return ((uint32_t)vid * 2654435761u) >> shift;
 }
 
-__device__ __forceinline__ bool lcb_used_bit(const uint32_t* used, uint32_t g)
+__device__ __forceinline__ LcbUsed lcb_used_of(const LcbTables& T, uint32_t view)
 {
-    return (used[g >> 5] >> (g & 31)) & 1u;
+    LcbUsed U;
+    U.live = T.used; U.pool = T.viewPool;
+    U.tab = view ? T.viewTab + (size_t)view * T.nPages : nullptr;
+    return U;
+}
+
+// word w of the state (a view costs one more load, of a table entry that stays in the L1/L2 of the CU)
+__device__ __forceinline__ uint32_t lcb_uword(const LcbUsed& U, uint32_t w)
+{
+    if (U.tab) {
+        const uint32_t e = U.tab[w >> LCB_PAGE_SHIFT];
+        if (e) return U.pool[((size_t)(e & 0x7FFFFFFFu) << LCB_PAGE_SHIFT) + (w & ((1u << LCB_PAGE_SHIFT) - 1u))];
+    }
+    return U.live[w];
+}
+
+__device__ __forceinline__ bool lcb_used_bit(const LcbUsed& U, uint32_t g)
+{
+    return (lcb_uword(U, g >> 5) >> (g & 31)) & 1u;
 }
 
 // JunctionSequentialIterator::IsUsed (junctionstorage.h:270-283): `used` marks the edge idx -> idx+1.
-__device__ __forceinline__ bool lcb_it_used(const LcbTables& T, uint32_t g, bool positive, uint32_t lo)
+__device__ __forceinline__ bool lcb_it_used(const LcbUsed& U, uint32_t g, bool positive, uint32_t lo)
 {
-    if (positive) return lcb_used_bit(T.used, g);
-    return g > lo ? lcb_used_bit(T.used, g - 1) : false;
+    if (positive) return lcb_used_bit(U, g);
+    return g > lo ? lcb_used_bit(U, g - 1) : false;
 }
 
 // JunctionSequentialIterator::GetChar (junctionstorage.h:234-243)
@@ -294,20 +324,20 @@ __device__ __forceinline__ uint8_t lcb_it_char(const LcbTables& T, uint32_t g, b
 
 // Any used bit in [a, b)?  This is the `used` walk of Path::Compatible (path.h:387-393) for both strands:
 // + strand visits bits a..b-1 going up, - strand visits bits b-1..a going down.
-__device__ inline bool lcb_range_any_used(const uint32_t* used, uint32_t a, uint32_t b)
+__device__ inline bool lcb_range_any_used(const LcbUsed& U, uint32_t a, uint32_t b)
 {
     if (a >= b) return false;
     const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
     const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-    if (wa == wb) return (used[wa] & ma & mb) != 0;
-    if (used[wa] & ma) return true;
+    if (wa == wb) return (lcb_uword(U, wa) & ma & mb) != 0;
+    if (lcb_uword(U, wa) & ma) return true;
     for (uint32_t w = wa + 1; w < wb; w++)
-        if (used[w]) return true;
-    return (used[wb] & mb) != 0;
+        if (lcb_uword(U, w)) return true;
+    return (lcb_uword(U, wb) & mb) != 0;
 }
 
 // Number of iterations the reference's walk makes over [a, b) (stats mode only).
-__device__ inline uint32_t lcb_range_walk_steps(const uint32_t* used, uint32_t a, uint32_t b, bool up)
+__device__ inline uint32_t lcb_range_walk_steps(const LcbUsed& used, uint32_t a, uint32_t b, bool up)
 {
     uint32_t steps = 0;
     if (up) { for (uint32_t g = a; g < b; g++) { steps++; if (lcb_used_bit(used, g)) break; } }
@@ -459,7 +489,7 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
             g = rec.x; chr = rec.y; pos = rec.z;
             lo = T.chrStart[chr]; hi = T.chrStart[chr + 1];
             positive = ((int32_t)rec.w == vid);
-            ok = !lcb_it_used(T, g, positive, lo) && (int32_t)lcb_it_char(T, g, positive) == ch;
+            ok = !lcb_it_used(S.U, g, positive, lo) && (int32_t)lcb_it_char(T, g, positive) == ch;
         }
         const unsigned long long m = __ballot(ok);
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -554,7 +584,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             w.id = T.posId[w.g];
             // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
             const uint32_t ub = w.g - (v.positive ? 0u : 1u);
-            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = T.used[ub >> 5] >> (ub & 31);
+            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, ub >> 5) >> (ub & 31);
         }
         return w;
     };
@@ -755,7 +785,7 @@ __device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, uint32_t j, bo
     return r;
 }
 
-__device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const uint4& rec, bool active)
+__device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const LcbUsed& U, const uint4& rec, bool active)
 {
     LcbOcc o;
     o.rec = rec; o.lo = 0; o.hi = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
@@ -763,7 +793,7 @@ __device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const uint4
         o.lo = T.chrStart[rec.y]; o.hi = T.chrStart[rec.y + 1];
         const uint32_t wi = rec.x >> 5;
         o.wbase = wi ? wi - 1 : 0;
-        o.uw0 = T.used[o.wbase]; o.uw1 = T.used[o.wbase + 1]; o.uw2 = T.used[o.wbase + 2];
+        o.uw0 = lcb_uword(U, o.wbase); o.uw1 = lcb_uword(U, o.wbase + 1); o.uw2 = lcb_uword(U, o.wbase + 2);
     }
     return o;
 }
@@ -776,11 +806,11 @@ __device__ __forceinline__ bool lcb_occ_bit(const LcbOcc& o, uint32_t g)
 }
 
 // lcb_range_any_used over [a, b), served from the cached words when the range lies inside them.
-__device__ inline bool lcb_range_any_used_c(const LcbTables& T, const LcbOcc& o, uint32_t a, uint32_t b)
+__device__ inline bool lcb_range_any_used_c(const LcbUsed& U, const LcbOcc& o, uint32_t a, uint32_t b)
 {
     if (a >= b) return false;
     const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
-    if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(T.used, a, b);
+    if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(U, a, b);
     const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
     const uint32_t ia = wa - o.wbase, ib = wb - o.wbase;
     uint32_t acc = 0;
@@ -813,7 +843,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
     const uint32_t o0 = E.o0, o1 = E.o1;
     // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
-    LcbOcc occ = lcb_finish_occ(T, rec0, o0 + S.lane < o1);
+    LcbOcc occ = lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
     bool inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
     if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
     if (inPath) return false;
@@ -836,7 +866,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         bool positive = false, usedS = false, usesP = false;
-        if (base != o0) occ = lcb_finish_occ(T, lcb_load_rec(T, j, active), active);
+        if (base != o0) occ = lcb_finish_occ(T, S.U, lcb_load_rec(T, j, active), active);
         if (active) {
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
@@ -876,7 +906,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                         const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
                         const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
                         const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
-                        if (STATS) stStep = lcb_range_walk_steps(T.used, ga, gb, positive);
+                        if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
                         bool okDist = realDiff >= 0;
                         if (okDist && (realDiff > B || ancestralDiff > B)) {
                             // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
@@ -888,7 +918,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                                 okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
                             }
                         }
-                        compat = okDist && !lcb_range_any_used_c(T, occ, ga, gb);
+                        compat = okDist && !lcb_range_any_used_c(S.U, occ, ga, gb);
                         // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
                         // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
                         // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
@@ -936,7 +966,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             const uint32_t posT = lcb_bcast(positive ? 1u : 0u, t);
             if (active && usesP && prior && !(extXM & below & ~((1ull << s0) - 1)) && act != LCB_ACT_SKIP) {
                 stCall = 1;
-                stStep = (posT != 0) == positive ? lcb_range_walk_steps(T.used, gT, g, positive) : 0u;
+                stStep = (posT != 0) == positive ? lcb_range_walk_steps(S.U, gT, g, positive) : 0u;
             }
             S.cCompatCall += stCall; S.cCompatStep += stStep;
         }
@@ -1286,7 +1316,7 @@ struct LcbLaunchArgs {
     uint32_t* cursor;
     const uint32_t* live;
     uint32_t cursorBase, nSeeds;
-    const uint32_t* usedView;      // `used` view of the seed wave 0 is working on (read by the helpers at each vote)
+    const uint32_t* usedTab;       // page table of the `used` view of the seed wave 0 is working on (read by the helpers at each vote)
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
@@ -1324,7 +1354,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     }
 
     LcbStateT<MODE> S;
-    S.T = T; S.P = P;
+    S.T = T; S.P = P; S.U = lcb_used_of(T, 0);
     S.lane = threadIdx.x & 63u;
     uint8_t* slot = W.base + (uint64_t)blockIdx.x * W.slotBytes;
     const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, INST_LDS ? 0 : W.instCap, IDX_LDS ? 0 : W.voteCap);
@@ -1381,7 +1411,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             for (;;) {
                 __syncthreads();                                   // A
                 if (lcb_rfl(S.mail[LCB_MAIL_CMD]) == LCB_CMD_EXIT) return;
-                S.T.used = sArgs.usedView;
+                S.U.tab = sArgs.usedTab;
                 const uint32_t flags = lcb_rfl(S.mail[LCB_MAIL_FLAGS]);
                 S.nTouch = lcb_rfl(S.mail[LCB_MAIL_NTOUCH]);
                 S.cWalk = 0;
@@ -1418,8 +1448,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         const uint64_t tick0 = PROF ? wall_clock64() : 0;
         const LcbKSeed sd = sArgs.seeds[s];
         const int32_t vid = lcb_rfl(sd.vid), ch = lcb_rfl(sd.ch);
-        S.T.used = T.used + (size_t)lcb_rfl(sd.view) * T.usedStride;
-        if (NW > 1 && S.lane == 0) sArgs.usedView = S.T.used;     // published to the helpers by the vote's first barrier
+        S.U = lcb_used_of(T, lcb_rfl(sd.view));
+        if (NW > 1 && S.lane == 0) sArgs.usedTab = S.U.tab;      // published to the helpers by the vote's first barrier
         lcb_process_seed<MODE, STATS, PROF, NW>(S, vid, ch, bestScore);
         if (S.status == LCB_ST_VOTE_OVF) {
             // the vote table may hold stale keys after an overflow (the helpers have cleared their slices; wave 0 wipes all)
@@ -1490,7 +1520,7 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
     bool alive = false;
     if (s < nSeeds) {
         const LcbKSeed sd = seeds[s];
-        const uint32_t* used = T.used + (size_t)sd.view * T.usedStride;
+        const LcbUsed used = lcb_used_of(T, sd.view);
         const uint32_t av = (uint32_t)(sd.vid < 0 ? -sd.vid : sd.vid);
         const uint32_t o1 = T.occStart[av + 1];
         for (uint32_t j = T.occStart[av]; j < o1 && !alive; j++) {

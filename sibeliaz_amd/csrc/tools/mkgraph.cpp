@@ -11,6 +11,7 @@
 // predecessor characters over both strands of the whole input, or the occurrence class touches a
 // sequence end / a non-ACGT character. id = 1-based rank of the canonical k-mer in order of first
 // appearance among junctions; the sign is + iff the occurrence spells the canonical form.
+// The k-mer table is filled by all cores (OpenMP, lock-free open addressing); the output does not depend on the thread count.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -19,8 +20,17 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <chrono>
 
 namespace {
+
+double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+const bool kVerbose = getenv("LCB_MKGRAPH_VERBOSE") != nullptr;
+#define PHASE(name) do { if (kVerbose) { const double t_ = nowS(); fprintf(stderr, "lcb-mkgraph: %-28s %.2f s\n", name, t_ - tPhase); tPhase = t_; } } while (0)
+
 
 struct Record { std::string name; std::string seq; };
 
@@ -53,51 +63,57 @@ inline int code(char c) {
     return -1;
 }
 
-// Open-addressing map canonical k-mer -> {succ mask(4) | pred mask(4) << 4 | forced << 8}, junction id.
+// Open-addressing map canonical k-mer -> {succ mask(4) | pred mask(4) << 4 | forced << 8}, junction id. Fixed capacity,
+// filled concurrently: a slot is claimed with a compare-and-swap on its key, the masks are OR-ed in atomically.
 struct KmerTable {
-    std::vector<uint64_t> key;   // code + 1, 0 = empty
-    std::vector<uint16_t> val;
+    std::vector<std::atomic<uint64_t>> key;   // code + 1, 0 = empty
+    std::vector<std::atomic<uint32_t>> val;
     std::vector<uint32_t> id;
-    size_t used = 0, mask = 0;
-    explicit KmerTable(size_t cap) { resize(cap); }
+    std::atomic<size_t> used{0};
+    size_t mask = 0;
+    explicit KmerTable(size_t cap) : key(cap), val(cap), mask(cap - 1)
+    {
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < cap; i++) { key[i].store(0, std::memory_order_relaxed); val[i].store(0, std::memory_order_relaxed); }
+    }
     static uint64_t mix(uint64_t x) {
         x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
         return x;
     }
-    void resize(size_t cap) {
-        std::vector<uint64_t> ok; ok.swap(key);
-        std::vector<uint16_t> ov; ov.swap(val);
-        key.assign(cap, 0); val.assign(cap, 0); mask = cap - 1; used = 0;
-        for (size_t i = 0; i < ok.size(); i++) if (ok[i]) val[slot(ok[i] - 1, true)] = ov[i];
-    }
-    size_t slot(uint64_t kmer, bool insert) {
-        size_t h = mix(kmer) & mask;
-        for (;; h = (h + 1) & mask) {
-            if (key[h] == kmer + 1) return h;
-            if (key[h] == 0) {
-                if (!insert) return SIZE_MAX;
-                key[h] = kmer + 1; used++;
-                return h;
-            }
+    size_t find(uint64_t kmer) const {
+        for (size_t h = mix(kmer) & mask;; h = (h + 1) & mask) {
+            const uint64_t k = key[h].load(std::memory_order_relaxed);
+            if (k == kmer + 1) return h;
+            if (k == 0) return SIZE_MAX;
         }
     }
-    void add(uint64_t kmer, uint16_t bits) {
-        if ((used + 1) * 10 > (mask + 1) * 6) resize((mask + 1) * 2);
-        val[slot(kmer, true)] |= bits;
+    // false: the table is too full (the caller starts over with a larger one)
+    bool add(uint64_t kmer, uint32_t bits) {
+        for (size_t h = mix(kmer) & mask;; h = (h + 1) & mask) {
+            uint64_t k = key[h].load(std::memory_order_relaxed);
+            if (k == 0) {
+                if (key[h].compare_exchange_strong(k, kmer + 1, std::memory_order_relaxed)) {
+                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 7) return false;
+                    k = kmer + 1;
+                }
+            }
+            if (k == kmer + 1) { val[h].fetch_or(bits, std::memory_order_relaxed); return true; }
+        }
     }
 };
 
-inline bool isJunction(uint16_t v) {
+inline bool isJunction(uint32_t v) {
     return (v & 0x100) || __builtin_popcount(v & 0xF) >= 2 || __builtin_popcount((v >> 4) & 0xF) >= 2;
 }
 
-// Calls fn(pos, fwdCode, rcCode) for every k-mer window of seq made of ACGT only.
+// Calls fn(pos, fwdCode, rcCode) for every k-mer window of seq made of ACGT only whose start lies in [from, to).
 template <class F>
-void forEachKmer(const std::string& seq, int k, F fn) {
+void forEachKmer(const std::string& seq, int k, size_t from, size_t to, F fn) {
     const uint64_t m = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     uint64_t fwd = 0, rc = 0;
     int valid = 0;
-    for (size_t i = 0; i < seq.size(); i++) {
+    const size_t stop = std::min(seq.size(), to + (size_t)k - 1);
+    for (size_t i = from; i < stop; i++) {
         int c = code(seq[i]);
         if (c < 0) { valid = 0; fwd = rc = 0; continue; }
         fwd = ((fwd << 2) | (uint64_t)c) & m;
@@ -123,50 +139,95 @@ int main(int argc, char** argv) {
         return 2;
     }
     try {
+        double tPhase = nowS();
         std::vector<Record> rec;
         for (auto& f : fasta) readFasta(f, rec);
+        PHASE("read FASTA");
 
-        KmerTable table(1 << 20);
-        for (auto& r : rec) {
-            const std::string& s = r.seq;
-            forEachKmer(s, k, [&](size_t p, uint64_t fwd, uint64_t rc) {
-                const int nx = p + k < s.size() ? code(s[p + k]) : -1;
-                const int pv = p > 0 ? code(s[p - 1]) : -1;
-                uint16_t bits = (nx < 0 || pv < 0) ? 0x100 : 0;
-                if (fwd < rc) {
-                    if (nx >= 0) bits |= 1u << nx;
-                    if (pv >= 0) bits |= 1u << (4 + pv);
-                    table.add(fwd, bits);
-                } else {
-                    if (pv >= 0) bits |= 1u << (3 - pv);
-                    if (nx >= 0) bits |= 1u << (4 + 3 - nx);
-                    table.add(rc, bits);
-                }
+        // work units: chunks of sequence starts, so that all cores share one long chromosome
+        struct Chunk { uint32_t rec; size_t from, to; };
+        std::vector<Chunk> chunks;
+        size_t nWindows = 0;
+        for (size_t r = 0; r < rec.size(); r++) {
+            const size_t n = rec[r].seq.size() >= (size_t)k ? rec[r].seq.size() - k + 1 : 0;
+            nWindows += n;
+            for (size_t a = 0; a < n; a += (1u << 20)) chunks.push_back(Chunk{(uint32_t)r, a, std::min(n, a + (1u << 20))});
+        }
+        size_t cap = 1 << 20;
+        while (cap < nWindows / 2) cap <<= 1;
+        std::unique_ptr<KmerTable> tp;
+        for (;; cap <<= 1) {
+            tp.reset(new KmerTable(cap));
+            KmerTable& table = *tp;
+            bool full = false;
+            #pragma omp parallel for schedule(dynamic, 1)
+            for (size_t c = 0; c < chunks.size(); c++) {
+                if (full) continue;
+                const std::string& s = rec[chunks[c].rec].seq;
+                forEachKmer(s, k, chunks[c].from, chunks[c].to, [&](size_t p, uint64_t fwd, uint64_t rc) {
+                    const int nx = p + k < s.size() ? code(s[p + k]) : -1;
+                    const int pv = p > 0 ? code(s[p - 1]) : -1;
+                    uint32_t bits = (nx < 0 || pv < 0) ? 0x100 : 0;
+                    bool ok;
+                    if (fwd < rc) {
+                        if (nx >= 0) bits |= 1u << nx;
+                        if (pv >= 0) bits |= 1u << (4 + pv);
+                        ok = table.add(fwd, bits);
+                    } else {
+                        if (pv >= 0) bits |= 1u << (3 - pv);
+                        if (nx >= 0) bits |= 1u << (4 + 3 - nx);
+                        ok = table.add(rc, bits);
+                    }
+                    if (!ok) full = true;
+                });
+            }
+            if (!full) break;
+        }
+        KmerTable& table = *tp;
+        PHASE("k-mer table");
+
+        // junction occurrences of every chunk (parallel), then ids in order of first appearance and the records (in order)
+        struct Occ { uint32_t pos; uint32_t slotLo; uint8_t slotHi; uint8_t fwd; };
+        std::vector<std::vector<Occ>> found(chunks.size());
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (size_t c = 0; c < chunks.size(); c++) {
+            forEachKmer(rec[chunks[c].rec].seq, k, chunks[c].from, chunks[c].to, [&](size_t p, uint64_t fwd, uint64_t rc) {
+                const bool isFwd = fwd < rc;
+                const size_t h = table.find(isFwd ? fwd : rc);
+                if (!isJunction(table.val[h].load(std::memory_order_relaxed))) return;
+                found[c].push_back(Occ{(uint32_t)p, (uint32_t)h, (uint8_t)(h >> 32), (uint8_t)isFwd});
             });
         }
-
-        table.id.assign(table.key.size(), 0);
+        PHASE("junction occurrences");
+        table.id.assign(cap, 0);
         uint32_t nextId = 1;
         uint64_t written = 0;
         FILE* f = fopen(out.c_str(), "wb");
         if (!f) throw std::runtime_error("cannot create " + out);
+        std::vector<unsigned char> buf;
+        auto flushBuf = [&]() { if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("cannot write " + out); buf.clear(); };
         auto put = [&](uint32_t pos, int64_t id) {
-            unsigned char b[12];
-            memcpy(b, &pos, 4); memcpy(b + 4, &id, 8);
-            if (fwrite(b, 1, 12, f) != 12) throw std::runtime_error("cannot write " + out);
+            const size_t at = buf.size();
+            buf.resize(at + 12);
+            memcpy(&buf[at], &pos, 4); memcpy(&buf[at + 4], &id, 8);
+            if (buf.size() >= (64u << 20)) flushBuf();
         };
-        for (auto& r : rec) {
-            forEachKmer(r.seq, k, [&](size_t p, uint64_t fwd, uint64_t rc) {
-                const bool isFwd = fwd < rc;
-                const size_t h = table.slot(isFwd ? fwd : rc, false);
-                if (!isJunction(table.val[h])) return;
-                if (!table.id[h]) table.id[h] = nextId++;
-                put((uint32_t)p, isFwd ? (int64_t)table.id[h] : -(int64_t)table.id[h]);
-                written++;
-            });
+        size_t c = 0;
+        for (size_t r = 0; r < rec.size(); r++) {
+            for (; c < chunks.size() && chunks[c].rec == r; c++) {
+                for (const Occ& o : found[c]) {
+                    const size_t h = ((size_t)o.slotHi << 32) | o.slotLo;
+                    if (!table.id[h]) table.id[h] = nextId++;
+                    put(o.pos, o.fwd ? (int64_t)table.id[h] : -(int64_t)table.id[h]);
+                    written++;
+                }
+                std::vector<Occ>().swap(found[c]);
+            }
             put(0xFFFFFFFFu, INT64_MAX);
         }
+        flushBuf();
         fclose(f);
+        PHASE("ids + records");
         fprintf(stderr, "lcb-mkgraph: %zu records, %llu junction occurrences, %u junction k-mers\n",
                 rec.size(), (unsigned long long)written, nextId - 1);
     } catch (std::exception& e) {

@@ -49,8 +49,9 @@ struct EmuCtx {
 struct Emu {
     const lcb_graph* g;
     lcb_params p;
-    std::vector<uint32_t> chrStart32, used;      // used: view 0 (live) followed by the predicted views
-    size_t usedWords = 0;
+    std::vector<uint32_t> chrStart32, used;      // used: the live bitmap (view 0), padded to whole pages
+    std::vector<uint32_t> viewTab, viewPool;     // predicted views: page tables (0 = live page, else 0x80000000 | pool page) and their private pages
+    size_t usedWords = 0, nPages = 0;
     int nViewsAlloc = 0;
     LcbTables T;
     LcbKParams KP;
@@ -68,13 +69,16 @@ struct Emu {
     Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode >= 2)
     {
         chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
-        usedWords = g->nPos() / 32 + 2;
+        const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT;
+        usedWords = ((g->nPos() / 32 + 2) + pageWords - 1) & ~(pageWords - 1);
+        nPages = usedWords >> LCB_PAGE_SHIFT;
         used.assign(usedWords, 0);
+        viewTab.assign(nPages, 0); viewPool.assign(pageWords, 0);
         T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
         T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
         occRec.resize(g->nPos());
         for (size_t j = 0; j < occRec.size(); j++) { const uint32_t q = g->occG[j]; occRec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]}; }
-        T.occRec = occRec.data(); T.used = used.data(); T.usedStride = (uint32_t)usedWords;
+        T.occRec = occRec.data(); T.used = used.data(); T.viewTab = viewTab.data(); T.viewPool = viewPool.data(); T.nPages = (uint32_t)nPages;
         T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
         const char* te = getenv("EMU_THREADS");
@@ -101,17 +105,30 @@ struct Emu {
         }
     }
 
-    // predicted views 1..nViews = live state + the marks whose firstView <= v
+    // predicted views 1..nViews = live state + the marks whose firstView <= v, copy-on-write over pages like the product's
+    // device (device.hip): a page that a mark of view v touches gets a private copy in each of the views v..nViews
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks)
     {
-        used.resize(usedWords * (size_t)(nViews + 1));
-        T.used = used.data();
-        for (int v = 1; v <= nViews; v++) {
-            uint32_t* w = used.data() + usedWords * (size_t)v;
-            memcpy(w, used.data(), usedWords * 4);
-            for (int64_t m = 0; m < nMarks; m++)
-                if ((int)marks[m].firstView <= v) for (uint64_t q = marks[m].lo; q < marks[m].hi; q++) w[q >> 5] |= 1u << (q & 31);
-        }
+        const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT, pageBits = pageWords * 32;
+        viewTab.assign((size_t)(nViews + 1) * nPages, 0);
+        viewPool.assign(pageWords, 0);                           // pool page 0 is never referenced (an entry of 0 means "live")
+        for (int v = 1; v <= nViews; v++)
+            for (int64_t m = 0; m < nMarks; m++) {
+                if ((int)marks[m].firstView > v) continue;
+                for (uint64_t q = marks[m].lo; q < marks[m].hi; q++) {
+                    const size_t page = q / pageBits;
+                    uint32_t& e = viewTab[(size_t)v * nPages + page];
+                    if (!e) {
+                        const size_t pp = viewPool.size() / pageWords;
+                        viewPool.resize(viewPool.size() + pageWords);
+                        memcpy(&viewPool[pp * pageWords], &used[page * pageWords], pageWords * 4);
+                        e = 0x80000000u | (uint32_t)pp;
+                    }
+                    const size_t w = (size_t)(e & 0x7FFFFFFFu) * pageWords + (q % pageBits) / 32;
+                    viewPool[w] |= 1u << (q & 31);
+                }
+            }
+        T.viewTab = viewTab.data(); T.viewPool = viewPool.data();
         nViewsAlloc = nViews;
     }
 
@@ -213,6 +230,7 @@ struct Emu {
         if (again.empty() || mode >= 3) return;
         if (!next) next.reset(new Emu(g, p, mode + 1));
         next->used = used; next->T.used = next->used.data(); next->nViewsAlloc = nViewsAlloc;
+        next->viewTab = viewTab; next->viewPool = viewPool; next->T.viewTab = next->viewTab.data(); next->T.viewPool = next->viewPool.data();
         std::vector<LcbKSeed> sub;
         for (size_t i : again) sub.push_back(seeds[i]);
         next->runRetry(sub);
@@ -267,7 +285,7 @@ struct EmuProcessor : LcbProcessor {
     {
         for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
     }
-    void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; }
+    void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }

@@ -177,3 +177,29 @@ def test_cli_drop_in(built, case, tmp_path):
     if "chunks4" in case.meta["sha256"]:
         import hashlib
         assert hashlib.sha256(chunks).hexdigest() == case.meta["sha256"]["chunks4"]
+
+
+def test_rccl_exchange_path_single_rank(built, case):
+    """The native multi-rank path on the one GPU of the test box: an RCCL communicator of world 1 (ncclCommInitRank), every
+    launch packed, all-gathered with ncclAllGather through device staging buffers and unpacked (exchange_always), identical
+    commit. Same blocks as the reference. (More ranks need more GPUs: RCCL refuses two ranks on one device; the multi-rank
+    logic itself runs with 2-4 ranks under the emulator and over gloo in the CPU suite.)"""
+    st, p, dev = _setup(case)
+    comm = sibeliaz_amd.Comm(dev, sibeliaz_amd.Comm.unique_id(), 0, 1)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, comm=comm, exchange_always=1)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    assert finder.stats["exchanges"] > 0
+    comm.close()
+
+
+def test_find_blocks_gpus_one_process(built, case):
+    """lcb_find_blocks_gpus (what sibeliaz-lcb does with LCB_GPUS=N): devices, ncclCommInitAll and one host thread per GPU
+    inside one process — with the single GPU of the test box, forced through the exchange path."""
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, threads=4, abundance=case.a)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocksGpus(case.m, case.b, [0], threads=4, exchange_always=1)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    assert finder.stats["exchanges"] > 0

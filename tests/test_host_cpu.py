@@ -151,6 +151,9 @@ def emu_built():
                                             ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SHARE": "1"}),
                                             ("inv_k25", "huge", {"EMU_NW": "4", "EMU_LIMIT": "200"}),
                                             ("collinear6", "seeds-init", {"EMU_NW": "4", "EMU_LIMIT": "100", "EMU_SHARE": "1"}),
+                                            # predicted `used` views spanning many copy-on-write pages (the EMU_SHARE build has 128-position pages)
+                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
+                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
