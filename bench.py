@@ -57,6 +57,14 @@ WORKLOADS = {
     "ecoli10": _wl(10, 1200, 1001, "10 synthetic E. coli-like strains (45 Mbp), k=15, b=200, m=50, a=150 [BASELINE configs[1]; SURVEY.md §8d config 2, lcb-synth seed 1001]"),
     "ecoli10_small": _wl(10, 120, 1001, "10 synthetic strains (4.5 Mbp: config 2 with 1/10 of the segments), k=15, b=200, m=50, a=150"),
     "ecoli10_tiny": _wl(10, 30, 1001, "10 synthetic strains (1.1 Mbp), k=15, b=200, m=50, a=150"),
+    # SURVEY.md §8d configs 4 / 5 (k=25, many chromosomes, repeat families that exercise the abundance filter), scaled to what one
+    # box generates in about a minute: 8 x 24 chromosomes x ~6.5 Mbp = 1.24 Gbp and 16 x 20 x ~3.2 Mbp = 1.0 Gbp
+    "primates8_scaled": dict(synth="--strains 8 --chromosomes 24 --segments 1200 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "
+                                   "--indel 0.001 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1003",
+                             k=25, b=200, m=50, a=150, desc="8 synthetic strains x 24 chromosomes (1.24 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 4, scaled]"),
+    "mice16_scaled": dict(synth="--strains 16 --chromosomes 20 --segments 600 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.005 "
+                                "--indel 0.0005 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1004",
+                          k=25, b=200, m=50, a=150, desc="16 synthetic strains x 20 chromosomes (1.0 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 5, scaled]"),
     # same genomes as config 2, other parameters (k=25, b=400, m=100)
     "ecoli10_k25": _wl(10, 1200, 1001, "10 synthetic E. coli-like strains (45 Mbp), k=25, b=400, m=100, a=150", k=25, b=400, m=100),
 }

@@ -43,7 +43,9 @@
 #ifndef LCB_NW_BIG
 #define LCB_NW_BIG 8
 #endif
+#ifndef LCB_NW_COMPACT
 #define LCB_NW_COMPACT 1
+#endif
 #define LCB_NW_HUGE 8
 // PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
 template <int MODE, bool STATS, int NW, bool PROF>
@@ -96,12 +98,12 @@ __global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const Lcb
 static_assert(LCB_PAGE_SHIFT == 10u, "lcb_build_view_pages_kernel copies one page as 256 threads x 16 bytes");
 struct LcbViewPage { uint32_t view, page, poolPage, pieceBegin, pieceEnd; };   // pieces [pieceBegin, pieceEnd) of the launch's piece list
 struct LcbViewPiece { uint32_t lo, hi; };                                      // bit range inside the page, [lo, hi)
-__global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(const uint32_t* live, uint32_t* pool, uint32_t* viewTab, uint32_t nPages,
+__global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* live, uint32_t liveWords, uint32_t* viewTab, uint32_t nPages,
                                                                    const LcbViewPage* entries, const LcbViewPiece* pieces)
 {
     const LcbViewPage e = entries[blockIdx.x];
     const uint4* src = (const uint4*)(live + ((size_t)e.page << LCB_PAGE_SHIFT));
-    uint32_t* dstW = pool + ((size_t)e.poolPage << LCB_PAGE_SHIFT);
+    uint32_t* dstW = live + liveWords + ((size_t)e.poolPage << LCB_PAGE_SHIFT);      // the pool lies behind the live bitmap
     ((uint4*)dstW)[threadIdx.x] = src[threadIdx.x];            // 256 threads x 16 B = one page
     __syncthreads();
     for (uint32_t q = e.pieceBegin; q < e.pieceEnd; q++) {
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(const uint32_
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) viewTab[(size_t)e.view * nPages + e.page] = 0x80000000u | e.poolPage;
+    // word offset from the live page to this copy (lcb_uword adds it to the word index)
+    if (threadIdx.x == 0) viewTab[(size_t)e.view * nPages + e.page] = liveWords + (e.poolPage << LCB_PAGE_SHIFT) - (e.page << LCB_PAGE_SHIFT);
 }
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
@@ -160,14 +163,14 @@ struct lcb_device_impl {
     size_t usedWords = 0;                        // its words (a multiple of the page size)
     uint32_t nPages = 0;
     int maxViews = 0;                            // predicted views (page tables) available per launch
-    uint32_t* dViewTab = nullptr;                // [(maxViews + 1) * nPages]: 0 = the live page, else 0x80000000 | pool page
-    uint32_t* dPool = nullptr;                   // private pages of the predicted views of the current launch
-    uint32_t poolPages = 0;
+    uint32_t* dViewTab = nullptr;                // [(maxViews + 1) * nPages]: word offset from a live page to the view's copy (0 = shared)
+    uint32_t poolPages = 0;                      // private pages of the predicted views of the current launch, behind the live bitmap in dUsed
     int lastViews = 0;                           // views whose tables hold entries from the previous build
     LcbViewPage* dEntries = nullptr; LcbViewPiece* dPieces = nullptr;
     size_t entryCap = 0, pieceCap = 0;
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
+    uint32_t* hLive = nullptr;                   // ... copied to the host after the launch, [batchCap + 1]: the last word is their number
     WorkSet ws[4];                               // compact, wide, big, huge
     // pinned, device-mapped host buffers
     LcbKSeed* hSeeds = nullptr;
@@ -248,7 +251,7 @@ struct lcb_device_impl {
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
-        if (watchdogS > 0 && !screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // lets the watchdog name unfinished seeds
+        if (watchdogS > 0 || screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // unfinished seeds can be named (and a header nobody wrote is noticed)
         HIP_CHECK(hipMemsetAsync(dCursor, 0, 32, stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         if (screen) {
@@ -267,6 +270,10 @@ struct lcb_device_impl {
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ev1, stream));
+        if (screen) {      // the host only looks at the seeds that survived the screening
+            HIP_CHECK(hipMemcpyAsync(hLive + batchCap, dCursor + 1, 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(hLive, dLive, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+        }
         if (watchdogS > 0) {
             // bounded wait: a kernel that does not finish is reported with its flight recorder instead of hanging the caller
             const auto t0 = std::chrono::steady_clock::now();
@@ -374,13 +381,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->nPages = (uint32_t)(d->usedWords >> LCB_PAGE_SHIFT);
         // predicted `used` views for the engine's dry-run launches: a page table per view, private pages from a pool that grows on demand
         d->maxViews = (int)o.max_views;
-        HIP_CHECK(hipMalloc((void**)&d->dUsed, d->usedWords * 4));
+        d->poolPages = 4096;
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, (d->usedWords + (size_t)d->poolPages * pageWords) * 4));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
         HIP_CHECK(hipMalloc((void**)&d->dViewTab, (size_t)(d->maxViews + 1) * d->nPages * 4));
         HIP_CHECK(hipMemset(d->dViewTab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
-        d->poolPages = 4096;
-        HIP_CHECK(hipMalloc((void**)&d->dPool, (size_t)d->poolPages * pageWords * 4));
-        d->T.used = d->dUsed; d->T.viewTab = d->dViewTab; d->T.viewPool = d->dPool; d->T.nPages = d->nPages;
+        d->T.used = d->dUsed; d->T.viewTab = d->dViewTab; d->T.nPages = d->nPages;
         d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
@@ -408,6 +414,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->allocWork(hg);
         d->batchCap = o.batch;
         HIP_CHECK(hipMalloc((void**)&d->dLive, (size_t)d->batchCap * sizeof(uint32_t)));
+        HIP_CHECK(hipHostMalloc((void**)&d->hLive, ((size_t)d->batchCap + 1) * sizeof(uint32_t), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
@@ -449,11 +456,11 @@ void lcb_device_destroy_impl(lcb_device* h)
         for (void* p : d->owned) (void)hipFree(p);
         if (d->dUsed) (void)hipFree(d->dUsed);
         if (d->dViewTab) (void)hipFree(d->dViewTab);
-        if (d->dPool) (void)hipFree(d->dPool);
         if (d->dEntries) (void)hipFree(d->dEntries);
         if (d->dPieces) (void)hipFree(d->dPieces);
         if (d->dCursor) (void)hipFree(d->dCursor);
         if (d->dLive) (void)hipFree(d->dLive);
+        if (d->hLive) (void)hipHostFree(d->hLive);
         for (auto& w : d->ws) if (w.base) (void)hipFree(w.base);
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
@@ -544,17 +551,22 @@ void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* m
         i = j;
     }
     if (entries.size() > d->poolPages) {
+        // the pool lies behind the live bitmap in one allocation (a table entry is a word offset): grow = move the live state
         HIP_CHECK(hipStreamSynchronize(d->stream));
-        HIP_CHECK(hipFree(d->dPool)); d->dPool = nullptr;
-        while (d->poolPages < entries.size()) d->poolPages *= 2;
-        HIP_CHECK(hipMalloc((void**)&d->dPool, ((size_t)d->poolPages << LCB_PAGE_SHIFT) * 4));
-        d->T.viewPool = d->dPool;
+        uint32_t np = d->poolPages;
+        while (np < entries.size()) np *= 2;
+        if (d->usedWords + ((uint64_t)np << LCB_PAGE_SHIFT) >= (1ull << 32)) throw LcbError("predicted views need more private pages than a 32-bit word offset reaches");
+        uint32_t* nu = nullptr;
+        HIP_CHECK(hipMalloc((void**)&nu, (d->usedWords + ((size_t)np << LCB_PAGE_SHIFT)) * 4));
+        HIP_CHECK(hipMemcpy(nu, d->dUsed, d->usedWords * 4, hipMemcpyDeviceToDevice));
+        HIP_CHECK(hipFree(d->dUsed));
+        d->dUsed = nu; d->poolPages = np; d->T.used = nu;
     }
     if (entries.size() > d->entryCap) { if (d->dEntries) HIP_CHECK(hipFree(d->dEntries)); d->entryCap = entries.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dEntries, d->entryCap * sizeof(LcbViewPage))); }
     if (pieces.size() > d->pieceCap) { if (d->dPieces) HIP_CHECK(hipFree(d->dPieces)); d->pieceCap = pieces.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dPieces, d->pieceCap * sizeof(LcbViewPiece))); }
     HIP_CHECK(hipMemcpyAsync(d->dEntries, entries.data(), entries.size() * sizeof(LcbViewPage), hipMemcpyHostToDevice, d->stream));
     HIP_CHECK(hipMemcpyAsync(d->dPieces, pieces.data(), pieces.size() * sizeof(LcbViewPiece), hipMemcpyHostToDevice, d->stream));
-    hipLaunchKernelGGL(lcb_build_view_pages_kernel, dim3((uint32_t)entries.size()), dim3(256), 0, d->stream, d->dUsed, d->dPool, d->dViewTab, d->nPages,
+    hipLaunchKernelGGL(lcb_build_view_pages_kernel, dim3((uint32_t)entries.size()), dim3(256), 0, d->stream, d->dUsed, (uint32_t)d->usedWords, d->dViewTab, d->nPages,
                        d->dEntries, d->dPieces);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(d->stream));             // the host vectors above are the copy sources
@@ -610,6 +622,7 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     d->use();
     offsets.assign((size_t)n + 1, 0);
     inst.clear();
+    if (bestScore) memset(bestScore, 0, (size_t)n * sizeof(int64_t));
     d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
     // per-seed results arrive in launch order (retries out of seed order); they are laid out in seed order at the end
     std::vector<lcb_instance> flat;                     // instances in arrival order
@@ -657,12 +670,13 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
             if (mode >= 2) d->bigRetries += m;
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
-            if (screen) d->screened += m;
-            for (uint32_t i = 0; i < m; i++) {
+            const uint32_t nLook = screen ? d->hLive[d->batchCap] : m;   // seeds the screening finalised (no instance, no footprint) keep their zeros
+            if (screen) { d->screened += m; d->screenedDead += m - nLook; }
+            for (uint32_t t = 0; t < nLook; t++) {
+                const uint32_t i = screen ? d->hLive[t] : t;
                 const LcbSeedOut& o = d->hOut[i];
                 const int64_t s = list[at + i];
                 if (o.status == LCB_ST_OK) {
-                    if (screen && o.nInst == 0 && o.nFp == 0) d->screenedDead++;
                     cnt[(size_t)s] = o.nInst;
                     flatOff[(size_t)s] = flat.size();
                     if (o.nInst) {

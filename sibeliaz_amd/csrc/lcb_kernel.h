@@ -56,7 +56,11 @@
 //   mode 3 "huge":    everything in the global workspace, capacities chosen (and grown) by the host
 // IC instances, VC vote slots, BW Bloom words (0 = none), PC path-set slots in LDS (0 = global workspace)
 template <int MODE> struct LcbCfg;
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
+#ifndef LCB_COMPACT_VC
+#define LCB_COMPACT_VC 1024
+#define LCB_COMPACT_BW 256
+#endif
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = LCB_COMPACT_VC, BW = LCB_COMPACT_BW, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; };
 template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; };
@@ -82,16 +86,17 @@ struct LcbTables {
     const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
     const uint4* occRec;        // [nPos]  per occurrence, ascending in g: {g, chr, Position::pos, Position::id} (one 16-B load)
     const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx) — the LIVE state (view 0)
-    // Predicted views 1.. of it (engine.cpp) are copy-on-write at a granularity of 4-KB pages (1024 words, 32768 positions):
-    // viewTab[v * nPages + page] is 0 if view v shares the live page, else 0x80000000 | index of its private page in viewPool.
+    // Predicted views 1.. of it (engine.cpp) are copy-on-write at a granularity of 4-KB pages (1024 words, 32768 positions).
+    // The private pages live BEHIND the live bitmap in the same allocation, and viewTab[v * nPages + page] is the word offset
+    // from a page of the live bitmap to view v's copy of it (0 if the view shares the live page): word w of view v is
+    // used[w + viewTab[v * nPages + (w >> 10)]].
     const uint32_t* viewTab;
-    const uint32_t* viewPool;
     uint32_t nPages;
     uint32_t nChr, nVertex, nPos;
 };
 
 // The `used` state one seed reads: the live bitmap, or a predicted view of it through that view's page table.
-struct LcbUsed { const uint32_t* live; const uint32_t* tab; const uint32_t* pool; };
+struct LcbUsed { const uint32_t* live; const uint32_t* tab; };
 #ifndef LCB_PAGE_SHIFT
 #define LCB_PAGE_SHIFT 10u       // words per page = 1024 (the emulator tests also build with tiny pages, so that views span many)
 #endif
@@ -289,7 +294,7 @@ __device__ __forceinline__ uint32_t lcb_hash(int32_t vid, uint32_t shift)
 __device__ __forceinline__ LcbUsed lcb_used_of(const LcbTables& T, uint32_t view)
 {
     LcbUsed U;
-    U.live = T.used; U.pool = T.viewPool;
+    U.live = T.used;
     U.tab = view ? T.viewTab + (size_t)view * T.nPages : nullptr;
     return U;
 }
@@ -297,10 +302,7 @@ __device__ __forceinline__ LcbUsed lcb_used_of(const LcbTables& T, uint32_t view
 // word w of the state (a view costs one more load, of a table entry that stays in the L1/L2 of the CU)
 __device__ __forceinline__ uint32_t lcb_uword(const LcbUsed& U, uint32_t w)
 {
-    if (U.tab) {
-        const uint32_t e = U.tab[w >> LCB_PAGE_SHIFT];
-        if (e) return U.pool[((size_t)(e & 0x7FFFFFFFu) << LCB_PAGE_SHIFT) + (w & ((1u << LCB_PAGE_SHIFT) - 1u))];
-    }
+    if (U.tab) w += U.tab[w >> LCB_PAGE_SHIFT];
     return U.live[w];
 }
 
@@ -793,7 +795,14 @@ __device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const LcbUs
         o.lo = T.chrStart[rec.y]; o.hi = T.chrStart[rec.y + 1];
         const uint32_t wi = rec.x >> 5;
         o.wbase = wi ? wi - 1 : 0;
-        o.uw0 = lcb_uword(U, o.wbase); o.uw1 = lcb_uword(U, o.wbase + 1); o.uw2 = lcb_uword(U, o.wbase + 2);
+        if (U.tab) {
+            // the three words around the occurrence almost always share its page: one table entry serves them
+            const uint32_t pg = wi >> LCB_PAGE_SHIFT, d = U.tab[pg];
+            const uint32_t w1 = o.wbase + 1, w2 = o.wbase + 2;
+            o.uw0 = U.live[o.wbase + ((o.wbase >> LCB_PAGE_SHIFT) == pg ? d : U.tab[o.wbase >> LCB_PAGE_SHIFT])];
+            o.uw1 = U.live[w1 + ((w1 >> LCB_PAGE_SHIFT) == pg ? d : U.tab[w1 >> LCB_PAGE_SHIFT])];
+            o.uw2 = U.live[w2 + ((w2 >> LCB_PAGE_SHIFT) == pg ? d : U.tab[w2 >> LCB_PAGE_SHIFT])];
+        } else { o.uw0 = U.live[o.wbase]; o.uw1 = U.live[o.wbase + 1]; o.uw2 = U.live[o.wbase + 2]; }
     }
     return o;
 }
@@ -1512,8 +1521,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
 // ---- screening --------------------------------------------------------------------------------------
 // A seed none of whose occurrences is unused with the seed's character has an empty Path::Init (path.h:33-46), so its
 // Process() returns nothing and reads no bit as 0: its header is final here. Later rounds consist almost entirely of such
-// seeds (their neighbourhood is covered by committed blocks); the others are queued for the process kernel.
-// One thread per seed.
+// seeds (their neighbourhood is covered by committed blocks); the others are queued for the process kernel, and the host
+// reads the headers of the queued seeds only. One thread per seed.
 __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -1532,9 +1541,7 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
             else isUsed = g > T.chrStart[rec.y] ? lcb_used_bit(used, g - 1) : false;
             alive = !isUsed && (int32_t)(positive ? T.posCh[g] : T.posRevCh[g]) == sd.ch;
         }
-        LcbSeedOut o;
-        o.nInst = 0; o.status = alive ? (uint32_t)LCB_ST_PENDING : (uint32_t)LCB_ST_OK; o.bestScore = 0; o.arenaOff = 0; o.fpOff = 0; o.nFp = 0; o.pad = 0;
-        out[s] = o;
+        (void)out;      // a dead seed needs no header: the host looks at the live list only (its result is empty by definition)
     }
     // compact the live seeds in seed order within the wave (heavy seeds come first in the sorted seed list)
     const unsigned long long m = __ballot(alive);

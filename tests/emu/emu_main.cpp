@@ -49,8 +49,8 @@ struct EmuCtx {
 struct Emu {
     const lcb_graph* g;
     lcb_params p;
-    std::vector<uint32_t> chrStart32, used;      // used: the live bitmap (view 0), padded to whole pages
-    std::vector<uint32_t> viewTab, viewPool;     // predicted views: page tables (0 = live page, else 0x80000000 | pool page) and their private pages
+    std::vector<uint32_t> chrStart32, used;      // used: the live bitmap (view 0), padded to whole pages, followed by the private pages of the views
+    std::vector<uint32_t> viewTab;               // predicted views: page tables (word offset from a live page to the view's copy, 0 = shared)
     size_t usedWords = 0, nPages = 0;
     int nViewsAlloc = 0;
     LcbTables T;
@@ -73,12 +73,12 @@ struct Emu {
         usedWords = ((g->nPos() / 32 + 2) + pageWords - 1) & ~(pageWords - 1);
         nPages = usedWords >> LCB_PAGE_SHIFT;
         used.assign(usedWords, 0);
-        viewTab.assign(nPages, 0); viewPool.assign(pageWords, 0);
+        viewTab.assign(nPages, 0);
         T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
         T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
         occRec.resize(g->nPos());
         for (size_t j = 0; j < occRec.size(); j++) { const uint32_t q = g->occG[j]; occRec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]}; }
-        T.occRec = occRec.data(); T.used = used.data(); T.viewTab = viewTab.data(); T.viewPool = viewPool.data(); T.nPages = (uint32_t)nPages;
+        T.occRec = occRec.data(); T.used = used.data(); T.viewTab = viewTab.data(); T.nPages = (uint32_t)nPages;
         T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
         const char* te = getenv("EMU_THREADS");
@@ -111,7 +111,7 @@ struct Emu {
     {
         const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT, pageBits = pageWords * 32;
         viewTab.assign((size_t)(nViews + 1) * nPages, 0);
-        viewPool.assign(pageWords, 0);                           // pool page 0 is never referenced (an entry of 0 means "live")
+        used.resize(usedWords);                                  // drop the private pages of the previous launch
         for (int v = 1; v <= nViews; v++)
             for (int64_t m = 0; m < nMarks; m++) {
                 if ((int)marks[m].firstView > v) continue;
@@ -119,16 +119,15 @@ struct Emu {
                     const size_t page = q / pageBits;
                     uint32_t& e = viewTab[(size_t)v * nPages + page];
                     if (!e) {
-                        const size_t pp = viewPool.size() / pageWords;
-                        viewPool.resize(viewPool.size() + pageWords);
-                        memcpy(&viewPool[pp * pageWords], &used[page * pageWords], pageWords * 4);
-                        e = 0x80000000u | (uint32_t)pp;
+                        const size_t at = used.size();
+                        used.resize(at + pageWords);
+                        memcpy(&used[at], &used[page * pageWords], pageWords * 4);
+                        e = (uint32_t)(at - page * pageWords);
                     }
-                    const size_t w = (size_t)(e & 0x7FFFFFFFu) * pageWords + (q % pageBits) / 32;
-                    viewPool[w] |= 1u << (q & 31);
+                    used[page * pageWords + e + (q % pageBits) / 32] |= 1u << (q & 31);
                 }
             }
-        T.viewTab = viewTab.data(); T.viewPool = viewPool.data();
+        T.used = used.data(); T.viewTab = viewTab.data();
         nViewsAlloc = nViews;
     }
 
@@ -230,7 +229,7 @@ struct Emu {
         if (again.empty() || mode >= 3) return;
         if (!next) next.reset(new Emu(g, p, mode + 1));
         next->used = used; next->T.used = next->used.data(); next->nViewsAlloc = nViewsAlloc;
-        next->viewTab = viewTab; next->viewPool = viewPool; next->T.viewTab = next->viewTab.data(); next->T.viewPool = next->viewPool.data();
+        next->viewTab = viewTab; next->T.viewTab = next->viewTab.data();
         std::vector<LcbKSeed> sub;
         for (size_t i : again) sub.push_back(seeds[i]);
         next->runRetry(sub);
@@ -285,7 +284,7 @@ struct EmuProcessor : LcbProcessor {
     {
         for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
     }
-    void reset() override { std::fill(emu->used.begin(), emu->used.end(), 0u); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
+    void reset() override { emu->used.assign(emu->usedWords, 0u); emu->T.used = emu->used.data(); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
