@@ -9,7 +9,7 @@
 //
 // A launch is (optionally) a screening kernel — one thread per seed decides whether Path::Init would create any
 // instance at all and finalises the header of the seeds for which it would not — followed by the process kernel over
-// the surviving seeds in one of four variants (lcb_kernel.h): compact (1 wavefront per seed, 5 seeds per CU: launches
+// the surviving seeds in one of four variants (lcb_kernel.h): compact (2 wavefronts per seed, 5 seeds per CU: launches
 // with many seeds are throughput-bound), wide (16 wavefronts share the votes of one seed: launches with few seeds are
 // as long as their longest seed), big (4096 instances: index, lists and vote table in LDS, instance fields in HBM) and
 // huge (all per-path state in HBM, capacities grown on demand) for seeds that overflow the smaller ones.
@@ -44,7 +44,7 @@
 #define LCB_NW_BIG 8
 #endif
 #ifndef LCB_NW_COMPACT
-#define LCB_NW_COMPACT 1
+#define LCB_NW_COMPACT 2      // one helper wavefront: -10 % on the compact launches of the 62-strain workload; 4 brings nothing more
 #endif
 #define LCB_NW_HUGE 8
 // PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.

@@ -47,7 +47,7 @@
 
 // Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
-//   mode 0 "compact": 256 instances / 1024 vote slots in 32 KB of LDS -> 5 single-wave workgroups per CU (throughput; with 512
+//   mode 0 "compact": 256 instances / 1024 vote slots in 32 KB of LDS -> 5 two-wave workgroups per CU (throughput; with 512
 //                     vote slots 5 % of the seeds of the 62-strain workload overflowed into the wide variant's 256 slots);
 //                     path vertex set in the global workspace behind an LDS Bloom filter
 //   mode 1 "wide":    1024 / 2048 and the path vertex set (8192 slots) in 140 KB of LDS, 16 wavefronts share the votes

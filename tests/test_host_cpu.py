@@ -141,15 +141,16 @@ def emu_built():
 @pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
                                             # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
-                                            ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1"}),
+                                            ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1500"}),
                                             # every kernel variant: wide (LDS path set), big (index in LDS, fields in the workspace), huge (all in the workspace)
-                                            ("twogenomes", "medium", {}), ("twogenomes", "big", {}), ("inv_k25", "big", {"EMU_NOSTATS": "1"}),
-                                            ("twogenomes", "huge", {}), ("inv_k25", "huge", {"EMU_NOSTATS": "1"}),
+                                            ("twogenomes", "medium", {"EMU_LIMIT": "1500"}), ("twogenomes", "big", {"EMU_LIMIT": "1500"}), ("inv_k25", "big", {"EMU_NOSTATS": "1", "EMU_LIMIT": "600"}),
+                                            ("twogenomes", "huge", {"EMU_LIMIT": "1500"}), ("inv_k25", "huge", {"EMU_NOSTATS": "1", "EMU_LIMIT": "600"}),
                                             # helper wavefronts: the heaviest seeds with 16 / 8 / 4 wavefronts per workgroup, both vote protocols
                                             ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200"}),
                                             ("inv_k25", "medium", {"EMU_NW": "16", "EMU_LIMIT": "120", "EMU_SHARE": "1"}),
                                             ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SHARE": "1"}),
                                             ("inv_k25", "huge", {"EMU_NW": "4", "EMU_LIMIT": "200"}),
+                                            ("inv_k25", "seeds-init", {"EMU_NW": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "300"}),     # the shipped compact variant: 2 wavefronts
                                             ("collinear6", "seeds-init", {"EMU_NW": "4", "EMU_LIMIT": "100", "EMU_SHARE": "1"}),
                                             # predicted `used` views spanning many copy-on-write pages (the EMU_SHARE build has 128-position pages)
                                             ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
