@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--full-cpu-baseline", action="store_true", help="time the reference on the whole workload (minutes) instead of the bounded sample")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: never begin the next round's launch while this round is committed")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     args = ap.parse_args()
@@ -244,7 +245,7 @@ def main():
     finder = sibeliaz_amd.BlocksFinder(storage, w["k"])
 
     def step():
-        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm)
+        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, no_overlap=1 if args.no_overlap else 0)
         return finder.blocks, dict(finder.stats)
 
     def sync():
@@ -319,7 +320,7 @@ def main():
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
-                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]),
+                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]), "early_rounds": int(st["early_rounds"]),
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())),
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},

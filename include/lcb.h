@@ -93,6 +93,7 @@ typedef struct {
     double plan_ms;             /* wall time of the dry runs */
     lcb_counters events;        /* lcb_hooks.count_events: the reference-semantics event counts of the whole FindBlocks (phase-start
                                    Process() of every seed + the re-Process() of every commit conflict), else zero */
+    int64_t early_rounds;       /* rounds whose speculative launch ran on the GPU while the host was committing the previous round */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -127,7 +128,7 @@ typedef struct {
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
     uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
     uint32_t huge_slots;     /* ... of the huge variant (all per-path state in HBM); default 1 per 4 CUs */
-    uint32_t path_cap;       /* path vertex set capacity of a compact slot (power of two); default 32768 */
+    uint32_t path_cap;       /* path vertex set capacity of a compact slot (power of two; HBM-resident); default 131072 */
     uint32_t wide_path_cap;  /* ... of a wide slot (the set lives in LDS); default and maximum 8192 */
     uint32_t max_views;      /* predicted `used` views kept behind the live bitmap; default 256 (within 2 GiB) */
     uint32_t batch;          /* seeds per launch; default 65536 */
@@ -211,6 +212,7 @@ typedef struct {
                                    2 the still-free instances of its phase-start result, 3 (default) a stale re-processed result if any, else as 2 */
     int32_t exchange_always;    /* 1: a single rank still packs / all-gathers / unpacks every launch (tests of the exchange path) */
     int32_t count_events;       /* 1: fill lcb_stats.events (the device must be in stats mode; one rank) */
+    int32_t no_overlap;         /* 1: never run the next round's launch while this round is being committed */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

@@ -27,7 +27,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->no_overlap == 0;
     }
     return cfg;
 }
@@ -206,7 +206,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->no_overlap == 0;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -221,7 +221,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
             stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-            stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
+            stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));

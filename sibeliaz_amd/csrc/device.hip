@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -166,6 +167,7 @@ struct lcb_device_impl {
     uint32_t* dViewTab = nullptr;                // [(maxViews + 1) * nPages]: word offset from a live page to the view's copy (0 = shared)
     uint32_t poolPages = 0;                      // private pages of the predicted views of the current launch, behind the live bitmap in dUsed
     int lastViews = 0;                           // views whose tables hold entries from the previous build
+    struct lcb_async_call* async = nullptr;      // the call begun with processBegin and not yet ended
     LcbViewPage* dEntries = nullptr; LcbViewPiece* dPieces = nullptr;
     size_t entryCap = 0, pieceCap = 0;
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
@@ -180,6 +182,15 @@ struct lcb_device_impl {
     uint2* hFp = nullptr;                        // footprint arena (pinned)
     unsigned long long fpCap = 0;
     LcbMarkRange* hRanges = nullptr;
+    // second set of the host buffers, for the launch that runs while the host still commits the previous round (processBegin/End)
+    LcbKSeed* hSeedsB = nullptr; LcbSeedOut* hOutB = nullptr; uint4* hArenaB = nullptr; uint2* hFpB = nullptr; uint32_t* hLiveB = nullptr;
+    unsigned long long arenaCapB = 0, fpCapB = 0;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
+    void swapBufs()
+    {
+        std::swap(hSeeds, hSeedsB); std::swap(hOut, hOutB); std::swap(hArena, hArenaB); std::swap(hFp, hFpB); std::swap(hLive, hLiveB);
+        std::swap(arenaCap, arenaCapB); std::swap(fpCap, fpCapB);
+    }
     uint32_t* hDbg = nullptr;                    // flight recorder (LCB_DEBUG=1): 16 words per workgroup
     uint32_t dbgSlots = 0;
     bool forceProf = false;                      // LCB_FORCE_PROF=1: always use the instrumented kernel variants
@@ -235,9 +246,11 @@ struct lcb_device_impl {
     }
 
     // One launch over hSeeds[0..m): optional screening, then the process kernel of w's variant. Returns after the stream
-    // has drained; hOut[0..m) then holds every seed's header.
-    void launch(WorkSet& w, uint32_t m, bool screen)
+    // has drained; hOut[0..m) then holds every seed's header. wait = false only enqueues (events evA/evB); finishLaunch()
+    // then waits for it.
+    void launch(WorkSet& w, uint32_t m, bool screen, bool wait = true)
     {
+        hipEvent_t evA = wait ? ev0 : ev2, evB = wait ? ev1 : ev3;
         LcbWork W;
         W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap;
         W.instCap = w.instCap; W.voteCap = w.voteCap;
@@ -253,7 +266,7 @@ struct lcb_device_impl {
         if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
         if (watchdogS > 0 || screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // unfinished seeds can be named (and a header nobody wrote is noticed)
         HIP_CHECK(hipMemsetAsync(dCursor, 0, 32, stream));
-        HIP_CHECK(hipEventRecord(ev0, stream));
+        HIP_CHECK(hipEventRecord(evA, stream));
         if (screen) {
             hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
             HIP_CHECK(hipGetLastError());
@@ -269,16 +282,22 @@ struct lcb_device_impl {
 #undef LCB_LAUNCH_MODE
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(ev1, stream));
+        HIP_CHECK(hipEventRecord(evB, stream));
         if (screen) {      // the host only looks at the seeds that survived the screening
             HIP_CHECK(hipMemcpyAsync(hLive + batchCap, dCursor + 1, 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(hLive, dLive, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
         }
+        if (!wait) return;
+        finishLaunch(w, m, grid, W.dbg != nullptr, evA, evB);
+    }
+
+    void finishLaunch(WorkSet& w, uint32_t m, uint32_t grid, bool haveDbg, hipEvent_t evA, hipEvent_t evB)
+    {
         if (watchdogS > 0) {
             // bounded wait: a kernel that does not finish is reported with its flight recorder instead of hanging the caller
             const auto t0 = std::chrono::steady_clock::now();
             for (;;) {
-                const hipError_t q = hipEventQuery(ev1);
+                const hipError_t q = hipEventQuery(evB);
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) HIP_CHECK(q);
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -293,7 +312,7 @@ struct lcb_device_impl {
                             if (hOut[i].status == LCB_ST_PENDING) { fprintf(stderr, " [%u] vid=%d ch=%d", i, hSeeds[i].vid, hSeeds[i].ch); shownSeeds++; }
                         fprintf(stderr, "\n");
                     }
-                    if (W.dbg) {
+                    if (haveDbg) {
                         int shown = 0;
                         for (uint32_t b = 0; b < grid && shown < 8; b++) {
                             const uint32_t* r = hDbg + 16 * b;
@@ -310,7 +329,7 @@ struct lcb_device_impl {
         }
         HIP_CHECK(hipStreamSynchronize(stream));
         float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
         kernelMs += ms;
         launches++;
         modeSeeds[w.mode] += m;
@@ -349,7 +368,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
-        if (!o.path_cap) o.path_cap = 32768;
+        if (!o.path_cap) o.path_cap = 131072;
         if (!o.max_views) o.max_views = 256;
         if (!o.batch) o.batch = 65536;
         if (!o.wide_threshold) o.wide_threshold = 2 * o.wide_slots;
@@ -358,6 +377,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&d->ev0));
         HIP_CHECK(hipEventCreate(&d->ev1));
+        HIP_CHECK(hipEventCreate(&d->ev2));
+        HIP_CHECK(hipEventCreate(&d->ev3));
         const uint64_t P = g->nPos();
         if (P >= (1ull << 32) - (1ull << 20)) throw LcbError("more than 2^32 - 2^20 junction occurrences are not supported by the device tables");
         std::vector<uint32_t> cs(g->chrStart.begin(), g->chrStart.end());
@@ -419,6 +440,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
         d->allocArena(1u << 20);
+        d->swapBufs();
+        HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&d->hLive, ((size_t)d->batchCap + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        d->allocArena(1u << 20);
+        d->swapBufs();
         const char* tf = getenv("LCB_TRACE_LAUNCHES");
         if (tf && *tf) d->traceFile = fopen(tf, "w");
         d->seedTrace = envU32("LCB_TRACE_SEEDS", 0) != 0;
@@ -438,11 +465,14 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
     return handle;
 }
 
+static void lcb_device_drop_async(lcb_device_impl* d);
+
 void lcb_device_destroy_impl(lcb_device* h)
 {
     if (!h) return;
     lcb_device_impl* d = h->impl;
     if (d) {
+        lcb_device_drop_async(d);
         if (getenv("LCB_VERBOSE")) {
             fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
@@ -462,6 +492,9 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->dLive) (void)hipFree(d->dLive);
         if (d->hLive) (void)hipHostFree(d->hLive);
         for (auto& w : d->ws) if (w.base) (void)hipFree(w.base);
+        for (void* q : {(void*)d->hSeedsB, (void*)d->hOutB, (void*)d->hArenaB, (void*)d->hFpB, (void*)d->hLiveB}) if (q) (void)hipHostFree(q);
+        if (d->ev2) (void)hipEventDestroy(d->ev2);
+        if (d->ev3) (void)hipEventDestroy(d->ev3);
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
         if (d->hCtr) (void)hipHostFree(d->hCtr);
@@ -613,112 +646,149 @@ void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
 void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = h->impl->modeSeeds[i]; }
 
-void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
-                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr)
-{
-    if (perSeedCtr) perSeedCtr->assign((size_t)n, lcb_counters{});
-    lcb_device_impl* d = h->impl;
-    d->use();
-    offsets.assign((size_t)n + 1, 0);
-    inst.clear();
-    if (bestScore) memset(bestScore, 0, (size_t)n * sizeof(int64_t));
-    d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
-    // per-seed results arrive in launch order (retries out of seed order); they are laid out in seed order at the end
+namespace {
+
+// The accumulators of one process() call: per-seed results arrive in launch order (retries out of seed order) and are laid
+// out in seed order at the end.
+struct ProcAcc {
+    const lcb_seed* seeds = nullptr; const uint32_t* view = nullptr; int64_t n = 0;
+    int64_t* bestScore = nullptr; lcb_counters* ctr = nullptr; std::vector<lcb_counters>* perSeedCtr = nullptr;
+    bool wantFp = false;
     std::vector<lcb_instance> flat;                     // instances in arrival order
-    std::vector<uint64_t> flatOff((size_t)n, 0);
-    std::vector<uint32_t> cnt((size_t)n, 0);
+    std::vector<uint64_t> flatOff;
+    std::vector<uint32_t> cnt;
     std::vector<lcb_fp> fpFlat;                         // footprints in arrival order (only when they are wanted) ...
     std::vector<uint64_t> fpAt;                         // ... and where each seed's intervals start / how many there are
     std::vector<uint32_t> fpCnt;
-    if (d->wantFp) { fpAt.assign((size_t)n, 0); fpCnt.assign((size_t)n, 0); }
-    auto keyOf = [](const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; };
-    auto setHint = [&](const lcb_seed& sd, uint8_t mode) {
-        const uint64_t key = keyOf(sd);
-        const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
-        d->hintBits[hb >> 6] |= 1ull << (hb & 63);
-        d->modeHint[key] = mode;
-    };
-    // first mode of every seed: the caller's choice, else wide for launches of few seeds (as long as their longest seed)
-    // and compact for launches of many (throughput); a seed known to overflow a mode starts in the next
+    std::vector<int64_t> todo[4];                       // seeds still to run, per kernel variant
+    std::vector<uint8_t> tried;                         // per seed: bit m = it overflowed variant m in this call
+    std::vector<lcb_seed> ownSeeds;                     // (an asynchronous call keeps its own copy of the seeds)
+};
+
+uint64_t hintKey(const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; }
+
+void setHint(lcb_device_impl* d, const lcb_seed& sd, uint8_t mode)
+{
+    const uint64_t key = hintKey(sd);
+    const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
+    d->hintBits[hb >> 6] |= 1ull << (hb & 63);
+    d->modeHint[key] = mode;
+}
+
+void accInit(lcb_device_impl* d, ProcAcc& A, const lcb_seed* seeds, int64_t n, const uint32_t* view, int64_t* bestScore, lcb_counters* ctr,
+             std::vector<lcb_counters>* perSeedCtr, bool wantFp)
+{
+    A.seeds = seeds; A.view = view; A.n = n; A.bestScore = bestScore; A.ctr = ctr; A.perSeedCtr = perSeedCtr; A.wantFp = wantFp;
+    if (perSeedCtr) perSeedCtr->assign((size_t)n, lcb_counters{});
+    if (bestScore) memset(bestScore, 0, (size_t)n * sizeof(int64_t));
+    A.flatOff.assign((size_t)n, 0); A.cnt.assign((size_t)n, 0); A.tried.assign((size_t)n, 0);
+    if (wantFp) { A.fpAt.assign((size_t)n, 0); A.fpCnt.assign((size_t)n, 0); }
+    // first variant of every seed: the caller's choice, else wide for calls with few seeds (as long as their longest seed)
+    // and compact for calls with many (throughput); a seed that overflowed a variant earlier in this pass starts where it ended up
     const int base = d->o.start_mode ? (int)d->o.start_mode - 1 : (n <= (int64_t)d->o.wide_threshold ? 1 : 0);
-    std::vector<int64_t> todo[4];
-    if (d->modeHint.empty() || d->o.start_mode) { todo[base].resize((size_t)n); for (int64_t s = 0; s < n; s++) todo[base][(size_t)s] = s; }
+    if (d->modeHint.empty() || d->o.start_mode) { A.todo[base].resize((size_t)n); for (int64_t s = 0; s < n; s++) A.todo[base][(size_t)s] = s; }
     else
         for (int64_t s = 0; s < n; s++) {
-            const uint64_t key = keyOf(seeds[s]);
+            const uint64_t key = hintKey(seeds[s]);
             const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
             int m = base;
-            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end() && it->second > m) m = it->second; }
-            todo[m].push_back(s);
+            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) m = it->second; }
+            A.todo[m].push_back(s);
         }
+}
+
+void fillSeeds(lcb_device_impl* d, const ProcAcc& A, const std::vector<int64_t>& list, size_t at, uint32_t m)
+{
+    for (uint32_t i = 0; i < m; i++) {
+        const int64_t s = list[at + i];
+        d->hSeeds[i].vid = A.seeds[s].vid; d->hSeeds[i].ch = A.seeds[s].ch; d->hSeeds[i].view = A.view ? A.view[s] : 0u; d->hSeeds[i].pad = 0;
+    }
+}
+
+// Takes the results of one finished launch out of the host buffers; seeds that overflowed go to the next variant's list.
+// Returns true if a seed overflowed the huge variant (its capacities must grow).
+bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& list, size_t at, uint32_t m, bool screen, int mode)
+{
+    bool hugeOverflow = false;
+    const uint32_t nLook = screen ? d->hLive[d->batchCap] : m;   // seeds the screening finalised (no instance, no footprint) keep their zeros
+    if (screen) { d->screened += m; d->screenedDead += m - nLook; }
+    for (uint32_t t = 0; t < nLook; t++) {
+        const uint32_t i = screen ? d->hLive[t] : t;
+        const LcbSeedOut& o = d->hOut[i];
+        const int64_t s = list[at + i];
+        if (o.status == LCB_ST_OK) {
+            A.cnt[(size_t)s] = o.nInst;
+            A.flatOff[(size_t)s] = A.flat.size();
+            if (o.nInst) {
+                const uint4* src = d->hArena + o.arenaOff;
+                const size_t f0 = A.flat.size();
+                A.flat.resize(f0 + o.nInst);
+                for (uint32_t e = 0; e < o.nInst; e++) A.flat[f0 + e] = lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w};
+            }
+            if (A.bestScore) A.bestScore[s] = o.bestScore;
+            if (A.wantFp) {
+                A.fpAt[(size_t)s] = A.fpFlat.size(); A.fpCnt[(size_t)s] = o.nFp;
+                const uint2* src = d->hFp + o.fpOff;
+                const size_t f0 = A.fpFlat.size();
+                A.fpFlat.resize(f0 + o.nFp);
+                for (uint32_t e = 0; e < o.nFp; e++) A.fpFlat[f0 + e] = lcb_fp{src[e].x, src[e].y};
+            }
+            if (A.perSeedCtr && d->stats) {
+                const LcbSeedCtr& k = d->hCtr[i];
+                lcb_counters& q = (*A.perSeedCtr)[(size_t)s];
+                q.n_walk = k.c[0]; q.n_occ = k.c[1]; q.n_compat_call = k.c[2]; q.n_compat_step = k.c[3];
+                q.n_inst_out = k.c[4]; q.n_vote = k.c[5]; q.n_push = k.c[6]; q.n_process = k.c[7];
+            }
+            if (A.ctr) {
+                const LcbSeedCtr& k = d->hCtr[i];
+                A.ctr->n_walk += k.c[0]; A.ctr->n_occ += k.c[1]; A.ctr->n_compat_call += k.c[2]; A.ctr->n_compat_step += k.c[3];
+                A.ctr->n_inst_out += k.c[4]; A.ctr->n_vote += k.c[5]; A.ctr->n_push += k.c[6]; A.ctr->n_process += k.c[7];
+            }
+        } else if (o.status == LCB_ST_DIST_OVF) {
+            throw LcbError("a path longer than 2^31 bp is not supported");
+        } else if (o.status == LCB_ST_PENDING) {
+            throw LcbError("device: a seed of the launch was not processed");
+        } else if (o.status == LCB_ST_ARENA_OVF) {
+            A.todo[mode].push_back(s);                          // same variant again: the arena is emptied between launches
+        } else {
+            if (o.status < 8) d->overflow[mode][o.status]++;
+            A.tried[(size_t)s] |= (uint8_t)(1u << mode);
+            // The next variant. The ladder is compact -> wide -> big -> huge by capacity of instances and vote table, but the
+            // PATH capacity is the other way round between the first two: the wide variant keeps its path set in LDS (4096
+            // vertices), the compact one in HBM (65 536). A long path with few instances (long blocks of few genomes, k = 25)
+            // that started in the wide variant therefore goes back to the compact one; only what overflowed both goes on to big.
+            int nextMode = mode < 3 ? mode + 1 : 3;
+            if (mode == 1 && o.status == LCB_ST_PATH_OVF && !(A.tried[(size_t)s] & 1u)) nextMode = 0;
+            else if (mode == 0 && o.status == LCB_ST_PATH_OVF) nextMode = 2;
+            else if (mode == 0 && (A.tried[(size_t)s] & 2u)) nextMode = 2;
+            if (mode == 3) hugeOverflow = true; else setHint(d, A.seeds[s], (uint8_t)nextMode);
+            A.todo[nextMode].push_back(s);
+        }
+    }
+    return hugeOverflow;
+}
+
+// Launches (and waits for) everything that is still to do, variant by variant, until no seed is left.
+void runToCompletion(lcb_device_impl* d, ProcAcc& A)
+{
     for (int round = 0; ; round++) {
         int mode = -1;
-        for (int m = 0; m < 4; m++) if (!todo[m].empty()) { mode = m; break; }
+        for (int m = 0; m < 4; m++) if (!A.todo[m].empty()) { mode = m; break; }
         if (mode < 0) break;
         if (round > 20) throw LcbError("a seed keeps overflowing the device workspaces");
         WorkSet& ws = d->ws[mode];
         std::vector<int64_t> list;
-        list.swap(todo[mode]);
+        list.swap(A.todo[mode]);
         bool hugeOverflow = false;
         for (size_t at = 0; at < list.size(); at += d->batchCap) {
             const uint32_t m = (uint32_t)std::min<size_t>(list.size() - at, d->batchCap);
-            for (uint32_t i = 0; i < m; i++) {
-                const int64_t s = list[at + i];
-                d->hSeeds[i].vid = seeds[s].vid; d->hSeeds[i].ch = seeds[s].ch; d->hSeeds[i].view = view ? view[s] : 0u; d->hSeeds[i].pad = 0;
-            }
+            fillSeeds(d, A, list, at, m);
             if (mode >= 2) d->bigRetries += m;
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
-            const uint32_t nLook = screen ? d->hLive[d->batchCap] : m;   // seeds the screening finalised (no instance, no footprint) keep their zeros
-            if (screen) { d->screened += m; d->screenedDead += m - nLook; }
-            for (uint32_t t = 0; t < nLook; t++) {
-                const uint32_t i = screen ? d->hLive[t] : t;
-                const LcbSeedOut& o = d->hOut[i];
-                const int64_t s = list[at + i];
-                if (o.status == LCB_ST_OK) {
-                    cnt[(size_t)s] = o.nInst;
-                    flatOff[(size_t)s] = flat.size();
-                    if (o.nInst) {
-                        const uint4* src = d->hArena + o.arenaOff;
-                        const size_t f0 = flat.size();
-                        flat.resize(f0 + o.nInst);
-                        for (uint32_t e = 0; e < o.nInst; e++) flat[f0 + e] = lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w};
-                    }
-                    if (bestScore) bestScore[s] = o.bestScore;
-                    if (d->wantFp) {
-                        fpAt[(size_t)s] = fpFlat.size(); fpCnt[(size_t)s] = o.nFp;
-                        const uint2* src = d->hFp + o.fpOff;
-                        const size_t f0 = fpFlat.size();
-                        fpFlat.resize(f0 + o.nFp);
-                        for (uint32_t e = 0; e < o.nFp; e++) fpFlat[f0 + e] = lcb_fp{src[e].x, src[e].y};
-                    }
-                    if (perSeedCtr && d->stats) {
-                        const LcbSeedCtr& k = d->hCtr[i];
-                        lcb_counters& q = (*perSeedCtr)[(size_t)s];
-                        q.n_walk = k.c[0]; q.n_occ = k.c[1]; q.n_compat_call = k.c[2]; q.n_compat_step = k.c[3];
-                        q.n_inst_out = k.c[4]; q.n_vote = k.c[5]; q.n_push = k.c[6]; q.n_process = k.c[7];
-                    }
-                    if (ctr) {
-                        const LcbSeedCtr& k = d->hCtr[i];
-                        ctr->n_walk += k.c[0]; ctr->n_occ += k.c[1]; ctr->n_compat_call += k.c[2]; ctr->n_compat_step += k.c[3];
-                        ctr->n_inst_out += k.c[4]; ctr->n_vote += k.c[5]; ctr->n_push += k.c[6]; ctr->n_process += k.c[7];
-                    }
-                } else if (o.status == LCB_ST_DIST_OVF) {
-                    throw LcbError("a path longer than 2^31 bp is not supported");
-                } else if (o.status == LCB_ST_PENDING) {
-                    throw LcbError("device: a seed of the launch was not processed");
-                } else if (o.status == LCB_ST_ARENA_OVF) {
-                    todo[mode].push_back(s);                          // same mode again: the arena is emptied between launches
-                } else {
-                    if (o.status < 8) d->overflow[mode][o.status]++;
-                    const int nextMode = mode < 3 ? mode + 1 : 3;
-                    if (mode == 3) hugeOverflow = true; else setHint(seeds[s], (uint8_t)nextMode);
-                    todo[nextMode].push_back(s);
-                }
-            }
+            hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
         }
-        if (!todo[mode].empty() && mode < 3 && todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
+        if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
             WorkSet& b = d->ws[3];
@@ -726,23 +796,107 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
             d->allocArena(d->arenaCap * 4);
             b.pathCap *= 2; b.bodyCap *= 2; b.instCap *= 2; b.voteCap *= 2; b.bestCap *= 2;
             d->allocWork(b);
-        } else if (mode == 3 && !todo[3].empty()) d->allocArena(d->arenaCap * 4);
+        } else if (mode == 3 && !A.todo[3].empty()) d->allocArena(d->arenaCap * 4);
     }
+}
+
+void accLayout(ProcAcc& A, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut)
+{
+    const int64_t n = A.n;
+    offsets.assign((size_t)n + 1, 0);
     uint64_t total = 0;
-    for (int64_t s = 0; s < n; s++) { offsets[(size_t)s] = total; total += cnt[(size_t)s]; }
+    for (int64_t s = 0; s < n; s++) { offsets[(size_t)s] = total; total += A.cnt[(size_t)s]; }
     offsets[(size_t)n] = total;
     inst.resize((size_t)total);
     for (int64_t s = 0; s < n; s++)
-        if (cnt[(size_t)s]) memcpy(inst.data() + offsets[(size_t)s], flat.data() + flatOff[(size_t)s], (size_t)cnt[(size_t)s] * sizeof(lcb_instance));
-    if (d->wantFp) {
+        if (A.cnt[(size_t)s]) memcpy(inst.data() + offsets[(size_t)s], A.flat.data() + A.flatOff[(size_t)s], (size_t)A.cnt[(size_t)s] * sizeof(lcb_instance));
+    if (A.wantFp) {
         fpOffsets->assign((size_t)n + 1, 0);
         uint64_t tf = 0;
-        for (int64_t s = 0; s < n; s++) { (*fpOffsets)[(size_t)s] = tf; tf += fpCnt[(size_t)s]; }
+        for (int64_t s = 0; s < n; s++) { (*fpOffsets)[(size_t)s] = tf; tf += A.fpCnt[(size_t)s]; }
         (*fpOffsets)[(size_t)n] = tf;
         fpOut->resize((size_t)tf);
         for (int64_t s = 0; s < n; s++)
-            if (fpCnt[(size_t)s]) memcpy(fpOut->data() + (*fpOffsets)[(size_t)s], fpFlat.data() + fpAt[(size_t)s], (size_t)fpCnt[(size_t)s] * sizeof(lcb_fp));
+            if (A.fpCnt[(size_t)s]) memcpy(fpOut->data() + (*fpOffsets)[(size_t)s], A.fpFlat.data() + A.fpAt[(size_t)s], (size_t)A.fpCnt[(size_t)s] * sizeof(lcb_fp));
     }
+}
+
+}  // namespace
+
+void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
+                             std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    inst.clear();
+    d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
+    ProcAcc A;
+    accInit(d, A, seeds, n, view, bestScore, ctr, perSeedCtr, d->wantFp);
+    runToCompletion(d, A);
+    accLayout(A, offsets, inst, fpOffsets, fpOut);
+    d->wantFp = false;
+}
+
+// ---- a call whose first launch runs while the host is still busy with something else --------------------------------------
+// begin: the seeds that start in the compact variant are enqueued (second set of host buffers, nothing is waited for) against
+// the live `used` state of this moment — later marks and launches are ordered behind it on the stream; end: waits for that
+// launch, takes its results, then runs whatever is left (seeds with a hint for another variant, overflows) like a normal call.
+struct lcb_async_call { ProcAcc A; std::vector<int64_t> list; uint32_t m = 0; bool screen = false, launched = false; };
+
+static void lcb_device_drop_async(lcb_device_impl* d)
+{
+    if (d->async && d->stream) (void)hipStreamSynchronize(d->stream);
+    delete d->async;
+    d->async = nullptr;
+}
+
+bool lcb_device_process_begin_impl(lcb_device* h, const lcb_seed* seeds, int64_t n)
+{
+    lcb_device_impl* d = h->impl;
+    if (d->stats || d->async || n > (int64_t)d->batchCap || n <= (int64_t)d->o.wide_threshold || d->o.start_mode > 1) return false;
+    if (d->hDbg || d->seedTrace || d->forceProf) return false;     // (the instrumented variants share one profile buffer)
+    d->use();
+    std::unique_ptr<lcb_async_call> c(new lcb_async_call());
+    c->A.ownSeeds.assign(seeds, seeds + n);
+    accInit(d, c->A, c->A.ownSeeds.data(), n, nullptr, nullptr, nullptr, nullptr, true);
+    c->list.swap(c->A.todo[0]);
+    c->m = (uint32_t)c->list.size();
+    if (c->m) {
+        d->wantFp = true;
+        d->swapBufs();
+        fillSeeds(d, c->A, c->list, 0, c->m);
+        c->screen = c->m >= d->o.screen_min;
+        try { d->launch(d->ws[0], c->m, c->screen, false); } catch (...) { d->swapBufs(); d->wantFp = false; throw; }
+        d->swapBufs();
+        d->wantFp = false;
+        c->launched = true;
+    }
+    d->async = c.release();
+    return true;
+}
+
+void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOffsets,
+                                 std::vector<lcb_fp>& fpOut)
+{
+    lcb_device_impl* d = h->impl;
+    if (!d->async) throw LcbError("lcb_device_process_end without a begin");
+    std::unique_ptr<lcb_async_call> c(d->async);
+    d->async = nullptr;
+    d->use();
+    inst.clear();
+    d->wantFp = true;
+    if (c->launched) {
+        d->swapBufs();
+        try {
+            const uint32_t grid = c->m < d->ws[0].nSlots ? c->m : d->ws[0].nSlots;
+            d->finishLaunch(d->ws[0], c->m, grid, false, d->ev2, d->ev3);
+            gatherBatch(d, c->A, c->list, 0, c->m, c->screen, 0);
+        } catch (...) { d->swapBufs(); d->wantFp = false; throw; }
+        d->swapBufs();
+    }
+    runToCompletion(d, c->A);
+    accLayout(c->A, offsets, inst, &fpOffsets, &fpOut);
     d->wantFp = false;
 }
 
@@ -760,6 +914,11 @@ struct DeviceProcessor : LcbProcessor {
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
     int concurrency() const override { return lcb_device_concurrency_impl(dev); }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { lcb_device_build_views_impl(dev, nViews, marks, nMarks); }
+    bool processBegin(const lcb_seed* seeds, int64_t n) override { return lcb_device_process_begin_impl(dev, seeds, n); }
+    void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        lcb_device_process_end_impl(dev, off, inst, fpOff, fp);
+    }
     void mark(const uint64_t* ranges, int64_t n) override { lcb_device_mark_used_impl(dev, ranges, n); }
     void reset() override { lcb_device_reset_used_impl(dev); }
 };
@@ -784,6 +943,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-        stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
+        stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
     }
 }

@@ -164,9 +164,18 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         pending.clear();
     };
     std::vector<RangeSet> epochMarks;              // epochMarks[e]: ranges marked after launch e of this round and before launch e+1
+    // Overlap of host and device (one rank): while the host validates and commits round r, the processor already runs the
+    // speculative launch of round r+1 — begun against the state at the START of round r (its W), so everything round r commits is
+    // "marked since" for its results (sinceBegin becomes epoch 0 of round r+1). Only in sparse stretches (the previous round
+    // re-launched < 5 % of its seeds): where commits are dense the results of the early launch would mostly be void.
+    bool begun = false;                            // a processBegin for the next round is in flight
+    int64_t begunN = 0;
+    RangeSet sinceBegin;
+    double lastInvalid = 1.0;
     auto takeMarks = [&]() {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
             epochMarks.back().add(com.marks[i], com.marks[i + 1]);
+            if (begun) sinceBegin.add(com.marks[i], com.marks[i + 1]);
             pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]);
         }
         com.marks.clear();
@@ -259,13 +268,32 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     };
 
     for (int64_t pos = 0; pos < nSeeds;) {
-        const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
-        flush();                                    // processor state == live state at the start of phase `pos`
-        epochMarks.assign(1, RangeSet());
+        const bool early = begun;                   // this round's launch was begun while the previous round was committed
+        const int64_t nRound = early ? begunN : std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
         st.rounds++;
-        // ---- speculative launch of the whole round (dealt to the ranks) ---------------------------------------------
-        sub.assign(seeds + pos, seeds + pos + nRound);
-        processSharded(sub.data(), nullptr, nRound, round, (uint64_t)pos);
+        if (early) {
+            // its results were computed against the state at the start of the previous round: what that round marked is epoch 0
+            const auto tp = std::chrono::steady_clock::now();
+            proc.processEnd(round.off, round.inst, round.fpOff, round.fp);
+            st.processMs += msSince(tp);
+            begun = false;
+            epochMarks.assign(1, sinceBegin);
+            sinceBegin.clear();
+            st.earlyRounds++;
+        } else {
+            flush();                                // processor state == live state at the start of phase `pos`
+            epochMarks.assign(1, RangeSet());
+            // ---- speculative launch of the whole round (dealt to the ranks) ---------------------------------------------
+            sub.assign(seeds + pos, seeds + pos + nRound);
+            processSharded(sub.data(), nullptr, nRound, round, (uint64_t)pos);
+        }
+        if (world == 1 && !cfg.countEvents && !cfg.exchangeAlways && !fixedRound && cfg.overlap && lastInvalid < 0.05 && pos + nRound < nSeeds) {
+            // the processor's state is still the one this round's launch saw (nothing has been committed since): begin the next round
+            flush();
+            begunN = std::min<int64_t>(nSeeds - (pos + nRound), (int64_t)roundPhases * phase);
+            begun = proc.processBegin(seeds + pos + nRound, begunN);
+            sinceBegin.clear();
+        }
         cands.clear(); viewSets.clear();
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
@@ -488,10 +516,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             com.endPhase();
         }
         pos += nRound;
+        lastInvalid = (double)(st.recomputedSeeds - recomputedBefore) / (double)nRound;
         if (!fixedRound) {
-            const double invalid = (double)(st.recomputedSeeds - recomputedBefore) / (double)nRound;
-            if (invalid > 0.25) roundPhases = std::max(1, roundPhases / 2);
-            else if (invalid < 0.05) roundPhases = std::min(maxRound, roundPhases * 2);
+            if (lastInvalid > 0.25) roundPhases = std::max(1, roundPhases / 2);
+            else if (lastInvalid < 0.05) roundPhases = std::min(maxRound, roundPhases * 2);
         }
     }
     flush();

@@ -26,6 +26,11 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
                              std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr,
                              const uint32_t* view = nullptr,    // view[i]: `used` view of seed i (null = the live state)
                              std::vector<lcb_counters>* perSeedCtr = nullptr);   // stats mode: the counters of every seed
+// The same for a call whose first launch overlaps with host work: begin enqueues it against the live state of this moment (false:
+// not applicable, use the synchronous call), end waits and completes it.
+bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n);
+void lcb_device_process_end_impl(lcb_device* d, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOffsets,
+                                 std::vector<lcb_fp>& fp);
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
 void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_max_views_impl(lcb_device* d);

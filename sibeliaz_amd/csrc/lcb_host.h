@@ -85,6 +85,13 @@ struct LcbProcessor {
     // count them: the device in stats mode; others leave it empty)
     std::vector<lcb_counters>* ctrSink = nullptr;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
+    // Optional: start process(seeds, view 0) now, against the state of this moment (marks applied later must not reach it),
+    // and collect it with processEnd — the engine commits the previous round in between. false = not supported / not applicable.
+    virtual bool processBegin(const lcb_seed* seeds, int64_t n) { (void)seeds; (void)n; return false; }
+    virtual void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp)
+    {
+        (void)off; (void)inst; (void)fpOff; (void)fp; throw LcbError("processEnd without processBegin");
+    }
     virtual int maxViews() const { return 0; }
     // seeds the processor works on at the same time: a dry run plans about this many jobs per launch (more only queue up)
     virtual int concurrency() const { return 16384; }
@@ -106,6 +113,7 @@ struct LcbEngineConfig {
     int maxJobs = 0;          // a dry run stops planning beyond this many jobs (0 = the processor's concurrency)
     int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
     bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
+    bool overlap = true;      // begin the next round's launch while this round is committed (sparse stretches, one rank)
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
 };
 
@@ -116,6 +124,7 @@ struct LcbEngineStats {
     int64_t jobsUsed = 0;         // ... results that were committed from (exactly validated)
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
+    int64_t earlyRounds = 0;      // rounds whose launch ran while the previous round was being committed
     double wallMs = 0;
     double processMs = 0, planMs = 0;   // wall time inside the processor (launches + result gathering) / inside the dry runs
     lcb_counters events{};              // countEvents: totals over the phase-start result of every seed + the re-processed result of every conflict

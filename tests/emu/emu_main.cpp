@@ -285,6 +285,26 @@ struct EmuProcessor : LcbProcessor {
         for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
     }
     void reset() override { emu->used.assign(emu->usedWords, 0u); emu->T.used = emu->used.data(); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
+    // begin / end (the engine overlaps the next round's launch with this round's commit): the emulated launch must see the
+    // state of the moment of the begin, so the live bitmap is snapshotted there and the seeds run against the snapshot at the end
+    std::vector<lcb_seed> begunSeeds; std::vector<uint32_t> begunUsed; bool begunValid = false;
+    bool processBegin(const lcb_seed* sd, int64_t n) override
+    {
+        if (getenv("EMU_NO_OVERLAP")) return false;
+        begunSeeds.assign(sd, sd + n);
+        begunUsed.assign(emu->used.begin(), emu->used.begin() + emu->usedWords);
+        begunValid = true;
+        return true;
+    }
+    void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        if (!begunValid) throw LcbError("processEnd without begin");
+        begunValid = false;
+        std::vector<uint32_t> now(emu->used.begin(), emu->used.begin() + emu->usedWords);
+        std::copy(begunUsed.begin(), begunUsed.end(), emu->used.begin());
+        process(begunSeeds.data(), nullptr, (int64_t)begunSeeds.size(), off, inst, fpOff, fp);
+        std::copy(now.begin(), now.end(), emu->used.begin());
+    }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
@@ -448,6 +468,7 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
+                fprintf(stderr, "       early rounds %lld\n", (long long)es.earlyRounds);
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);

@@ -140,6 +140,7 @@ def emu_built():
 
 @pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NO_OVERLAP": "1"}),     # without the early launch of the next round
                                             # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
                                             ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1500"}),
                                             # every kernel variant: wide (LDS path set), big (index in LDS, fields in the workspace), huge (all in the workspace)
