@@ -169,10 +169,12 @@ def cpu_baseline(workload, threads, full):
         per_t[str(t)] = {"seeds_per_s": s / an, "analyze_s_median": an, "wall_s_median": statistics.median(x[1] for x in runs), "runs": len(runs),
                          "sample": w["desc"], "sample_seeds": s}
     same = md5(gff_ref) == md5(our_gff(big, threads)) if gff_ref else False
-    top = per_t[str(min(64, host))]
-    return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": min(64, host), "kind": "reference",
-            "sample": "%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %d, median of %d run(s), 'Analyzing' to 'Generating' banner "
-                      "%.2f s (includes its serial seed enumeration); host has %d hardware threads" % (big["desc"], min(64, host), top["runs"], top["analyze_s_median"], host),
+    # the reported figure is the reference's BEST thread count of the protocol (more threads are slower on this box)
+    best_t = max((t for t in per_t if t != "1"), key=lambda t: per_t[t]["seeds_per_s"])
+    top = per_t[best_t]
+    return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": int(best_t), "kind": "reference",
+            "sample": "%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %s (its fastest of -t 32 / -t 64), median of %d run(s), 'Analyzing' to "
+                      "'Generating' banner %.2f s (includes its serial seed enumeration); host has %d hardware threads" % (big["desc"], best_t, top["runs"], top["analyze_s_median"], host),
             "threads": per_t, "gff_md5_equal_on_sample": bool(same),
             "note": "-t 1 is timed on the smaller sample named in threads['1']; the reference's own wrapper caps -t at 32 (sibeliaz:139)"}
 
@@ -192,7 +194,7 @@ def main():
     ap.add_argument("--full-cpu-baseline", action="store_true", help="time the reference on the whole workload (minutes) instead of the bounded sample")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
-    ap.add_argument("--no-overlap", action="store_true", help="A/B: never begin the next round's launch while this round is committed")
+    ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     args = ap.parse_args()
@@ -245,7 +247,7 @@ def main():
     finder = sibeliaz_amd.BlocksFinder(storage, w["k"])
 
     def step():
-        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, no_overlap=1 if args.no_overlap else 0)
+        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, overlap=1 if args.overlap else 0)
         return finder.blocks, dict(finder.stats)
 
     def sync():

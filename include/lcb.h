@@ -212,7 +212,8 @@ typedef struct {
                                    2 the still-free instances of its phase-start result, 3 (default) a stale re-processed result if any, else as 2 */
     int32_t exchange_always;    /* 1: a single rank still packs / all-gathers / unpacks every launch (tests of the exchange path) */
     int32_t count_events;       /* 1: fill lcb_stats.events (the device must be in stats mode; one rank) */
-    int32_t no_overlap;         /* 1: never run the next round's launch while this round is being committed */
+    int32_t overlap;            /* 1: run the next round's speculative launch while this round is being committed (measured slower
+                                   on configs 2 and 3, so off by default) */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

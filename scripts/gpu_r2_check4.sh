@@ -8,7 +8,7 @@ sys.path.insert(0, os.getcwd())
 import bench
 bench.ensure_workload('primates8_scaled')" > gpurun_out/gen4.log 2>&1 ) &
 for v in 0 1; do
-  EXTRA=""; if [ $v = 1 ]; then EXTRA="--no-overlap"; fi
+  EXTRA=""; if [ $v = 0 ]; then EXTRA="--overlap"; fi
   timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cli $EXTRA > gpurun_out/ab4_c3_$v.json 2> gpurun_out/ab4_c3_$v.err
   timeout 600 python bench.py --workload ecoli10 --steps 3 --warmup 1 --no-cpu-baseline --no-cli $EXTRA > gpurun_out/ab4_c2_$v.json 2> gpurun_out/ab4_c2_$v.err
   python - <<PY

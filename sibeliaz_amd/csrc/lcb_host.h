@@ -113,7 +113,9 @@ struct LcbEngineConfig {
     int maxJobs = 0;          // a dry run stops planning beyond this many jobs (0 = the processor's concurrency)
     int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
     bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
-    bool overlap = true;      // begin the next round's launch while this round is committed (sparse stretches, one rank)
+    bool overlap = false;     // begin the next round's launch while this round is committed (sparse stretches, one rank). Off by
+                              // default: measured slower on configs 2 and 3 (the early results are computed against an older state, more of
+                              // them are void, and a stop has to wait for the early launch): 437 k vs 457 k and 1.87 M vs 1.93 M seeds/s
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
 };
 

@@ -217,16 +217,16 @@ def test_find_blocks_gpus_one_process(built, case):
     assert finder.stats["exchanges"] > 0
 
 
-@pytest.mark.parametrize("no_overlap", [0, 1])
-def test_overlapped_rounds(built, case, no_overlap):
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_overlapped_rounds(built, case, overlap):
     """The next round's speculative launch begun while the host commits the current round (second set of host buffers, results
     validated against everything the current round marks): same blocks with and without it. wide_threshold=1 / screen_min=1
     make even the small rounds of the golden cases take the asynchronous, screened compact path."""
     st, p, dev = _setup(case, wide_threshold=1, screen_min=1)
     finder = sibeliaz_amd.BlocksFinder(st, case.k)
-    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, no_overlap=no_overlap)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, overlap=overlap)
     got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
     assert got == case.golden("pretrim.tsv")
     summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
     assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
-    assert no_overlap == 0 or finder.stats["early_rounds"] == 0
+    assert overlap == 1 or finder.stats["early_rounds"] == 0
