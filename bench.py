@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
     ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
+    ap.add_argument("--device-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: a field of lcb_device_opts (e.g. path_cap=8192)")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     args = ap.parse_args()
 
@@ -232,7 +233,8 @@ def main():
     t_seeds = time.time() - t
     params = sibeliaz_amd.Params.make(w["k"], b=w["b"], m=w["m"])
     t = time.time()
-    dev = sibeliaz_amd.Device(storage, params, local_rank)          # tables now resident in HBM
+    dev_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.device_opt}
+    dev = sibeliaz_amd.Device(storage, params, local_rank, **dev_opts)          # tables now resident in HBM
     t_upload = time.time() - t
     S = len(seeds)
     log("bench[%d]: P=%d V=%d S=%d load %.2fs seeds %.2fs upload %.2fs" % (rank, storage.n_positions(), storage.GetVerticesNumber(), S, t_load, t_seeds, t_upload))

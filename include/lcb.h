@@ -128,13 +128,15 @@ typedef struct {
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
     uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
     uint32_t huge_slots;     /* ... of the huge variant (all per-path state in HBM); default 1 per 4 CUs */
-    uint32_t path_cap;       /* path vertex set capacity of a compact slot (power of two; HBM-resident); default 131072 */
+    uint32_t path_cap;       /* INITIAL path vertex set capacity of a compact slot (power of two; HBM-resident); default 32768.
+                                Grows x4 on demand (a path of few instances that overflows it) up to path_cap_max */
     uint32_t wide_path_cap;  /* ... of a wide slot (the set lives in LDS); default and maximum 8192 */
     uint32_t max_views;      /* predicted `used` views kept behind the live bitmap; default 256 (within 2 GiB) */
     uint32_t batch;          /* seeds per launch; default 65536 */
     uint32_t wide_threshold; /* calls with at most this many seeds start in the wide variant; default 2 * wide_slots */
     uint32_t start_mode;     /* 0 = automatic; 1 / 2 / 3 / 4 = every seed starts in the compact / wide / big / huge variant */
     uint32_t screen_min;     /* launches of at least this many seeds are screened first; default 2048 */
+    uint32_t path_cap_max;   /* largest compact path set (a seed that needs more goes to the big variant); default 1 << 20 */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows

@@ -211,6 +211,7 @@ struct lcb_device_impl {
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
     int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
     int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
+    int compactPathGrown = 0;                    // times the compact path set was enlarged (x4 each)
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
 
@@ -368,7 +369,9 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
-        if (!o.path_cap) o.path_cap = 131072;
+        if (!o.path_cap) o.path_cap = 32768;
+        if (!o.path_cap_max) o.path_cap_max = 1u << 20;
+        if (o.path_cap_max < o.path_cap) o.path_cap_max = o.path_cap;
         if (!o.max_views) o.max_views = 256;
         if (!o.batch) o.batch = 65536;
         if (!o.wide_threshold) o.wide_threshold = 2 * o.wide_slots;
@@ -477,6 +480,7 @@ void lcb_device_destroy_impl(lcb_device* h)
             fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->poolPages);
+            fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
             for (int m = 0; m < 4; m++)
                 fprintf(stderr, "   overflows out of %-7s: instances %lld vote table %lld path %lld snapshot %lld\n", modeName(m), (long long)d->overflow[m][LCB_ST_INST_OVF],
                         (long long)d->overflow[m][LCB_ST_VOTE_OVF], (long long)d->overflow[m][LCB_ST_PATH_OVF], (long long)d->overflow[m][LCB_ST_BEST_OVF]);
@@ -663,6 +667,7 @@ struct ProcAcc {
     std::vector<int64_t> todo[4];                       // seeds still to run, per kernel variant
     std::vector<uint8_t> tried;                         // per seed: bit m = it overflowed variant m in this call
     std::vector<lcb_seed> ownSeeds;                     // (an asynchronous call keeps its own copy of the seeds)
+    bool growCompactPath = false;                       // a compact seed overflowed the path set and the set can still grow
 };
 
 uint64_t hintKey(const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; }
@@ -756,9 +761,18 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
             // The next variant. The ladder is compact -> wide -> big -> huge by capacity of instances and vote table, but the
             // PATH capacity is the other way round between the first two: the wide variant keeps its path set in LDS (4096
             // vertices), the compact one in HBM (65 536). A long path with few instances (long blocks of few genomes, k = 25)
-            // that started in the wide variant therefore goes back to the compact one; only what overflowed both goes on to big.
+            // that started in the wide variant therefore goes back to the compact one - unless it already holds more
+            // instances than half the compact pool (the repeat-rich seeds of config 3: thousands of instances AND > 4096
+            // pushes; they would crawl through the compact variant only to overflow its pool) - the rest goes on to big.
             int nextMode = mode < 3 ? mode + 1 : 3;
-            if (mode == 1 && o.status == LCB_ST_PATH_OVF && !(A.tried[(size_t)s] & 1u)) nextMode = 0;
+            if (mode == 1 && o.status == LCB_ST_PATH_OVF && !(A.tried[(size_t)s] & 1u) && o.poolInst * 2 <= LcbCfg<0>::IC) nextMode = 0;
+            else if (mode == 0 && o.status == LCB_ST_PATH_OVF && d->ws[0].pathCap < d->o.path_cap_max && o.poolInst * 2 <= LcbCfg<0>::IC) {
+                // a long path of few instances: the compact slots get a larger path set (runToCompletion) and the seed runs there again
+                A.growCompactPath = true;
+                A.tried[(size_t)s] &= (uint8_t)~1u;
+                A.todo[0].push_back(s);
+                continue;
+            }
             else if (mode == 0 && o.status == LCB_ST_PATH_OVF) nextMode = 2;
             else if (mode == 0 && (A.tried[(size_t)s] & 2u)) nextMode = 2;
             if (mode == 3) hugeOverflow = true; else setHint(d, A.seeds[s], (uint8_t)nextMode);
@@ -788,6 +802,15 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
         }
+        if (A.growCompactPath) {
+            // The compact path set starts small on purpose (the sets of all slots together stay cache-resident: 1280 x 128 KB)
+            // and grows only for workloads whose paths need it (k = 25, long blocks of few genomes)
+            A.growCompactPath = false;
+            WorkSet& c = d->ws[0];
+            c.pathCap = (uint32_t)std::min<uint64_t>((uint64_t)c.pathCap * 4, d->o.path_cap_max); c.bodyCap = c.pathCap / 2;
+            d->allocWork(c);
+            d->compactPathGrown++;
+        } else
         if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)

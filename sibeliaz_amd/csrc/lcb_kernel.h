@@ -111,7 +111,7 @@ struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint64_t arenaOff;
     uint64_t fpOff;            // first footprint interval of this seed in the footprint arena
     uint32_t nFp;              // number of footprint intervals (= instances ever created)
-    uint32_t pad;
+    uint32_t poolInst;         // instances in the pool when the seed ended (on an overflow: what the next variant has to hold at least)
 };
 struct LcbSeedCtr { uint64_t c[8]; };   // lcb_counters order in stats mode, a cheap profile in the instrumented variant
 
@@ -242,6 +242,7 @@ struct LcbStateT {
     // of the next vote (blocksfinder.h:716-717) — no scan over the instance list is needed.
     uint16_t* touch;
     uint32_t nTouch, nInit;
+    uint32_t endInst;          // instances in the pool when the seed ended (reported with an overflow status: the host picks the next variant by it)
     // Footprint: per instance ever created, the range of flat positions whose `used` bit was read as 0 and could
     // have changed the result (its span plus every look-ahead window walked from its ends). A result computed
     // against an older `used` snapshot is still exact iff no bit inside these ranges has been set since
@@ -1243,7 +1244,7 @@ template <int MODE, bool STATS, bool PROF, int NW, class ST>
 __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
     int64_t score = 0, bestScore = 0;
-    S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0;
+    S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0; S.endInst = 0;
     LCB_MARK(S, 2, 1);
     lcb_path_init<STATS>(S, vid, ch);
     LCB_MARK(S, 2, 2); LCB_MARK(S, 3, S.nInst);
@@ -1306,6 +1307,7 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
         }
     }
     LCB_MARK(S, 2, 5);
+    S.endInst = S.nInst;
     lcb_path_clear(S);            // Path::Clear (blocksfinder.h:308)
     bestScoreOut = bestScore;
 }
@@ -1502,7 +1504,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             LcbSeedOut* o = sArgs.out + s;
             o->nInst = n;   // kept on ARENA_OVF so the host can track the allocator
             o->status = S.status; o->bestScore = bestScore; o->arenaOff = off;
-            o->fpOff = fpo; o->nFp = nfp; o->pad = 0;
+            o->fpOff = fpo; o->nFp = nfp; o->poolInst = S.endInst;
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }

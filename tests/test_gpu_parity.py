@@ -77,12 +77,24 @@ def test_overflow_chain_reaches_big_mode(built, case):
     """Tiny path sets in the compact AND the wide slots: a seed that pushes more than a few vertices overflows the compact
     variant's path set, skips the wide one (whose LDS path set is the smaller of the two) and ends in the big variant; results
     are the oracle's."""
-    st, p, dev = _setup(case, path_cap=16, wide_path_cap=16, start_mode=1)
+    st, p, dev = _setup(case, path_cap=16, path_cap_max=16, wide_path_cap=16, start_mode=1)
     orc = Oracle(case.graph, [case.fasta], case.k, case.a)
     seeds = st.seeds(4)[:600]
     _compare_all(case, st, dev, orc, seeds, "overflow chain")
     counts = dev.mode_seeds()
     assert counts[0] == len(seeds) and counts[2] > 0, counts
+
+
+def test_compact_path_set_grows_on_demand(built, case):
+    """The compact variant's HBM path set starts small (so that the sets of all slots stay cache-resident) and is enlarged x4
+    when a path of few instances overflows it: with a 16-vertex start every longer path is re-run in the compact variant after
+    a growth, nothing reaches the big variant, results are the oracle's."""
+    st, p, dev = _setup(case, path_cap=16, start_mode=1)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    seeds = st.seeds(4)[:600]
+    _compare_all(case, st, dev, orc, seeds, "growing compact path set")
+    counts = dev.mode_seeds()
+    assert counts[0] > len(seeds) and counts[2] == 0 and counts[3] == 0, counts
 
 
 def test_long_paths_fall_back_from_wide_to_compact(built, case):
