@@ -15,8 +15,9 @@ The JSON line also carries
   roofline      the process kernels (lcb_process_kernel, all variants): ALGORITHMIC bytes per launch (SURVEY.md §8d formula
                 over the reference-semantics event counters, counted by the kernels themselves in one untimed stats-mode pass of
                 the engine) / average launch duration, measured in this run with HIP events on the kernels' stream; against the
-                8 TB/s HBM peak, with this GPU's measured STREAM-triad rate beside it. `traffic` (PMC) is not measured inside
-                this run: null here, the rocprofv3 --pmc summaries are committed under profiles/.
+                8 TB/s HBM peak, with this GPU's measured STREAM-triad rate beside it. `traffic` (PMC) cannot be measured inside
+                this run: it is the per-launch figure of the committed rocprofv3 --pmc passes of this same command
+                (profiles/r02/pmc_traffic.json) for the default workload, null for the others.
   cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container) timed
                 on this box's host cores on a BOUNDED sample of the same workload (same generator and parameters, 1/10 of
                 the ancestor's segments; 1/40 for the single-thread run): -t 1, -t 32 (the cap of the reference's wrapper
@@ -312,14 +313,21 @@ def main():
         lps = launches / float(args.steps)
         achieved = abytes / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
         triad = dev.hbm_triad()
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command
+        # (scripts/gpu_r2_evidence.sh), committed with the profile summaries; only for the workload they were taken on
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        if args.workload == "ecoli62" and world == 1 and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
         line = {
             "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": w["desc"], "lcb_synth": w["synth"], "seeds": S, "junction_occurrences": storage.n_positions(),
                        "vertices": storage.GetVerticesNumber(), "phase_size": 256,
-                       "parallelism": "one seed per workgroup: compact variant 1 wavefront x 6 per CU for launches of many seeds, wide variant 16 wavefronts sharing the votes "
-                                      "for launches of few; speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint "
+                       "parallelism": "one seed per workgroup: compact variant (2 wavefronts, 5 workgroups per CU) for launches of many seeds, wide variant (16 wavefronts "
+                                      "sharing the votes) for launches of few, big variant for seeds with thousands of instances; speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint "
                                       "validation; %d GPU(s)%s" % (world, ", every launch dealt to the ranks, ncclAllGather of results" if world > 1 else ""),
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
@@ -329,7 +337,7 @@ def main():
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
                        "untimed_s": {"load_graph": t_load, "enumerate_seeds": t_seeds, "create_device_upload_tables": t_upload}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "lcb_process_kernel (all variants)", "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": abytes / max(1.0, lps), "avg_launch_ms": kernel_ms / max(1, launches),
                          "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps, "bytes_per_seed": abytes / S,
