@@ -137,6 +137,8 @@ typedef struct {
     uint32_t start_mode;     /* 0 = automatic; 1 / 2 / 3 / 4 = every seed starts in the compact / wide / big / huge variant */
     uint32_t screen_min;     /* launches of at least this many seeds are screened first; default 2048 */
     uint32_t path_cap_max;   /* largest compact path set (a seed that needs more goes to the big variant); default 1 << 20 */
+    uint32_t arena;          /* INITIAL capacity of the pinned result arena of a launch, in instances (and footprint intervals);
+                                default 1 << 22; enlarged x4 when a launch fills it (its unlucky seeds run again) */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows

@@ -212,6 +212,7 @@ struct lcb_device_impl {
     int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
     int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
     int compactPathGrown = 0;                    // times the compact path set was enlarged (x4 each)
+    int arenaGrown = 0;                          // times the result arena was enlarged (x4 each)
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
 
@@ -371,6 +372,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
         if (!o.path_cap) o.path_cap = 32768;
         if (!o.path_cap_max) o.path_cap_max = 1u << 20;
+        if (!o.arena) o.arena = 1u << 22;
         if (o.path_cap_max < o.path_cap) o.path_cap_max = o.path_cap;
         if (!o.max_views) o.max_views = 256;
         if (!o.batch) o.batch = 65536;
@@ -442,12 +444,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
-        d->allocArena(1u << 20);
+        d->allocArena(o.arena);
         d->swapBufs();
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hLive, ((size_t)d->batchCap + 1) * sizeof(uint32_t), hipHostMallocDefault));
-        d->allocArena(1u << 20);
+        d->allocArena(o.arena);
         d->swapBufs();
         const char* tf = getenv("LCB_TRACE_LAUNCHES");
         if (tf && *tf) d->traceFile = fopen(tf, "w");
@@ -481,6 +483,7 @@ void lcb_device_destroy_impl(lcb_device* h)
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->poolPages);
             fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
+            fprintf(stderr, "   result arena: %llu instances (enlarged %d times)\n", d->arenaCap, d->arenaGrown);
             for (int m = 0; m < 4; m++)
                 fprintf(stderr, "   overflows out of %-7s: instances %lld vote table %lld path %lld snapshot %lld\n", modeName(m), (long long)d->overflow[m][LCB_ST_INST_OVF],
                         (long long)d->overflow[m][LCB_ST_VOTE_OVF], (long long)d->overflow[m][LCB_ST_PATH_OVF], (long long)d->overflow[m][LCB_ST_BEST_OVF]);
@@ -668,6 +671,7 @@ struct ProcAcc {
     std::vector<uint8_t> tried;                         // per seed: bit m = it overflowed variant m in this call
     std::vector<lcb_seed> ownSeeds;                     // (an asynchronous call keeps its own copy of the seeds)
     bool growCompactPath = false;                       // a compact seed overflowed the path set and the set can still grow
+    int64_t arenaOvf = 0;                               // seeds of the current variant's launches that found the result arena full
 };
 
 uint64_t hintKey(const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; }
@@ -755,6 +759,7 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
             throw LcbError("device: a seed of the launch was not processed");
         } else if (o.status == LCB_ST_ARENA_OVF) {
             A.todo[mode].push_back(s);                          // same variant again: the arena is emptied between launches
+            A.arenaOvf++;
         } else {
             if (o.status < 8) d->overflow[mode][o.status]++;
             A.tried[(size_t)s] |= (uint8_t)(1u << mode);
@@ -810,8 +815,14 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             c.pathCap = (uint32_t)std::min<uint64_t>((uint64_t)c.pathCap * 4, d->o.path_cap_max); c.bodyCap = c.pathCap / 2;
             d->allocWork(c);
             d->compactPathGrown++;
+        } else if (A.arenaOvf && d->arenaCap < (1ull << 26)) {
+            // Seeds that found the result arena full were computed for nothing: it is enlarged at the first sign (config 3 lost
+            // 10 % of its kernel time to second and third launches of the same seeds with a fixed arena of 2^20 instances)
+            d->allocArena(d->arenaCap * 4);
+            d->arenaGrown++;
         } else
         if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
+        A.arenaOvf = 0;
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
             WorkSet& b = d->ws[3];

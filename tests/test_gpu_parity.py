@@ -97,6 +97,15 @@ def test_compact_path_set_grows_on_demand(built, case):
     assert counts[0] > len(seeds) and counts[2] == 0 and counts[3] == 0, counts
 
 
+def test_result_arena_grows_when_a_launch_fills_it(built, case):
+    """A launch whose results do not fit the pinned result arena re-runs the unlucky seeds after the arena was enlarged (x4 at
+    the first overflow, so that a workload pays for it once or twice, not in every round): a 64-instance start still gives the
+    oracle's results for every seed."""
+    st, p, dev = _setup(case, arena=64)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    _compare_all(case, st, dev, orc, st.seeds(4), "tiny result arena")
+
+
 def test_long_paths_fall_back_from_wide_to_compact(built, case):
     """The wide variant keeps its path set in LDS (4096 vertices), the compact one in HBM: a path that overflows the wide
     variant's set is re-run in the compact variant, not in the slow big one."""
