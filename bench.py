@@ -16,8 +16,8 @@ The JSON line also carries
                 over the reference-semantics event counters, counted by the kernels themselves in one untimed stats-mode pass of
                 the engine) / average launch duration, measured in this run with HIP events on the kernels' stream; against the
                 8 TB/s HBM peak, with this GPU's measured STREAM-triad rate beside it. `traffic` (PMC) cannot be measured inside
-                this run: it is the per-launch figure of the committed rocprofv3 --pmc passes of this same command
-                (profiles/r02/pmc_traffic.json) for the default workload, null for the others.
+                this run and is null; `traffic_profiled` quotes the per-launch figure of the committed rocprofv3 --pmc
+                passes of this same command (profiles/r02/pmc_traffic.json) for the default workload.
   cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container) timed
                 on this box's host cores on a BOUNDED sample of the same workload (same generator and parameters, 1/10 of
                 the ancestor's segments; 1/40 for the single-thread run): -t 1, -t 32 (the cap of the reference's wrapper
@@ -337,7 +337,8 @@ def main():
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
                        "untimed_s": {"load_graph": t_load, "enumerate_seeds": t_seeds, "create_device_upload_tables": t_upload}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_profiled": {"hbm_bytes_per_launch": traffic, "source": traffic_src} if traffic else None,
                          "kernel": "lcb_process_kernel (all variants)", "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": abytes / max(1.0, lps), "avg_launch_ms": kernel_ms / max(1, launches),
                          "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps, "bytes_per_seed": abytes / S,
