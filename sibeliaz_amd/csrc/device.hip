@@ -213,6 +213,8 @@ struct lcb_device_impl {
     int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
     int compactPathGrown = 0;                    // times the compact path set was enlarged (x4 each)
     int arenaGrown = 0;                          // times the result arena was enlarged (x4 each)
+    double recentBigFrac = 0;                    // share of the seeds of the last sizeable call that needed the big variant
+    int64_t joinedBig = 0;                       // seeds that ran in the big variant because their call had to go there anyway
 
     void use() { HIP_CHECK(hipSetDevice(ordinal)); }
 
@@ -484,6 +486,7 @@ void lcb_device_destroy_impl(lcb_device* h)
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->poolPages);
             fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
             fprintf(stderr, "   result arena: %llu instances (enlarged %d times)\n", d->arenaCap, d->arenaGrown);
+            fprintf(stderr, "   seeds that joined a call's big launch instead of a wide launch in front of it: %lld\n", (long long)d->joinedBig);
             for (int m = 0; m < 4; m++)
                 fprintf(stderr, "   overflows out of %-7s: instances %lld vote table %lld path %lld snapshot %lld\n", modeName(m), (long long)d->overflow[m][LCB_ST_INST_OVF],
                         (long long)d->overflow[m][LCB_ST_VOTE_OVF], (long long)d->overflow[m][LCB_ST_PATH_OVF], (long long)d->overflow[m][LCB_ST_BEST_OVF]);
@@ -524,6 +527,7 @@ void lcb_device_reset_used_impl(lcb_device* h)
     d->use();
     if (d->lastViews) { HIP_CHECK(hipMemsetAsync(d->dViewTab + d->nPages, 0, (size_t)d->lastViews * d->nPages * 4, d->stream)); d->lastViews = 0; }
     d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
+    d->recentBigFrac = 0;
     std::fill(d->hintBits.begin(), d->hintBits.end(), 0ull);
     HIP_CHECK(hipMemsetAsync(d->dUsed, 0, d->usedWords * 4, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
@@ -672,6 +676,9 @@ struct ProcAcc {
     std::vector<lcb_seed> ownSeeds;                     // (an asynchronous call keeps its own copy of the seeds)
     bool growCompactPath = false;                       // a compact seed overflowed the path set and the set can still grow
     int64_t arenaOvf = 0;                               // seeds of the current variant's launches that found the result arena full
+    std::vector<uint8_t> start;                         // first variant of every seed of the call
+    bool allBig = false;                                // every seed of the call starts in the big variant (accInit)
+    int64_t neededBig = 0;                              // seeds that finished in the big / huge variant and could not have run in a smaller one
 };
 
 uint64_t hintKey(const lcb_seed& sd) { return ((uint64_t)(uint32_t)sd.vid << 8) | (uint64_t)(uint8_t)sd.ch; }
@@ -696,14 +703,27 @@ void accInit(lcb_device_impl* d, ProcAcc& A, const lcb_seed* seeds, int64_t n, c
     // and compact for calls with many (throughput); a seed that overflowed a variant earlier in this pass starts where it ended up
     const int base = d->o.start_mode ? (int)d->o.start_mode - 1 : (n <= (int64_t)d->o.wide_threshold ? 1 : 0);
     if (d->modeHint.empty() || d->o.start_mode) { A.todo[base].resize((size_t)n); for (int64_t s = 0; s < n; s++) A.todo[base][(size_t)s] = s; }
-    else
+    else {
+        A.start.assign((size_t)n, (uint8_t)base);
+        int64_t nBig = 0;
         for (int64_t s = 0; s < n; s++) {
             const uint64_t key = hintKey(seeds[s]);
             const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
-            int m = base;
-            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) m = it->second; }
-            A.todo[m].push_back(s);
+            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) A.start[(size_t)s] = it->second; }
+            nBig += A.start[(size_t)s] >= 2;
         }
+        // Variants run one after the other and a launch lasts as long as its longest seed. In the stretch of the seed order
+        // where seeds outgrow the wide variant (config 3: the first ~12 000 seeds are paths of 3 000 - 7 000 vertices whose pools
+        // reach 1 000 - 3 600 instances) a small call that has to visit the big variant anyway is as long as its big launch:
+        // everything runs there, instead of a wide launch of tens of ms in front of it (73 such launches, 3.0 s of a 22-s
+        // pass, in profiles/r02/launch_trace_config3.tsv). Two triggers: at least an eighth of the call's seeds are already known
+        // to need the big variant, or the last sizeable call sent at least 5 % of its seeds there.
+        const bool small = n <= 2 * (int64_t)d->ws[2].nSlots;
+        const bool allBig = small && (nBig * 8 >= n || (n >= 64 && d->recentBigFrac >= 0.05));
+        for (int64_t s = 0; s < n; s++) A.todo[allBig && A.start[(size_t)s] < 2 ? 2 : A.start[(size_t)s]].push_back(s);
+        A.allBig = allBig;
+        if (allBig) d->joinedBig += n - nBig;
+    }
 }
 
 void fillSeeds(lcb_device_impl* d, const ProcAcc& A, const std::vector<int64_t>& list, size_t at, uint32_t m)
@@ -726,6 +746,7 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
         const LcbSeedOut& o = d->hOut[i];
         const int64_t s = list[at + i];
         if (o.status == LCB_ST_OK) {
+            if (mode >= 2 && (!(A.allBig && A.start[(size_t)s] < 2) || o.poolInst > LcbCfg<1>::IC)) A.neededBig++;
             A.cnt[(size_t)s] = o.nInst;
             A.flatOff[(size_t)s] = A.flat.size();
             if (o.nInst) {
@@ -832,6 +853,7 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->allocWork(b);
         } else if (mode == 3 && !A.todo[3].empty()) d->allocArena(d->arenaCap * 4);
     }
+    if (A.n >= 64 && !d->o.start_mode) d->recentBigFrac = (double)A.neededBig / (double)A.n;
 }
 
 void accLayout(ProcAcc& A, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut)
