@@ -1,0 +1,18 @@
+# Round 3, first GPU call: A/B of the candidates prepared at the end of round 2 (no GPU budget was left to measure them).
+# Same box, config 3 at full size, one pass each (hints are per pass), plus the parity tests of each variant build.
+#   base     the shipped build
+#   bighot   -DLCB_BIG_HOT=256u : fields of the first 256 pool entries of the big variant in LDS (build: python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u)
+#   jobs256  lcb_hooks.max_jobs = 256 (job launches in the wide variant; 0.8 % of 1 280 jobs per stop are used)
+mkdir -p gpurun_out
+export LCB_WATCHDOG_S=300
+python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u
+for v in base bighot; do
+  LIB=""; if [ $v != base ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  LCB_LIB=$LIB timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 100 -x -k "variant or overflow" 2>&1 | grep -E "passed|failed|rror" | tail -2
+  LCB_LIB=$LIB LCB_VERBOSE=1 LCB_TRACE_LAUNCHES=gpurun_out/r3ab_trace_$v.tsv timeout 200 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline > gpurun_out/r3ab_$v.json 2> gpurun_out/r3ab_$v.err
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/r3ab_$v.json"))
+print("$v: %.0f seeds/s, %.1f ms, kernel %.1f ms, launches %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"].get("launches_per_step")))
+PY
+done

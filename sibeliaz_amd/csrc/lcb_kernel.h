@@ -223,16 +223,35 @@ __device__ __forceinline__ uint32_t lcb_wave_umin(uint32_t v) { return ~lcb_wave
 #define LCB_FLAG_FRONTFIN 4u
 #define LCB_FLAG_BITS 3u       // iFlags = (chromosome << 3) | flags
 
+// Big variant, optional (build with -DLCB_BIG_HOT=<n>, a round-3 candidate that is NOT in the shipped build): the fields of
+// the first n pool entries live in LDS, the rest in the workgroup's HBM slot. The pool of a long path grows to thousands of
+// instances that are never removed (path.h:684) while the instances that are extended, voted and scored at every step are the
+// initial ones — the lowest pool indices (profiles/r02/launch_trace_analysis.md).
+#ifndef LCB_BIG_HOT
+#define LCB_BIG_HOT 0u
+#endif
+template <class T> struct LcbHotCold {
+    T* hot; T* cold;
+    __device__ __forceinline__ T& operator[](uint32_t i) const { return i < LCB_BIG_HOT ? hot[i] : cold[i]; }
+};
+template <class T, bool SPLIT> struct LcbFieldSel { typedef T* type; };
+template <class T> struct LcbFieldSel<T, true> { typedef LcbHotCold<T> type; };
+template <class T> __device__ __forceinline__ void lcb_field_set(T*& f, T* hot, T* cold) { (void)hot; f = cold; }
+template <class T> __device__ __forceinline__ void lcb_field_set(LcbHotCold<T>& f, T* hot, T* cold) { f.hot = hot; f.cold = cold; }
+
 template <int MODE_>
 struct LcbStateT {
     static constexpr int MODE = MODE_;
+    static constexpr bool SPLIT = MODE_ == 2 && LCB_BIG_HOT > 0u;
+    typedef typename LcbFieldSel<uint32_t, SPLIT>::type FieldU;
+    typedef typename LcbFieldSel<int32_t, SPLIT>::type FieldI;
     LcbTables T;
     LcbUsed U;                 // the `used` state this seed reads
     LcbKParams P;
     uint32_t lane;
     // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
-    uint32_t *iFrontG, *iBackG, *iFrontPos, *iBackPos, *iLo, *iHi, *iFlags;
-    int32_t *iFrontDist, *iBackDist;
+    FieldU iFrontG, iBackG, iFrontPos, iBackPos, iLo, iHi, iFlags;
+    FieldI iFrontDist, iBackDist;
     uint32_t* ordKey;          // instance_ ordered sets flattened: keys (flat compare position) ... [2][instCap], half `cur` is live
     uint16_t* ordIdx;          // ... and pool indices, double buffered the same way
     uint16_t* good;            // goodInstance_ (path.h:685), pool indices in append order
@@ -247,7 +266,7 @@ struct LcbStateT {
     // have changed the result (its span plus every look-ahead window walked from its ends). A result computed
     // against an older `used` snapshot is still exact iff no bit inside these ranges has been set since
     // (bits only go 0 -> 1 and the computation is deterministic). Survives the replay's Clear.
-    uint32_t *fpLo, *fpHi;
+    FieldU fpLo, fpHi;
     uint32_t nFp;
     uint32_t instCap;
     // vote table (open addressing): key, accumulated weight, (list ordinal << 16) | step of the last contribution
@@ -1378,8 +1397,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.ck = (uint32_t*)(slot + L.ck); S.ckN = S.ckInst = S.ckGood = S.ckPath = 0; S.ckFlank = 0;
     uint32_t* instBase;
     uint32_t instStride;                                           // words between the instance field arrays
-    if (INST_LDS) { instBase = sInst; instStride = IC; S.fpLo = sFp; S.fpHi = sFp + IC; }
-    else { instBase = (uint32_t*)(slot + L.inst); instStride = W.instCap; S.fpLo = (uint32_t*)(slot + L.fp); S.fpHi = S.fpLo + W.instCap; }
+    constexpr uint32_t HOT = LcbStateT<MODE>::SPLIT ? LCB_BIG_HOT : 0u;
+    __shared__ uint32_t sHot[HOT ? 11u * HOT : 1u];
+    uint32_t *fpBase;
+    if (INST_LDS) { instBase = sInst; instStride = IC; fpBase = sFp; }
+    else { instBase = (uint32_t*)(slot + L.inst); instStride = W.instCap; fpBase = (uint32_t*)(slot + L.fp); }
+    lcb_field_set(S.fpLo, sHot + 9u * HOT, fpBase); lcb_field_set(S.fpHi, sHot + 10u * HOT, fpBase + instStride);
     if (IDX_LDS) {
         S.instCap = IC;
         S.ordKey = sOrdKey; S.ordIdx = sOrdIdx; S.good = sGood; S.goodPos = sGoodPos; S.touch = sTouch;
@@ -1398,10 +1421,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.bloomShift = BW ? 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u : 0u;
     for (uint32_t h = threadIdx.x; h < BW; h += 64 * NW) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
-    S.iFrontG = instBase; S.iBackG = instBase + instStride; S.iFrontPos = instBase + 2 * instStride;
-    S.iBackPos = instBase + 3 * instStride; S.iLo = instBase + 4 * instStride;
-    S.iHi = instBase + 5 * instStride; S.iFlags = instBase + 6 * instStride;
-    S.iFrontDist = (int32_t*)(instBase + 7 * instStride); S.iBackDist = (int32_t*)(instBase + 8 * instStride);
+    lcb_field_set(S.iFrontG, sHot, instBase); lcb_field_set(S.iBackG, sHot + HOT, instBase + instStride);
+    lcb_field_set(S.iFrontPos, sHot + 2u * HOT, instBase + 2 * instStride); lcb_field_set(S.iBackPos, sHot + 3u * HOT, instBase + 3 * instStride);
+    lcb_field_set(S.iLo, sHot + 4u * HOT, instBase + 4 * instStride); lcb_field_set(S.iHi, sHot + 5u * HOT, instBase + 5 * instStride);
+    lcb_field_set(S.iFlags, sHot + 6u * HOT, instBase + 6 * instStride);
+    lcb_field_set(S.iFrontDist, (int32_t*)(sHot + 7u * HOT), (int32_t*)(instBase + 7 * instStride));
+    lcb_field_set(S.iBackDist, (int32_t*)(sHot + 8u * HOT), (int32_t*)(instBase + 8 * instStride));
     S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
