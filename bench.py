@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--device-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: a field of lcb_device_opts (e.g. path_cap=8192)")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: an engine field of lcb_hooks (e.g. max_jobs=256)")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
     args = ap.parse_args()
 
@@ -235,6 +236,9 @@ def main():
     params = sibeliaz_amd.Params.make(w["k"], b=w["b"], m=w["m"])
     t = time.time()
     dev_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.device_opt}
+    engine_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.engine_opt}
+    if args.overlap:
+        engine_opts["overlap"] = 1
     dev = sibeliaz_amd.Device(storage, params, local_rank, **dev_opts)          # tables now resident in HBM
     t_upload = time.time() - t
     S = len(seeds)
@@ -250,7 +254,7 @@ def main():
     finder = sibeliaz_amd.BlocksFinder(storage, w["k"])
 
     def step():
-        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, overlap=1 if args.overlap else 0)
+        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, **engine_opts)
         return finder.blocks, dict(finder.stats)
 
     def sync():

@@ -6,10 +6,13 @@
 mkdir -p gpurun_out
 export LCB_WATCHDOG_S=300
 python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u
-for v in base bighot; do
-  LIB=""; if [ $v != base ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
-  LCB_LIB=$LIB timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 100 -x -k "variant or overflow" 2>&1 | grep -E "passed|failed|rror" | tail -2
-  LCB_LIB=$LIB LCB_VERBOSE=1 LCB_TRACE_LAUNCHES=gpurun_out/r3ab_trace_$v.tsv timeout 200 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline > gpurun_out/r3ab_$v.json 2> gpurun_out/r3ab_$v.err
+for v in base bighot jobs256 jobs512; do
+  LIB=""; EXTRA=""
+  if [ $v = bighot ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  if [ $v = jobs256 ]; then EXTRA="--engine-opt max_jobs=256"; fi
+  if [ $v = jobs512 ]; then EXTRA="--engine-opt max_jobs=512"; fi
+  if [ -n "$LIB" ]; then LCB_LIB=$LIB timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 100 -x -k "variant or overflow" 2>&1 | grep -E "passed|failed|rror" | tail -2; fi
+  LCB_LIB=$LIB LCB_VERBOSE=1 LCB_TRACE_LAUNCHES=gpurun_out/r3ab_trace_$v.tsv timeout 200 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline $EXTRA > gpurun_out/r3ab_$v.json 2> gpurun_out/r3ab_$v.err
   python - <<PY
 import json
 d = json.load(open("gpurun_out/r3ab_$v.json"))
