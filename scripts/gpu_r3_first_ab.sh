@@ -2,13 +2,17 @@
 # Same box, config 3 at full size, one pass each (hints are per pass), plus the parity tests of each variant build.
 #   base     the shipped build
 #   bighot   -DLCB_BIG_HOT=256u : fields of the first 256 pool entries of the big variant in LDS (build: python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u)
-#   jobs256  lcb_hooks.max_jobs = 256 (job launches in the wide variant; 0.8 % of 1 280 jobs per stop are used)
+#   jobs64 / jobs256 / jobs512   lcb_hooks.max_jobs (job launches in the wide variant; 0.8 % of the 1 280 jobs per stop are used)
+#   nwbig16  -DLCB_NW_BIG=16 : 16 wavefronts in the big variant
+# and a per-seed section trace (LCB_TRACE_SEEDS=1: vote / push / score split of the slowest seeds) of the shipped build
 mkdir -p gpurun_out
 export LCB_WATCHDOG_S=300
 python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u
-for v in base bighot jobs256 jobs512; do
+python sibeliaz_amd/build.py variant nwbig16 -DLCB_NW_BIG=16
+for v in base bighot nwbig16 jobs64 jobs256 jobs512; do
   LIB=""; EXTRA=""
-  if [ $v = bighot ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  if [ $v = bighot ] || [ $v = nwbig16 ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  if [ $v = jobs64 ]; then EXTRA="--engine-opt max_jobs=64"; fi
   if [ $v = jobs256 ]; then EXTRA="--engine-opt max_jobs=256"; fi
   if [ $v = jobs512 ]; then EXTRA="--engine-opt max_jobs=512"; fi
   if [ -n "$LIB" ]; then LCB_LIB=$LIB timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 100 -x -k "variant or overflow" 2>&1 | grep -E "passed|failed|rror" | tail -2; fi
@@ -19,3 +23,6 @@ d = json.load(open("gpurun_out/r3ab_$v.json"))
 print("$v: %.0f seeds/s, %.1f ms, kernel %.1f ms, launches %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"].get("launches_per_step")))
 PY
 done
+LCB_TRACE_SEEDS=1 LCB_TRACE_LAUNCHES=gpurun_out/r3ab_seedtrace.tsv timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline > gpurun_out/r3ab_seedtrace.json 2> gpurun_out/r3ab_seedtrace.err
+python scripts/analyze_trace.py gpurun_out/r3ab_seedtrace.tsv | tee gpurun_out/r3ab_seedtrace_summary.txt
+gzip -f gpurun_out/r3ab_seedtrace.tsv

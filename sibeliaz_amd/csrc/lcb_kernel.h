@@ -1244,7 +1244,10 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
                     if (nowScore > bestScore) {
                         bestScore = nowScore;
                         if (FORWARD) bestRightSize = S.nRight + 1;
-                        if (nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
+                        // bestInstance <- goodInstance_ (blocksfinder.h:820-824,883-887). Forward: the replay after the forward
+                        // extension rebuilds exactly the state of the best point, so the copy is taken once, there
+                        // (lcb_process_seed), not at every improvement on the way — a growing block improves at almost every push.
+                        if (!FORWARD && nowScore > 0) { lcb_snapshot(S); if (S.status) return false; }
                         if (FORWARD && !STATS && S.nRight >= S.ckN + LCB_CK_EVERY) lcb_checkpoint(S);
                     }
                     if (PROF) S.pfTScore += wall_clock64() - tp1;
@@ -1307,6 +1310,8 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
             }
             from += nE;
         }
+        // the state is the one of the best forward point: its good instances are the best instances so far
+        if (!S.status && bestScore > 0) lcb_snapshot(S);
     }
     LCB_MARK(S, 2, 4);
     if (!S.status && !dead) {
