@@ -499,7 +499,19 @@ typedef struct {
     int* allInstance; int64_t nAll, capAll;          /* PH:684, insertion ordered */
     int* goodInstance; int64_t nGood, capGood;       /* PH:685 */
     orc_counters* ctr;
+    /* Optional footprints (orc_worker_process; not part of the reference): per pool entry ever created, the range of
+     * positions whose `used` bit the computation read as 0 — the instance's span plus every look-ahead window walked from its
+     * ends. Pool entries are re-created in the same order by the replay (BF:271-284), so the arrays survive path_clear. */
+    int fpOn; int64_t* fpLo; int64_t* fpHi; int64_t* fpChr; int64_t nFp, capFp;
+    int64_t* seenV; int64_t nSeenV, capSeenV;       /* with fpOn: every vertex that was ever part of the path (with repeats) */
 } Path;
+
+static void fp_touch(Path* p, int id, int64_t idx)
+{
+    if (!p->fpOn) return;
+    if (idx < p->fpLo[id]) p->fpLo[id] = idx;
+    if (idx > p->fpHi[id]) p->fpHi[id] = idx;
+}
 
 static FILE* g_trace = NULL;
 void orc_set_trace(const char* file)
@@ -509,7 +521,11 @@ void orc_set_trace(const char* file)
 }
 
 static int dk_is_set(const Path* p, int64_t v) { return p->distance[v + p->vertices] != INT_MAX; }     /* DK:17 */
-static void dk_set(Path* p, int64_t v, int d) { p->distance[v + p->vertices] = d; }                    /* DK:22 */
+static void dk_set(Path* p, int64_t v, int d)                                                          /* DK:22 */
+{
+    p->distance[v + p->vertices] = d;
+    if (p->fpOn) { GROW(p->seenV, p->nSeenV, p->capSeenV, int64_t); p->seenV[p->nSeenV++] = v; }
+}
 static int dk_get(const Path* p, int64_t v) { return p->distance[v + p->vertices]; }                   /* DK:27 */
 static void dk_unset(Path* p, int64_t v) { p->distance[v + p->vertices] = INT_MAX; }                   /* DK:32 */
 
@@ -531,7 +547,7 @@ static void path_free(Path* p)
 {
     for (int64_t c = 0; c < p->g->nChr; c++) free(p->set[c]);
     free(p->set); free(p->setN); free(p->setCap); free(p->distance); free(p->leftBody); free(p->rightBody);
-    free(p->pool); free(p->allInstance); free(p->goodInstance); free(p);
+    free(p->pool); free(p->allInstance); free(p->goodInstance); free(p->fpLo); free(p->fpHi); free(p->fpChr); free(p->seenV); free(p);
 }
 
 /* multiset::upper_bound(Instance(seqIt, 0)) under operator< on compareIdx_ (PH:177-180) */
@@ -556,6 +572,17 @@ static int set_insert(Path* p, SeqIt it, int64_t distance)                      
     int id = (int)p->nPool;
     p->pool[p->nPool++] = in;
     int64_t chr = it_chr(it);
+    if (p->fpOn) {
+        if (id >= p->nFp) {
+            if (id >= p->capFp) {
+                p->capFp = p->capFp ? p->capFp * 2 : 1024;
+                p->fpLo = (int64_t*)realloc(p->fpLo, (size_t)p->capFp * sizeof(int64_t));
+                p->fpHi = (int64_t*)realloc(p->fpHi, (size_t)p->capFp * sizeof(int64_t));
+                p->fpChr = (int64_t*)realloc(p->fpChr, (size_t)p->capFp * sizeof(int64_t));
+            }
+            p->fpLo[id] = p->fpHi[id] = it.idx; p->fpChr[id] = chr; p->nFp = id + 1;
+        } else fp_touch(p, id, it.idx);
+    }
     int64_t at = set_upper_bound(p, chr, it.idx);
     GROW(p->set[chr], p->setN[chr], p->setCap[chr], int);
     memmove(p->set[chr] + at + 1, p->set[chr] + at, (size_t)(p->setN[chr] - at) * sizeof(int));
@@ -682,6 +709,7 @@ static void point_push_front_worker(Path* p, int64_t vertex, int64_t distance, c
             if (!in->frontFinished) {
                 int prevGood = path_is_good(p, in);
                 inst_change_front(in, seqIt, distance);
+                fp_touch(p, p->set[chr][inst], seqIt.idx);
                 if (!prevGood && path_is_good(p, in)) push_good(p, p->set[chr][inst]);
                 if (it_used(g, seqIt)) in->frontFinished = 1;
             }
@@ -716,6 +744,7 @@ static void point_push_back_worker(Path* p, int64_t vertex, int64_t distance, co
             if (!in->backFinished) {
                 int prevGood = path_is_good(p, in);
                 inst_change_back(in, seqIt, distance);
+                fp_touch(p, p->set[chr][inst], seqIt.idx);
                 if (!prevGood && path_is_good(p, in)) push_good(p, p->set[chr][inst]);
                 if (it_used(g, seqIt)) in->backFinished = 1;
             }
@@ -822,6 +851,7 @@ static int64_t most_popular_vertex(Finder* f, int forward, int tryUsed, NextVert
             for (size_t d = 1; it_valid(g, it) && (d < (size_t)f->prm.looking_depth ||
                                abs32(it_position(g, it) - it_position(g, origin)) <= f->prm.max_branch); d++) {
                 if (f->ctr) f->ctr->n_walk++;
+                fp_touch(p, instList[i], it.idx);
                 int64_t vid = it_vid(g, it);
                 if (!dk_is_set(p, vid) && (!it_used(g, it) || tryUsed)) {
                     int64_t adjVid = vid + g->nVertex;
@@ -986,6 +1016,46 @@ int64_t orc_process_seed(orc_graph* g, const orc_params* p, int64_t vid, int32_t
     if (best_score) *best_score = bs;
     finder_free(f);
     return n;
+}
+
+/* A reusable finder (the per-seed scratch of 2V counters is allocated once) that can also report the footprints of a seed:
+ * model / test support for the round engine, which needs them to validate speculative results. */
+struct orc_worker { Finder* f; };
+orc_worker* orc_worker_new(orc_graph* g, const orc_params* p)
+{
+    orc_worker* w = (orc_worker*)calloc(1, sizeof(orc_worker));
+    w->f = finder_new(g, p, NULL);
+    w->f->path->fpOn = 1;
+    return w;
+}
+void orc_worker_free(orc_worker* w) { if (w) { finder_free(w->f); free(w); } }
+int64_t orc_worker_process(orc_worker* w, int64_t vid, int32_t ch, orc_inst* out, int64_t cap, int64_t* best_score, orc_counters* ctr,
+                           orc_fp* fp, int64_t fp_cap, int64_t* n_fp)
+{
+    Finder* f = w->f;
+    f->ctr = ctr; f->path->ctr = ctr;
+    f->path->nFp = 0; f->path->nSeenV = 0;
+    int64_t bs = 0;
+    process(f, vid, (char)ch, &bs);
+    int64_t n = f->nBest;
+    for (int64_t i = 0; i < n && i < cap; i++) {
+        out[i].positive = it_positive(f->best[i].front);
+        out[i].chr = (uint32_t)it_chr(f->best[i].front);
+        out[i].front_idx = (uint32_t)f->best[i].front.idx;
+        out[i].back_idx = (uint32_t)f->best[i].back.idx;
+    }
+    if (best_score) *best_score = bs;
+    if (n_fp) *n_fp = f->path->nFp;
+    for (int64_t i = 0; fp && i < f->path->nFp && i < fp_cap; i++) { fp[i].chr = f->path->fpChr[i]; fp[i].lo = f->path->fpLo[i]; fp[i].hi = f->path->fpHi[i]; }
+    return n;
+}
+
+/* the vertices of the last orc_worker_process call's path (every vertex that was pushed at any time, and the seed vertex): |id|, with repeats */
+int64_t orc_worker_path_vertices(const orc_worker* w, int64_t* out, int64_t cap)
+{
+    const Path* p = w->f->path;
+    for (int64_t i = 0; i < p->nSeenV && i < cap; i++) out[i] = p->seenV[i] < 0 ? -p->seenV[i] : p->seenV[i];
+    return p->nSeenV;
 }
 
 /* --- phase loop + ordered commit: BF:312-433 --- */

@@ -87,6 +87,16 @@ int64_t orc_process_seed(orc_graph* g, const orc_params* p, int64_t vid, int32_t
 /* Same as above but appends a line-per-event trace to a file (debug aid for kernel diffs). */
 void orc_set_trace(const char* file);
 
+/* Reusable per-thread finder that also reports a seed's footprints (per pool entry ever created: chromosome and the index
+ * range whose `used` bits were read as 0). Not part of the reference: support for tests / models of the round engine. */
+typedef struct { int64_t chr, lo, hi; } orc_fp;
+typedef struct orc_worker orc_worker;
+orc_worker* orc_worker_new(orc_graph* g, const orc_params* p);
+void orc_worker_free(orc_worker* w);
+int64_t orc_worker_process(orc_worker* w, int64_t vid, int32_t ch, orc_inst* out, int64_t cap, int64_t* best_score, orc_counters* ctr,
+                           orc_fp* fp, int64_t fp_cap, int64_t* n_fp);
+int64_t orc_worker_path_vertices(const orc_worker* w, int64_t* out, int64_t cap);   /* |id| of every vertex ever in the last call's path */
+
 /* FindBlocks phase loop + ordered commit (blocksfinder.h:334-433,453-530): fills *out with the
  * pre-trim blocksInstance_ in commit order (malloc'ed, caller frees with orc_free_blocks). */
 int64_t orc_find_blocks(orc_graph* g, const orc_params* p, orc_block** out, orc_stats* st, orc_counters* ctr);

@@ -87,6 +87,7 @@ struct Results {                       // per-seed results of one process() call
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
     std::vector<lcb_counters> ctr;     // countEvents only
+    std::vector<std::vector<int32_t>> pathV;   // relaxViews only
 };
 
 inline void addCounters(lcb_counters& a, const lcb_counters& b)
@@ -104,6 +105,7 @@ struct Cand {
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
     lcb_counters ctr{};
+    std::vector<int32_t> pathV;        // relaxViews: sorted |id| of the path's vertices
 };
 
 void pack(const Results& r, int64_t n, std::vector<unsigned char>& buf)
@@ -207,8 +209,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         if (world == 1 && !(cfg.exchangeAlways && cfg.allgather)) {
             const auto tp = std::chrono::steady_clock::now();
             proc.ctrSink = cfg.countEvents ? &out.ctr : nullptr;
+            proc.pathSink = cfg.relaxViews ? &out.pathV : nullptr;
             proc.process(sd, view, n, out.off, out.inst, out.fpOff, out.fp);
-            proc.ctrSink = nullptr;
+            proc.ctrSink = nullptr; proc.pathSink = nullptr;
+            if (cfg.relaxViews && (int64_t)out.pathV.size() != n) throw LcbError("relaxViews needs a processor that reports the path vertices");
             if (cfg.countEvents && (int64_t)out.ctr.size() != n) throw LcbError("the processor does not count events (stats mode off?)");
             st.processMs += msSince(tp);
             return;
@@ -306,10 +310,21 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         };
         // Conditions (1) and (2) of the header for a result computed at launch `epoch` against view `view`, judged against
         // the live state now. `checkedTo` caches the closed epochs already examined; `viewOk` caches (1), which is monotone.
-        auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf) -> bool {
+        // relaxViews: can a computation with footprint f and path vertices pv have read a bit of the predicted mark q?
+        auto relevant = [&](const std::pair<uint64_t, uint64_t>& q, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv) -> bool {
+            if (!cfg.relaxViews || !pv) return true;
+            const uint64_t M = (uint64_t)std::max(p->max_branch, p->looking_depth) + 2;    // gap walks of Compatible, look-ahead windows of the vote
+            for (size_t k = 0; k < nf; k++) if (q.first <= (uint64_t)f[k].hi + M && q.second + M > (uint64_t)f[k].lo) return true;
+            for (uint64_t x = q.first; x < q.second; x++) {
+                const int32_t id = g->posId[(size_t)x];
+                if (std::binary_search(pv->begin(), pv->end(), id < 0 ? -id : id)) return true;
+            }
+            return false;
+        };
+        auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv = nullptr) -> bool {
             const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
             if (P && !(viewOk && *viewOk)) {
-                for (auto& q : P->r) if (!com.allUsed(q.first, q.second)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
+                for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && relevant(q, f, nf, pv)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
                 if (viewOk) *viewOk = true;
             }
             const uint32_t last = (uint32_t)epochMarks.size() - 1;
@@ -321,7 +336,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             return true;
         };
         auto eValidNow = [&](int64_t i) -> bool {
-            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
+            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV); }
             return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
         };
 
@@ -368,9 +383,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 return false;
             };
             // would this result still be exact if the predicted marks came true? (conditions (1) and (2) against live + simP)
-            auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf) -> bool {
+            auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv = nullptr) -> bool {
                 const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
-                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second)) {
+                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second) && relevant(q, f, nf, pv)) {
                     // a predicted mark that is neither true yet nor predicted now (partly true + partly predicted is rare: treat as invalid)
                     return false;
                 }
@@ -394,7 +409,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     bool any = false;
                     for (int64_t j = ph; j < ph + n; j++) {
                         bool ok;
-                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
+                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size(), &c.pathV); }
                         else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
                         if (!ok) {
                             if (!any) { currentView(); any = true; }
@@ -413,7 +428,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     bool have = false;
                     if (fIdx[(size_t)j] >= 0) {
                         Cand& c = cands[(size_t)fIdx[(size_t)j]];
-                        have = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size());
+                        have = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size(), &c.pathV);
                         if (have && c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
                     }
                     if (!have) {
@@ -472,6 +487,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 c.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
                 c.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
                 if (cfg.countEvents) c.ctr = tmp.ctr[k];
+                if (cfg.relaxViews) c.pathV = tmp.pathV[(size_t)k];
             }
         };
 
@@ -498,7 +514,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 for (;;) {
                     if (fIdx[(size_t)i] >= 0) {
                         Cand& c = cands[(size_t)fIdx[(size_t)i]];
-                        if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size())) break;
+                        if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV)) break;
                     }
                     planAndLaunch(ph, i, true);
                 }

@@ -84,6 +84,9 @@ struct LcbProcessor {
     // when set, process() also stores the reference-semantics event counters of every seed here (a processor that can
     // count them: the device in stats mode; others leave it empty)
     std::vector<lcb_counters>* ctrSink = nullptr;
+    // when set, process() also stores the sorted |vertex id| list of every seed's path (every vertex that was part of the path at
+    // any time of the computation); only the oracle-backed model processor of tests/emu provides it today (relaxViews below)
+    std::vector<std::vector<int32_t>>* pathSink = nullptr;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
     // Optional: start process(seeds, view 0) now, against the state of this moment (marks applied later must not reach it),
     // and collect it with processEnd — the engine commits the previous round in between. false = not supported / not applicable.
@@ -116,6 +119,10 @@ struct LcbEngineConfig {
     bool overlap = false;     // begin the next round's launch while this round is committed (sparse stretches, one rank). Off by
                               // default: measured slower on configs 2 and 3 (the early results are computed against an older state, more of
                               // them are void, and a stop has to wait for the early launch): 437 k vs 457 k and 1.87 M vs 1.93 M seeds/s
+    bool relaxViews = false;  // EXPERIMENT (needs a processor with pathSink): a predicted mark of a job's view that did not come true voids
+                              // the job's result only if the job can have read it - it lies within max_branch + 2 positions of the result's
+                              // footprint or holds an occurrence of one of the path's vertices. Every `used` read of Process() is of one of
+                              // these kinds, so the rule is exact; today any such mark voids every later job of the launch.
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
 };
 

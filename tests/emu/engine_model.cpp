@@ -1,0 +1,231 @@
+// TEST-ONLY: the product's round engine (csrc/engine.cpp, unmodified) driven by the CPU oracle instead of the device, at sizes the
+// wavefront emulator cannot reach (hundreds of thousands of seeds). Every process() call of the engine is a "launch"; the
+// oracle's per-seed event counters (pushes) and pool sizes give a cost model of that launch, so that engine policies (job cap,
+// F prediction, round sizing) can be compared on realistic inputs in a container without a GPU. The blocks are checked against
+// the oracle's own FindBlocks: the engine with oracle footprints must reproduce them exactly.
+//
+//   engine_model <graph> <fasta> <k> <b> <m> <a> [seed limit]
+//   environment: MODEL_THREADS (default 8), MODEL_LOG=1 (one line per launch), LCB_MAX_JOBS, LCB_PREDICT_F, LCB_EAGER_PHASES,
+//                MODEL_ROUNDS (upper bound of phases per round, default 256), MODEL_CONCURRENCY (default 1280)
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <omp.h>
+#include "lcb.h"
+#include "lcb_host.h"
+extern "C" {
+#include "../../oracle/lcb_oracle.h"
+size_t orc_used_stride(void);
+}
+
+extern "C" const char* lcb_last_error(void) { return ""; }     // (capi.cpp is not linked)
+
+namespace {
+
+int envInt(const char* n, int d) { const char* e = getenv(n); return e && *e ? atoi(e) : d; }
+
+struct Launch { int64_t n = 0, live = 0, maxPush = 0, sumPush = 0, nBig = 0, maxPushBig = 0, nWideOvf = 0, maxPool = 0; bool jobs = false; };
+
+struct OracleProc : LcbProcessor {
+    const lcb_graph* g = nullptr;
+    orc_params op;
+    int threads = 8;
+    std::vector<orc_graph*> og;            // one copy of the oracle's state per thread (each job sees its own `used` view)
+    std::vector<orc_worker*> ow;
+    std::vector<LcbViewMark> vmarks;
+    int nViews = 0, views = 256, conc = 1280;
+    std::vector<Launch> launches;
+    int stride = 1;
+    // the last result of every (vertex, character): how many recomputations reproduce it, and how long they were
+    std::unordered_map<uint64_t, std::pair<std::vector<lcb_instance>, int64_t>> last;
+    int64_t recomputed = 0, identical = 0, identicalPushes = 0, recomputedPushes = 0, launchesLongestIdentical = 0;
+
+    void setRange(orc_graph* o, uint64_t lo, uint64_t hi, std::vector<uint8_t*>* undo)
+    {
+        // flat positions [lo, hi) -> (chromosome, index)
+        const std::vector<uint64_t>& cs = g->chrStart;
+        size_t c = (size_t)(std::upper_bound(cs.begin(), cs.end(), lo) - cs.begin()) - 1;
+        for (uint64_t q = lo; q < hi; q++) {
+            while (q >= cs[c + 1]) c++;
+            uint8_t* u = orc_chr_used(o, (int64_t)c) + (q - cs[c]) * (uint64_t)stride;
+            if (!*u) { *u = 1; if (undo) undo->push_back(u); }
+        }
+    }
+
+    void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
+                 std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        std::vector<std::vector<lcb_instance>> ri((size_t)n);
+        std::vector<std::vector<lcb_fp>> rf((size_t)n);
+        std::vector<int64_t> pushes((size_t)n, 0), pool((size_t)n, 0);
+        if (pathSink) pathSink->assign((size_t)n, std::vector<int32_t>());
+        const int64_t chunk = 16;
+        const int64_t nChunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int64_t cI = 0; cI < nChunks; cI++) {
+            const int t = omp_get_thread_num();
+            orc_graph* o = og[(size_t)t];
+            std::vector<uint8_t*> undo;
+            uint32_t applied = 0;           // marks with firstView <= applied are set
+            std::vector<orc_inst> buf(1 << 16);
+            std::vector<orc_fp> fbuf(1 << 16);
+            for (int64_t i = cI * chunk; i < std::min(n, (cI + 1) * chunk); i++) {
+                const uint32_t v = view ? view[i] : 0u;
+                if (v < applied) { for (uint8_t* u : undo) *u = 0; undo.clear(); applied = 0; }
+                if (v > applied) {
+                    for (auto& mk : vmarks) if (mk.firstView > applied && mk.firstView <= v) setRange(o, mk.lo, mk.hi, &undo);
+                    applied = v;
+                }
+                orc_counters c; memset(&c, 0, sizeof(c));
+                int64_t score = 0, nfp = 0;
+                const int64_t k = orc_worker_process(ow[(size_t)t], seeds[i].vid, seeds[i].ch, buf.data(), (int64_t)buf.size(), &score, &c, fbuf.data(), (int64_t)fbuf.size(), &nfp);
+                if (k > (int64_t)buf.size() || nfp > (int64_t)fbuf.size()) { fprintf(stderr, "model: result too large\n"); exit(2); }
+                ri[(size_t)i].resize((size_t)k);
+                for (int64_t e = 0; e < k; e++) ri[(size_t)i][(size_t)e] = lcb_instance{buf[e].chr, buf[e].front_idx, buf[e].back_idx, buf[e].positive ? 1u : 0u};
+                rf[(size_t)i].resize((size_t)nfp);
+                for (int64_t e = 0; e < nfp; e++) {
+                    const uint32_t base = (uint32_t)g->chrStart[(size_t)fbuf[e].chr];
+                    const uint32_t lo = base + (uint32_t)fbuf[e].lo, hi = base + (uint32_t)fbuf[e].hi;
+                    rf[(size_t)i][(size_t)e] = lcb_fp{lo ? lo - 1 : 0u, hi};      // the - strand reads bit g-1
+                }
+                pushes[(size_t)i] = (int64_t)c.n_push; pool[(size_t)i] = nfp;
+                if (pathSink) {
+                    std::vector<int64_t> pvb((size_t)orc_worker_path_vertices(ow[(size_t)t], nullptr, 0));
+                    orc_worker_path_vertices(ow[(size_t)t], pvb.data(), (int64_t)pvb.size());
+                    std::vector<int32_t>& pv = (*pathSink)[(size_t)i];
+                    pv.assign(pvb.begin(), pvb.end());
+                    std::sort(pv.begin(), pv.end());
+                    pv.erase(std::unique(pv.begin(), pv.end()), pv.end());
+                }
+            }
+            for (uint8_t* u : undo) *u = 0;
+        }
+        off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0);
+        inst.clear(); fp.clear();
+        Launch L; L.n = n; L.jobs = view != nullptr;
+        for (int64_t i = 0; i < n; i++) {
+            off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
+            inst.insert(inst.end(), ri[(size_t)i].begin(), ri[(size_t)i].end());
+            fp.insert(fp.end(), rf[(size_t)i].begin(), rf[(size_t)i].end());
+            const int64_t pu = pushes[(size_t)i], pl = pool[(size_t)i];
+            if (pl) L.live++;
+            L.sumPush += pu; L.maxPush = std::max(L.maxPush, pu); L.maxPool = std::max(L.maxPool, pl);
+            if (pl > 1024) { L.nBig++; L.maxPushBig = std::max(L.maxPushBig, pu); }
+            else if (pl > 256) L.nWideOvf++;
+        }
+        off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
+        {
+            int64_t longest = -1; bool longestIdentical = false;
+            for (int64_t i = 0; i < n; i++) {
+                const uint64_t key = ((uint64_t)(uint32_t)seeds[i].vid << 8) | (uint8_t)seeds[i].ch;
+                auto it = last.find(key);
+                bool same = false;
+                if (it != last.end()) {
+                    recomputed++; recomputedPushes += pushes[(size_t)i];
+                    same = it->second.first.size() == ri[(size_t)i].size() && (ri[(size_t)i].empty() || !memcmp(it->second.first.data(), ri[(size_t)i].data(), ri[(size_t)i].size() * sizeof(lcb_instance)));
+                    if (same) { identical++; identicalPushes += pushes[(size_t)i]; }
+                }
+                if (pushes[(size_t)i] > longest) { longest = pushes[(size_t)i]; longestIdentical = same; }
+                last[key] = std::make_pair(ri[(size_t)i], pushes[(size_t)i]);
+            }
+            if (longestIdentical) launchesLongestIdentical++;
+        }
+        launches.push_back(L);
+        if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (int64_t i = 0; i < n; i++) fprintf(stderr, "   done %lld pushes %lld inst %zu pool %lld\n", (long long)i, (long long)pushes[(size_t)i], ri[(size_t)i].size(), (long long)pool[(size_t)i]);
+        if (getenv("MODEL_LOG"))
+            fprintf(stderr, "launch %zu %s n=%lld live=%lld maxPush=%lld sumPush=%lld pool>1024: %lld (maxPush %lld) pool>256: %lld maxPool=%lld\n", launches.size(), L.jobs ? "jobs " : "round",
+                    (long long)L.n, (long long)L.live, (long long)L.maxPush, (long long)L.sumPush, (long long)L.nBig, (long long)L.maxPushBig, (long long)L.nWideOvf, (long long)L.maxPool);
+    }
+    void mark(const uint64_t* r, int64_t n) override
+    {
+        for (orc_graph* o : og) for (int64_t i = 0; i < n; i++) setRange(o, r[2 * i], r[2 * i + 1], nullptr);
+    }
+    void reset() override { for (orc_graph* o : og) orc_reset_used(o); }
+    int maxViews() const override { return views; }
+    int concurrency() const override { return conc; }
+    void buildViews(int nv, const LcbViewMark* marks, int64_t nMarks) override { nViews = nv; vmarks.assign(marks, marks + nMarks); }
+};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: engine_model <graph> <fasta> <k> <b> <m> <a> [seed limit]\n"); return 2; }
+    const std::string graph = argv[1], fasta = argv[2];
+    const int k = atoi(argv[3]), b = atoi(argv[4]), m = atoi(argv[5]), a = atoi(argv[6]);
+    const int64_t limit = argc > 7 ? atoll(argv[7]) : 0;
+    try {
+        const int threads = envInt("MODEL_THREADS", 8);
+        lcb_graph* g = lcb_graph_load_impl(graph.c_str(), {fasta}, k, a, threads);
+        lcb_params p; memset(&p, 0, sizeof(p));
+        p.k = k; p.min_block = m; p.max_branch = b; p.max_flank = b; p.looking_depth = 8; p.phase_size = 256;
+        std::vector<lcb_seed> seeds;
+        lcb_enumerate_seeds_impl(*g, threads, seeds);
+        if (limit && (int64_t)seeds.size() > limit) seeds.resize((size_t)limit);
+        OracleProc proc; proc.g = g; proc.threads = threads;
+        proc.op.k = k; proc.op.min_block = m; proc.op.max_branch = b; proc.op.max_flank = b; proc.op.looking_depth = 8;
+        proc.stride = (int)orc_used_stride();
+        proc.conc = envInt("MODEL_CONCURRENCY", 1280);
+        char err[512];
+        const char* fa[1] = {fasta.c_str()};
+        for (int t = 0; t < threads; t++) {
+            orc_graph* o = orc_load(graph.c_str(), fa, 1, k, a, err, sizeof(err));
+            if (!o) { fprintf(stderr, "model: %s\n", err); return 1; }
+            proc.og.push_back(o); proc.ow.push_back(orc_worker_new(o, &proc.op));
+        }
+        LcbEngineConfig cfg;
+        cfg.roundPhases = envInt("MODEL_ROUNDS", 0);
+        cfg.maxJobs = envInt("LCB_MAX_JOBS", 0);
+        if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F", 0));
+        if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
+        cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
+        cfg.relaxViews = envInt("MODEL_RELAX", 0) != 0;
+        std::vector<lcb_block> blocks;
+        LcbEngineStats es;
+        const auto t0 = std::chrono::steady_clock::now();
+        lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // cost model: variants run one after the other; a launch is as long as its longest seed or its total work over the slots.
+        // us per push(+vote): compact 10, wide 8, big 20 (launch trace of config 3, profiles/r02); slots 1280 / 256 / 256
+        double tRound = 0, tJobs = 0, tBig = 0;
+        int64_t nRound = 0, nJobs = 0, jobSeeds = 0, critical = 0, total = 0, bigLaunches = 0;
+        for (const Launch& L : proc.launches) {
+            const bool wide = L.n <= 512;
+            const double c = wide ? 8.0 : 10.0;
+            const double slots = wide ? 256.0 : 1280.0;
+            double t = std::max((double)L.maxPush * c, (double)L.sumPush * c / slots) + 50.0;
+            double tb = 0;
+            if (L.nBig) { tb = (double)L.maxPushBig * 20.0 + 50.0; bigLaunches++; }
+            (L.jobs ? tJobs : tRound) += t; tBig += tb;
+            if (L.jobs) { nJobs++; jobSeeds += L.n; } else nRound++;
+            critical += L.maxPush; total += L.sumPush;
+        }
+        fprintf(stderr, "model: %zu seeds, %zu blocks, failures %lld, rounds %lld, job launches %lld (%lld jobs, %lld used), conflict launches %lld, over-predicted %lld, %.1f s\n",
+                seeds.size(), blocks.size(), (long long)es.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds, (long long)es.jobsUsed,
+                (long long)es.conflictLaunches, (long long)es.overPredicted, sec);
+        fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
+                proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
+                (tRound + tJobs + tBig) / 1000);
+        fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld\n",
+                (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical);
+        // parity of the model itself: the oracle's own FindBlocks on a fresh state
+        if (!limit && !getenv("MODEL_NOCHECK")) {
+            orc_graph* o = proc.og[0];
+            orc_reset_used(o);
+            orc_block* ob = nullptr; orc_stats st; orc_counters fc; memset(&fc, 0, sizeof(fc));
+            const int64_t nb = orc_find_blocks(o, &proc.op, &ob, &st, &fc);
+            int diffs = nb != (int64_t)blocks.size();
+            for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
+                if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
+            fprintf(stderr, "model: blocks vs the oracle's FindBlocks: %s (%lld vs %zu)\n", diffs ? "DIFFERENT" : "equal", (long long)nb, blocks.size());
+            return diffs ? 1 : 0;
+        }
+    } catch (std::exception& e) { fprintf(stderr, "model: error: %s\n", e.what()); return 1; }
+    return 0;
+}

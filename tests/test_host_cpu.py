@@ -173,3 +173,18 @@ def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode
     assert r.returncode == 0, r.stderr[-2000:]
     if mode == "find":
         assert open(str(tmp_path / "emu" / "blocks_coords.gff")).read() == c.golden("ref.gff")
+
+
+@pytest.mark.parametrize("name", ["nruns_abund", "inv_k25", "collinear6"])
+@pytest.mark.parametrize("relax", ["0", "1"])
+def test_engine_model_reproduces_the_oracle(built, case_dir, name, relax):
+    """tests/emu/engine_model: the product's round engine driven by the CPU oracle (with the oracle's own footprints) instead of
+    the device - the tool that prices engine policies at sizes the emulator cannot reach. It must reproduce the oracle's
+    FindBlocks exactly, also with the experimental relaxed view rule (LcbEngineConfig::relaxViews: a predicted mark that did not
+    come true voids a job's result only if the job can have read it)."""
+    from tests.conftest import Case
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/engine_model"])
+    c = Case(name, case_dir)
+    r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "engine_model"), c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a)],
+                       capture_output=True, text=True, env=dict(os.environ, MODEL_RELAX=relax, MODEL_THREADS="2"))
+    assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
