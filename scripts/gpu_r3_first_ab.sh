@@ -4,6 +4,7 @@
 #   bighot   -DLCB_BIG_HOT=256u : fields of the first 256 pool entries of the big variant in LDS (build: python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u)
 #   jobs64 / jobs256 / jobs512   lcb_hooks.max_jobs (job launches in the wide variant; 0.8 % of the 1 280 jobs per stop are used)
 #   nwbig16  -DLCB_NW_BIG=16 : 16 wavefronts in the big variant
+#   (next, needs the device plumbing of the signature arena: -DLCB_PATH_SIG=1 + lcb_hooks relaxViews; kernel, emulator and engine are done)
 # and a per-seed section trace (LCB_TRACE_SEEDS=1: vote / push / score split of the slowest seeds) of the shipped build
 mkdir -p gpurun_out
 export LCB_WATCHDOG_S=300

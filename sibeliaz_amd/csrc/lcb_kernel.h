@@ -104,6 +104,12 @@ struct LcbUsed { const uint32_t* live; const uint32_t* tab; };
 struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
 struct LcbKSeed { int32_t vid; int32_t ch; uint32_t view; uint32_t pad; };   // view: which `used` view this seed reads
 
+// Round-3 candidate, NOT in the shipped build (-DLCB_PATH_SIG=1): a seed that runs against a predicted view (a job) also reports
+// every vertex that was part of its path at any time - what LcbEngineConfig::relaxViews needs to tell which predicted marks the
+// computation can have read (profiles/r02/engine_model_findings.md).
+#ifndef LCB_PATH_SIG
+#define LCB_PATH_SIG 0
+#endif
 struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint32_t nInst;
     uint32_t status;
@@ -112,6 +118,11 @@ struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint64_t fpOff;            // first footprint interval of this seed in the footprint arena
     uint32_t nFp;              // number of footprint intervals (= instances ever created)
     uint32_t poolInst;         // instances in the pool when the seed ended (on an overflow: what the next variant has to hold at least)
+#if LCB_PATH_SIG
+    uint64_t sigOff;           // first path vertex of this seed in the signature arena
+    uint32_t nSig;             // number of them (with repeats); UINT32_MAX: the list did not fit - every mark counts as read
+    uint32_t pad2;
+#endif
 };
 struct LcbSeedCtr { uint64_t c[8]; };   // lcb_counters order in stats mode, a cheap profile in the instrumented variant
 
@@ -133,11 +144,17 @@ struct LcbWork {               // per-workgroup global-memory workspace slots + 
     unsigned long long fpBase;
     LcbSeedCtr* ctr;           // per-seed counters (stats / instrumented variants), or null
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
+#if LCB_PATH_SIG
+    int32_t* sigArena;         // path vertices of the seeds with a view (null: not wanted)
+    unsigned long long* sigCursor;
+    unsigned long long sigBase, sigCap;
+#endif
 };
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
     uint64_t pKeys, pSlots, body, best, ck;                   // always (ck: forward-extension checkpoint, 6 words per instance)
+    uint64_t sig;                                              // LCB_PATH_SIG: every vertex ever inserted into the path set
     uint64_t inst, fp;                                          // big and huge modes
     uint64_t ordKey, ordIdx, good, goodPos, touch, vKey, vCount, vLast, vTouched;   // huge mode
     uint64_t total;
@@ -153,6 +170,7 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.body = o; o = lcb_align16(o + 8ull * bodyCap);
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
     L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
+    L.sig = o; o = lcb_align16(o + (LCB_PATH_SIG ? 4ull * (2ull * pathCap + 8) : 0ull));
     L.inst = o; o = lcb_align16(o + 9ull * 4 * instCap);
     L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
     const uint32_t idxCap = voteCap ? instCap : 0;             // the index / list / vote arrays only exist in huge mode
@@ -287,6 +305,9 @@ struct LcbStateT {
     int32_t* pKeys;
     uint32_t* pSlots;
     uint32_t pathCap, pathShift;
+#if LCB_PATH_SIG
+    int32_t* sig; uint32_t nSig, sigCap;      // every vertex ever inserted (null: not recorded for this seed)
+#endif
     unsigned long long* body;  // right body: (strand << 32) | g of the iterator whose outgoing edge was pushed
     uint32_t bodyCap;
     uint4* best;
@@ -433,6 +454,9 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
     if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
     constexpr bool PL = LcbCfg<ST::MODE>::PC != 0;
     LCB_SYNC_IF(PL);               // every lane has finished probing before lane 0 publishes the key
+#if LCB_PATH_SIG
+    if (S.sig) { if (S.nSig < S.sigCap && S.lane == 0) S.sig[S.nSig] = vid; S.nSig++; }
+#endif
     if (S.lane == 0) {
         S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
         if (LcbCfg<ST::MODE>::BW) {
@@ -1352,6 +1376,9 @@ struct LcbLaunchArgs {
     const uint32_t* live;
     uint32_t cursorBase, nSeeds;
     const uint32_t* usedTab;       // page table of the `used` view of the seed wave 0 is working on (read by the helpers at each vote)
+#if LCB_PATH_SIG
+    int32_t* sigArena; unsigned long long* sigCursor; unsigned long long sigBase, sigCap;
+#endif
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
@@ -1386,6 +1413,9 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         sArgs.seeds = seeds; sArgs.out = out; sArgs.ctr = W.ctr; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
         sArgs.arenaBase = W.arenaBase; sArgs.fpBase = W.fpBase; sArgs.arenaCursor = W.arenaCursor; sArgs.fpCursor = W.fpCursor;
         sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.live = W.live; sArgs.nSeeds = W.live ? *W.nLive : nSeeds;
+#if LCB_PATH_SIG
+        sArgs.sigArena = W.sigArena; sArgs.sigCursor = W.sigCursor; sArgs.sigBase = W.sigBase; sArgs.sigCap = W.sigCap;
+#endif
     }
 
     LcbStateT<MODE> S;
@@ -1491,6 +1521,10 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         const int32_t vid = lcb_rfl(sd.vid), ch = lcb_rfl(sd.ch);
         S.U = lcb_used_of(T, lcb_rfl(sd.view));
         if (NW > 1 && S.lane == 0) sArgs.usedTab = S.U.tab;      // published to the helpers by the vote's first barrier
+#if LCB_PATH_SIG
+        S.sig = sArgs.sigArena ? (int32_t*)(slot + L.sig) : nullptr;      // (the host asks for it in job launches only)
+        S.nSig = 0; S.sigCap = 2u * W.pathCap + 8u;
+#endif
         lcb_process_seed<MODE, STATS, PROF, NW>(S, vid, ch, bestScore);
         if (S.status == LCB_ST_VOTE_OVF) {
             // the vote table may hold stale keys after an overflow (the helpers have cleared their slices; wave 0 wipes all)
@@ -1523,6 +1557,22 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
             else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
         }
+#if LCB_PATH_SIG
+        unsigned long long sgo = 0;
+        uint32_t nsg = 0;
+        if (S.sig && S.status == LCB_ST_OK) {
+            LCB_WAVE_SYNC();
+            nsg = S.nSig > S.sigCap ? 0xFFFFFFFFu : S.nSig;
+            if (nsg != 0xFFFFFFFFu && nsg) {
+                uint32_t olo = 0, ohi = 0;
+                if (S.lane == 0) { sgo = atomicAdd(sArgs.sigCursor, (unsigned long long)nsg) - sArgs.sigBase; olo = (uint32_t)sgo; ohi = (uint32_t)(sgo >> 32); }
+                olo = lcb_rfl(olo); ohi = lcb_rfl(ohi);
+                sgo = ((unsigned long long)ohi << 32) | olo;
+                if (sgo + nsg > sArgs.sigCap) nsg = 0xFFFFFFFFu;
+                else for (uint32_t e = S.lane; e < nsg; e += 64) sArgs.sigArena[sgo + e] = S.sig[e];
+            }
+        }
+#endif
         // (no local arrays here: the compiler would move them to LDS, 48 B x every lane of the workgroup)
         uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
         if (STATS) {
@@ -1535,6 +1585,9 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             o->nInst = n;   // kept on ARENA_OVF so the host can track the allocator
             o->status = S.status; o->bestScore = bestScore; o->arenaOff = off;
             o->fpOff = fpo; o->nFp = nfp; o->poolInst = S.endInst;
+#if LCB_PATH_SIG
+            o->sigOff = sgo; o->nSig = nsg; o->pad2 = 0;
+#endif
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }

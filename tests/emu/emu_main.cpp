@@ -44,6 +44,8 @@ struct EmuCtx {
     std::vector<uint4> arena;
     std::vector<LcbKSeed> ks;
     std::vector<size_t> which;
+    std::vector<int32_t> sigArena;        // LCB_PATH_SIG builds: path vertices of the seeds of the last run
+    unsigned long long sigCursor = 0;
 };
 
 struct Emu {
@@ -63,6 +65,7 @@ struct Emu {
     std::vector<LcbSeedOut> out;
     std::vector<LcbSeedCtr> octr;                // per-seed counters of the last run()
     std::vector<uint4> arena;
+    std::vector<std::vector<int32_t>> osig;      // LCB_PATH_SIG builds: per seed of the last run(), sorted |id| of its path vertices
     lcb_counters ctr{};
     uint64_t launches = 0, criticalPushes = 0, totalPushes = 0, firstPushes = 0;   // sum over launches of the largest per-seed push count
 
@@ -141,6 +144,11 @@ struct Emu {
         W.cursorBase = c.cursor[0];
         W.arenaBase = *W.arenaCursor;
         W.fpBase = *W.fpCursor;
+#if LCB_PATH_SIG
+        if (c.sigArena.empty()) c.sigArena.resize(1 << 20);
+        c.sigCursor = 0;
+        W.sigArena = c.sigArena.data(); W.sigCursor = &c.sigCursor; W.sigBase = 0; W.sigCap = c.sigArena.size();
+#endif
         const LcbKSeed* sp = c.ks.data();
         const uint32_t n = (uint32_t)c.ks.size();
         if (!n) return;
@@ -189,6 +197,7 @@ struct Emu {
         }
         out.assign(seeds.size(), LcbSeedOut{});
         octr.assign(seeds.size(), LcbSeedCtr{});
+        osig.assign(seeds.size(), std::vector<int32_t>());
         arena.clear(); fpArena.clear();
         uint64_t maxPush = 0;
         for (auto& c : ctx)
@@ -199,6 +208,13 @@ struct Emu {
                     arena.insert(arena.end(), c.arena.begin() + o.arenaOff, c.arena.begin() + o.arenaOff + o.nInst);
                     fpArena.insert(fpArena.end(), c.fpArena.begin() + o.fpOff, c.fpArena.begin() + o.fpOff + o.nFp);
                     o.arenaOff = ao; o.fpOff = fo;
+#if LCB_PATH_SIG
+                    if (o.nSig == 0xFFFFFFFFu) { fprintf(stderr, "emu: path signature did not fit\n"); exit(2); }
+                    std::vector<int32_t>& sg = osig[c.which[j]];
+                    for (uint32_t e = 0; e < o.nSig; e++) { const int32_t v = c.sigArena[o.sigOff + e]; sg.push_back(v < 0 ? -v : v); }
+                    std::sort(sg.begin(), sg.end());
+                    sg.erase(std::unique(sg.begin(), sg.end()), sg.end());
+#endif
                 }
                 out[c.which[j]] = o;
                 if (o.status != 0) continue;     // an overflowed attempt is re-run in a larger mode (runRetry) and counted there
@@ -243,6 +259,7 @@ struct Emu {
             }
             out[again[k]] = o;
             octr[again[k]] = next->octr[k];
+            osig[again[k]] = next->osig[k];
         }
         ctr.n_walk += next->ctr.n_walk; ctr.n_occ += next->ctr.n_occ; ctr.n_compat_call += next->ctr.n_compat_call; ctr.n_compat_step += next->ctr.n_compat_step;
         ctr.n_inst_out += next->ctr.n_inst_out; ctr.n_vote += next->ctr.n_vote; ctr.n_push += next->ctr.n_push; ctr.n_process += next->ctr.n_process;
@@ -272,6 +289,10 @@ struct EmuProcessor : LcbProcessor {
             for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
+        if (pathSink) {      // LCB_PATH_SIG builds: the path vertices the kernel reported (engine's relaxViews)
+            if (!LCB_PATH_SIG) throw LcbError("this emulator build has no path signatures (-DLCB_PATH_SIG=1)");
+            pathSink->assign(emu->osig.begin(), emu->osig.begin() + n);
+        }
         if (ctrSink) {       // stats-mode kernels: the per-seed event counters (engine's countEvents)
             ctrSink->assign((size_t)n, lcb_counters{});
             for (int64_t i = 0; i < n && !getenv("EMU_NOSTATS"); i++) {
@@ -417,6 +438,18 @@ int main(int argc, char** argv)
                 int64_t score = 0;
                 const int64_t n = orc_process_seed(og, &op, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &score, &octr);
                 bad += compareSeed((int64_t)i, seeds[i], emu.out[i], emu.arena.data(), ref.data(), n, score);
+#if LCB_PATH_SIG
+                {   // the kernel's path signature against the oracle's list of every vertex that was ever part of the path
+                    static orc_worker* wk = orc_worker_new(og, &op);
+                    int64_t sc2 = 0, nfp2 = 0;
+                    orc_worker_process(wk, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &sc2, nullptr, nullptr, 0, &nfp2);
+                    std::vector<int64_t> pv((size_t)orc_worker_path_vertices(wk, nullptr, 0));
+                    orc_worker_path_vertices(wk, pv.data(), (int64_t)pv.size());
+                    std::vector<int32_t> want(pv.begin(), pv.end());
+                    std::sort(want.begin(), want.end()); want.erase(std::unique(want.begin(), want.end()), want.end());
+                    if (want != emu.osig[i]) { fprintf(stderr, "FAIL: seed %zu: path signature of %zu vertices, the oracle's path had %zu\n", i, emu.osig[i].size(), want.size()); bad++; }
+                }
+#endif
                 {
                     static orc_counters prev; static int shown = 0;
                     const uint64_t dc = octr.n_compat_call - prev.n_compat_call, ds = octr.n_compat_step - prev.n_compat_step;
@@ -459,6 +492,7 @@ int main(int argc, char** argv)
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
                 cfg.overlap = !getenv("EMU_NO_OVERLAP");    // the early launch of the next round (off by default in the product) is exercised here
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls
+                cfg.relaxViews = getenv("EMU_RELAX") != nullptr;   // needs the -DLCB_PATH_SIG=1 build
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;

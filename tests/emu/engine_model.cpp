@@ -45,6 +45,7 @@ struct OracleProc : LcbProcessor {
     // the last result of every (vertex, character): how many recomputations reproduce it, and how long they were
     std::unordered_map<uint64_t, std::pair<std::vector<lcb_instance>, int64_t>> last;
     int64_t recomputed = 0, identical = 0, identicalPushes = 0, recomputedPushes = 0, launchesLongestIdentical = 0;
+    int64_t criticalNew = 0;       // critical path if no launch had to wait for a seed that merely reproduces its previous result
 
     void setRange(orc_graph* o, uint64_t lo, uint64_t hi, std::vector<uint8_t*>* undo)
     {
@@ -121,7 +122,7 @@ struct OracleProc : LcbProcessor {
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
         {
-            int64_t longest = -1; bool longestIdentical = false;
+            int64_t longest = -1, longestNew = 0; bool longestIdentical = false;
             for (int64_t i = 0; i < n; i++) {
                 const uint64_t key = ((uint64_t)(uint32_t)seeds[i].vid << 8) | (uint8_t)seeds[i].ch;
                 auto it = last.find(key);
@@ -132,9 +133,11 @@ struct OracleProc : LcbProcessor {
                     if (same) { identical++; identicalPushes += pushes[(size_t)i]; }
                 }
                 if (pushes[(size_t)i] > longest) { longest = pushes[(size_t)i]; longestIdentical = same; }
+                if (!same && pushes[(size_t)i] > longestNew) longestNew = pushes[(size_t)i];
                 last[key] = std::make_pair(ri[(size_t)i], pushes[(size_t)i]);
             }
             if (longestIdentical) launchesLongestIdentical++;
+            criticalNew += longestNew;
         }
         launches.push_back(L);
         if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (int64_t i = 0; i < n; i++) fprintf(stderr, "   done %lld pushes %lld inst %zu pool %lld\n", (long long)i, (long long)pushes[(size_t)i], ri[(size_t)i].size(), (long long)pool[(size_t)i]);
@@ -212,8 +215,8 @@ int main(int argc, char** argv)
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
                 (tRound + tJobs + tBig) / 1000);
-        fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld\n",
-                (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical);
+        fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld; critical path without the reproductions: %lld pushes\n",
+                (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical, (long long)proc.criticalNew);
         // parity of the model itself: the oracle's own FindBlocks on a fresh state
         if (!limit && !getenv("MODEL_NOCHECK")) {
             orc_graph* o = proc.og[0];
