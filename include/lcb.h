@@ -218,6 +218,8 @@ typedef struct {
     int32_t count_events;       /* 1: fill lcb_stats.events (the device must be in stats mode; one rank) */
     int32_t overlap;            /* 1: run the next round's speculative launch while this round is being committed (measured slower
                                    on configs 2 and 3, so off by default) */
+    int32_t relax_views;        /* 1 (experimental, needs a library built with -DLCB_PATH_SIG=1; an error otherwise): a predicted mark
+                                   that did not come true voids a job's result only if the job can have read it */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

@@ -4,15 +4,18 @@
 #   bighot   -DLCB_BIG_HOT=256u : fields of the first 256 pool entries of the big variant in LDS (build: python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u)
 #   jobs64 / jobs256 / jobs512   lcb_hooks.max_jobs (job launches in the wide variant; 0.8 % of the 1 280 jobs per stop are used)
 #   nwbig16  -DLCB_NW_BIG=16 : 16 wavefronts in the big variant
-#   (next, needs the device plumbing of the signature arena: -DLCB_PATH_SIG=1 + lcb_hooks relaxViews; kernel, emulator and engine are done)
+#   pathsig  -DLCB_PATH_SIG=1 + lcb_hooks.relax_views = 1 : the kernels report the path's vertices, a predicted mark that did not come
+#            true voids a job's result only if the job can have read it (model: jobs -30 %, critical path -11 %)
 # and a per-seed section trace (LCB_TRACE_SEEDS=1: vote / push / score split of the slowest seeds) of the shipped build
 mkdir -p gpurun_out
 export LCB_WATCHDOG_S=300
 python sibeliaz_amd/build.py variant bighot -DLCB_BIG_HOT=256u
 python sibeliaz_amd/build.py variant nwbig16 -DLCB_NW_BIG=16
-for v in base bighot nwbig16 jobs64 jobs256 jobs512; do
+python sibeliaz_amd/build.py variant pathsig -DLCB_PATH_SIG=1
+for v in base bighot nwbig16 pathsig jobs64 jobs256 jobs512; do
   LIB=""; EXTRA=""
-  if [ $v = bighot ] || [ $v = nwbig16 ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  if [ $v = bighot ] || [ $v = nwbig16 ] || [ $v = pathsig ]; then LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_$v.so; fi
+  if [ $v = pathsig ]; then EXTRA="--engine-opt relax_views=1"; fi
   if [ $v = jobs64 ]; then EXTRA="--engine-opt max_jobs=64"; fi
   if [ $v = jobs256 ]; then EXTRA="--engine-opt max_jobs=256"; fi
   if [ $v = jobs512 ]; then EXTRA="--engine-opt max_jobs=512"; fi

@@ -51,10 +51,10 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("overlap", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("overlap", C.c_int32), ("relax_views", C.c_int32)]
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "overlap")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "overlap", "relax_views")
 
 
 class DeviceOpts(C.Structure):

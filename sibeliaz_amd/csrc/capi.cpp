@@ -27,7 +27,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0;
     }
     return cfg;
 }
@@ -206,7 +206,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);

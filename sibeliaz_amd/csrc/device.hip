@@ -178,6 +178,11 @@ struct lcb_device_impl {
     LcbKSeed* hSeeds = nullptr;
     LcbSeedOut* hOut = nullptr;
     LcbSeedCtr* hCtr = nullptr;                  // stats / instrumented variants only
+#if LCB_PATH_SIG
+    int32_t* hSig = nullptr;                     // path vertices of the seeds of a launch (pinned, device-mapped)
+    unsigned long long sigCap = 0;
+    bool wantSig = false;
+#endif
     uint4* hArena = nullptr;
     uint2* hFp = nullptr;                        // footprint arena (pinned)
     unsigned long long fpCap = 0;
@@ -262,6 +267,9 @@ struct lcb_device_impl {
         W.live = screen ? dLive : nullptr; W.nLive = screen ? dCursor + 1 : nullptr;
         W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = 0;
         W.fpCursor = (unsigned long long*)(dCursor + 4); W.fpBase = 0;
+#if LCB_PATH_SIG
+        W.sigArena = wantSig ? hSig : nullptr; W.sigCursor = (unsigned long long*)(dCursor + 6); W.sigBase = 0; W.sigCap = sigCap;
+#endif
         const bool prof = (hDbg != nullptr) || seedTrace || forceProf;
         W.ctr = (stats || prof) ? hCtr : nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
@@ -447,6 +455,10 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
         d->allocArena(o.arena);
+#if LCB_PATH_SIG
+        d->sigCap = 1ull << 22;
+        HIP_CHECK(hipHostMalloc((void**)&d->hSig, (size_t)d->sigCap * sizeof(int32_t), hipHostMallocDefault));
+#endif
         d->swapBufs();
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
@@ -508,6 +520,9 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
         if (d->hCtr) (void)hipHostFree(d->hCtr);
+#if LCB_PATH_SIG
+        if (d->hSig) (void)hipHostFree(d->hSig);
+#endif
         if (d->hArena) (void)hipHostFree(d->hArena);
         if (d->hFp) (void)hipHostFree(d->hFp);
         if (d->hRanges) (void)hipHostFree(d->hRanges);
@@ -678,6 +693,7 @@ struct ProcAcc {
     int64_t arenaOvf = 0;                               // seeds of the current variant's launches that found the result arena full
     std::vector<uint8_t> start;                         // first variant of every seed of the call
     bool allBig = false;                                // every seed of the call starts in the big variant (accInit)
+    std::vector<std::vector<int32_t>>* sig = nullptr;   // LCB_PATH_SIG: where the path vertices of every seed go
     int64_t neededBig = 0;                              // seeds that finished in the big / huge variant and could not have run in a smaller one
 };
 
@@ -756,6 +772,18 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
                 for (uint32_t e = 0; e < o.nInst; e++) A.flat[f0 + e] = lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w};
             }
             if (A.bestScore) A.bestScore[s] = o.bestScore;
+#if LCB_PATH_SIG
+            if (A.sig) {
+                std::vector<int32_t>& sg = (*A.sig)[(size_t)s];
+                sg.clear();
+                if (o.nSig == 0xFFFFFFFFu) sg.push_back(INT32_MIN);          // the list did not fit: every predicted mark counts as read
+                else {
+                    for (uint32_t e = 0; e < o.nSig; e++) { const int32_t v = d->hSig[o.sigOff + e]; sg.push_back(v < 0 ? -v : v); }
+                    std::sort(sg.begin(), sg.end());
+                    sg.erase(std::unique(sg.begin(), sg.end()), sg.end());
+                }
+            }
+#endif
             if (A.wantFp) {
                 A.fpAt[(size_t)s] = A.fpFlat.size(); A.fpCnt[(size_t)s] = o.nFp;
                 const uint2* src = d->hFp + o.fpOff;
@@ -881,7 +909,8 @@ void accLayout(ProcAcc& A, std::vector<uint64_t>& offsets, std::vector<lcb_insta
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr)
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr,
+                             std::vector<std::vector<int32_t>>* pathSink)
 {
     lcb_device_impl* d = h->impl;
     d->use();
@@ -889,7 +918,19 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
     ProcAcc A;
     accInit(d, A, seeds, n, view, bestScore, ctr, perSeedCtr, d->wantFp);
-    runToCompletion(d, A);
+#if LCB_PATH_SIG
+    if (pathSink) { pathSink->assign((size_t)n, std::vector<int32_t>()); A.sig = pathSink; d->wantSig = true; }
+#else
+    if (pathSink) throw LcbError("this build does not report path vertices (-DLCB_PATH_SIG=1)");
+#endif
+    try { runToCompletion(d, A); } catch (...) {
+#if LCB_PATH_SIG
+        d->wantSig = false;
+#endif
+        d->wantFp = false; throw; }
+#if LCB_PATH_SIG
+    d->wantSig = false;
+#endif
     accLayout(A, offsets, inst, fpOffsets, fpOut);
     d->wantFp = false;
 }
@@ -965,7 +1006,8 @@ struct DeviceProcessor : LcbProcessor {
     void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
                  std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
-        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view, ctrSink);
+        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view, ctrSink, view ? pathSink : nullptr);
+        if (pathSink && !view) pathSink->assign((size_t)n, std::vector<int32_t>());      // a launch against the live state has no predicted marks
     }
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
     int concurrency() const override { return lcb_device_concurrency_impl(dev); }

@@ -313,6 +313,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // relaxViews: can a computation with footprint f and path vertices pv have read a bit of the predicted mark q?
         auto relevant = [&](const std::pair<uint64_t, uint64_t>& q, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv) -> bool {
             if (!cfg.relaxViews || !pv) return true;
+            if (!pv->empty() && pv->front() == INT32_MIN) return true;      // the processor could not report the whole path
             const uint64_t M = (uint64_t)std::max(p->max_branch, p->looking_depth) + 2;    // gap walks of Compatible, look-ahead windows of the vote
             for (size_t k = 0; k < nf; k++) if (q.first <= (uint64_t)f[k].hi + M && q.second + M > (uint64_t)f[k].lo) return true;
             for (uint64_t x = q.first; x < q.second; x++) {

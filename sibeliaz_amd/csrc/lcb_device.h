@@ -25,7 +25,8 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
                              std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr,
                              const uint32_t* view = nullptr,    // view[i]: `used` view of seed i (null = the live state)
-                             std::vector<lcb_counters>* perSeedCtr = nullptr);   // stats mode: the counters of every seed
+                             std::vector<lcb_counters>* perSeedCtr = nullptr,
+                             std::vector<std::vector<int32_t>>* pathSink = nullptr);   // -DLCB_PATH_SIG=1 builds: sorted |id| of every seed's path vertices   // stats mode: the counters of every seed
 // The same for a call whose first launch overlaps with host work: begin enqueues it against the live state of this moment (false:
 // not applicable, use the synchronous call), end waits and completes it.
 bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n);
