@@ -502,15 +502,23 @@ typedef struct {
     /* Optional footprints (orc_worker_process; not part of the reference): per pool entry ever created, the range of
      * positions whose `used` bit the computation read as 0 — the instance's span plus every look-ahead window walked from its
      * ends. Pool entries are re-created in the same order by the replay (BF:271-284), so the arrays survive path_clear. */
-    int fpOn; int64_t* fpLo; int64_t* fpHi; int64_t* fpChr; int64_t nFp, capFp;
+    int fpOn; int64_t* fpLo; int64_t* fpHi; int64_t nFp, capFp;   /* flat positions: chrBase[chr] + idx */
+    int64_t* chrBase;
+    /* The replay (BF:271-284) re-creates pool entries 0 .. n0-1 exactly as before; what the backward extension creates after it
+     * re-uses the pool indices of the entries the forward extension had created beyond the best point. Those are different
+     * instances: they get footprint slots of their own (index + fpShift for pool indices >= fpSplit). */
+    int64_t fpSplit, fpShift;
+    int fpMode;                                     /* 2: as described; 1: a re-used index merges into the old slot; 0: ... and the creating read is not recorded (the round-2 kernel) */
     int64_t* seenV; int64_t nSeenV, capSeenV;       /* with fpOn: every vertex that was ever part of the path (with repeats) */
 } Path;
 
-static void fp_touch(Path* p, int id, int64_t idx)
+static int64_t fp_slot(const Path* p, int id) { return id < p->fpSplit ? id : id + p->fpShift; }
+static void fp_touch(Path* p, int id, SeqIt it)
 {
     if (!p->fpOn) return;
-    if (idx < p->fpLo[id]) p->fpLo[id] = idx;
-    if (idx > p->fpHi[id]) p->fpHi[id] = idx;
+    const int64_t f = fp_slot(p, id), x = p->chrBase[it.chrId > 0 ? it.chrId - 1 : -it.chrId - 1] + it.idx;
+    if (x < p->fpLo[f]) p->fpLo[f] = x;
+    if (x > p->fpHi[f]) p->fpHi[f] = x;
 }
 
 static FILE* g_trace = NULL;
@@ -547,7 +555,7 @@ static void path_free(Path* p)
 {
     for (int64_t c = 0; c < p->g->nChr; c++) free(p->set[c]);
     free(p->set); free(p->setN); free(p->setCap); free(p->distance); free(p->leftBody); free(p->rightBody);
-    free(p->pool); free(p->allInstance); free(p->goodInstance); free(p->fpLo); free(p->fpHi); free(p->fpChr); free(p->seenV); free(p);
+    free(p->pool); free(p->allInstance); free(p->goodInstance); free(p->fpLo); free(p->fpHi); free(p->chrBase); free(p->seenV); free(p);
 }
 
 /* multiset::upper_bound(Instance(seqIt, 0)) under operator< on compareIdx_ (PH:177-180) */
@@ -573,15 +581,15 @@ static int set_insert(Path* p, SeqIt it, int64_t distance)                      
     p->pool[p->nPool++] = in;
     int64_t chr = it_chr(it);
     if (p->fpOn) {
-        if (id >= p->nFp) {
-            if (id >= p->capFp) {
+        const int64_t f = fp_slot(p, id);
+        if (f >= p->nFp) {
+            while (f >= p->capFp) {
                 p->capFp = p->capFp ? p->capFp * 2 : 1024;
                 p->fpLo = (int64_t*)realloc(p->fpLo, (size_t)p->capFp * sizeof(int64_t));
                 p->fpHi = (int64_t*)realloc(p->fpHi, (size_t)p->capFp * sizeof(int64_t));
-                p->fpChr = (int64_t*)realloc(p->fpChr, (size_t)p->capFp * sizeof(int64_t));
             }
-            p->fpLo[id] = p->fpHi[id] = it.idx; p->fpChr[id] = chr; p->nFp = id + 1;
-        } else fp_touch(p, id, it.idx);
+            p->fpLo[f] = p->fpHi[f] = p->chrBase[chr] + it.idx; p->nFp = f + 1;
+        } else if (p->fpMode != 0) fp_touch(p, id, it);
     }
     int64_t at = set_upper_bound(p, chr, it.idx);
     GROW(p->set[chr], p->setN[chr], p->setCap[chr], int);
@@ -709,7 +717,7 @@ static void point_push_front_worker(Path* p, int64_t vertex, int64_t distance, c
             if (!in->frontFinished) {
                 int prevGood = path_is_good(p, in);
                 inst_change_front(in, seqIt, distance);
-                fp_touch(p, p->set[chr][inst], seqIt.idx);
+                fp_touch(p, p->set[chr][inst], seqIt);
                 if (!prevGood && path_is_good(p, in)) push_good(p, p->set[chr][inst]);
                 if (it_used(g, seqIt)) in->frontFinished = 1;
             }
@@ -744,7 +752,7 @@ static void point_push_back_worker(Path* p, int64_t vertex, int64_t distance, co
             if (!in->backFinished) {
                 int prevGood = path_is_good(p, in);
                 inst_change_back(in, seqIt, distance);
-                fp_touch(p, p->set[chr][inst], seqIt.idx);
+                fp_touch(p, p->set[chr][inst], seqIt);
                 if (!prevGood && path_is_good(p, in)) push_good(p, p->set[chr][inst]);
                 if (it_used(g, seqIt)) in->backFinished = 1;
             }
@@ -851,7 +859,7 @@ static int64_t most_popular_vertex(Finder* f, int forward, int tryUsed, NextVert
             for (size_t d = 1; it_valid(g, it) && (d < (size_t)f->prm.looking_depth ||
                                abs32(it_position(g, it) - it_position(g, origin)) <= f->prm.max_branch); d++) {
                 if (f->ctr) f->ctr->n_walk++;
-                fp_touch(p, instList[i], it.idx);
+                fp_touch(p, instList[i], it);
                 int64_t vid = it_vid(g, it);
                 if (!dk_is_set(p, vid) && (!it_used(g, it) || tryUsed)) {
                     int64_t adjVid = vid + g->nVertex;
@@ -972,6 +980,7 @@ static void process(Finder* f, int64_t vid, char initChar, int64_t* bestScoreOut
         path_init(p, vid, initChar);
         for (int64_t i = 0; i < nEdge; i++) path_point_push_back(p, &bestEdge[i]);
         free(bestEdge);
+        if (p->fpOn && p->fpMode == 2) { p->fpSplit = p->nPool; p->fpShift = p->nFp - p->nPool; }
     }
     if (g_trace) fprintf(g_trace, "R %lld %lld %lld\n", (long long)bestRightSize, (long long)p->nAll, (long long)p->nGood);
     for (;;) {                                                     /* BF:292-306; note the stray ';' at BF:297 (Q1) */
@@ -1025,7 +1034,12 @@ orc_worker* orc_worker_new(orc_graph* g, const orc_params* p)
 {
     orc_worker* w = (orc_worker*)calloc(1, sizeof(orc_worker));
     w->f = finder_new(g, p, NULL);
-    w->f->path->fpOn = 1;
+    Path* pa = w->f->path;
+    pa->fpOn = 1;
+    pa->fpMode = getenv("ORC_FP_MODE") ? atoi(getenv("ORC_FP_MODE")) : 2;
+    pa->chrBase = (int64_t*)xmalloc((size_t)(g->nChr + 1) * sizeof(int64_t));
+    pa->chrBase[0] = 0;
+    for (int64_t c = 0; c < g->nChr; c++) pa->chrBase[c + 1] = pa->chrBase[c] + g->nPos[c];
     return w;
 }
 void orc_worker_free(orc_worker* w) { if (w) { finder_free(w->f); free(w); } }
@@ -1034,7 +1048,7 @@ int64_t orc_worker_process(orc_worker* w, int64_t vid, int32_t ch, orc_inst* out
 {
     Finder* f = w->f;
     f->ctr = ctr; f->path->ctr = ctr;
-    f->path->nFp = 0; f->path->nSeenV = 0;
+    f->path->nFp = 0; f->path->nSeenV = 0; f->path->fpSplit = INT64_MAX; f->path->fpShift = 0;
     int64_t bs = 0;
     process(f, vid, (char)ch, &bs);
     int64_t n = f->nBest;
@@ -1046,7 +1060,7 @@ int64_t orc_worker_process(orc_worker* w, int64_t vid, int32_t ch, orc_inst* out
     }
     if (best_score) *best_score = bs;
     if (n_fp) *n_fp = f->path->nFp;
-    for (int64_t i = 0; fp && i < f->path->nFp && i < fp_cap; i++) { fp[i].chr = f->path->fpChr[i]; fp[i].lo = f->path->fpLo[i]; fp[i].hi = f->path->fpHi[i]; }
+    for (int64_t i = 0; fp && i < f->path->nFp && i < fp_cap; i++) { fp[i].chr = -1; fp[i].lo = f->path->fpLo[i]; fp[i].hi = f->path->fpHi[i]; }   /* chr -1: flat positions */
     return n;
 }
 

@@ -87,8 +87,9 @@ int64_t orc_process_seed(orc_graph* g, const orc_params* p, int64_t vid, int32_t
 /* Same as above but appends a line-per-event trace to a file (debug aid for kernel diffs). */
 void orc_set_trace(const char* file);
 
-/* Reusable per-thread finder that also reports a seed's footprints (per pool entry ever created: chromosome and the index
- * range whose `used` bits were read as 0). Not part of the reference: support for tests / models of the round engine. */
+/* Reusable per-thread finder that also reports a seed's footprints (per instance ever created: the range of flat positions,
+ * first position of the chromosome + index, whose `used` bits were read as 0; chr = -1 marks flat coordinates). Not part of the
+ * reference: support for tests / models of the round engine. */
 typedef struct { int64_t chr, lo, hi; } orc_fp;
 typedef struct orc_worker orc_worker;
 orc_worker* orc_worker_new(orc_graph* g, const orc_params* p);

@@ -498,7 +498,19 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             // (a) exact phase-start results for every seed of the phase
             for (;;) {
                 bool all = true;
-                for (int64_t i = ph; i < ph + n && all; i++) if (!eValidNow(i)) all = false;
+                for (int64_t i = ph; i < ph + n && all; i++) {
+                    const bool ok = eValidNow(i);
+                    if (debug && getenv("LCB_ENGINE_DEBUG_SEED") && pos + i == atoll(getenv("LCB_ENGINE_DEBUG_SEED"))) {
+                        std::cerr << "   [seed " << (pos + i) << "] phase-start verdict " << ok << ", E from " << (eIdx[(size_t)i] >= 0 ? "a job" : "the round launch") << ", e0Checked " << e0Checked[(size_t)i] << ", footprint:";
+                        const lcb_fp* f = eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].fp.data() : round.fp.data() + round.fpOff[i];
+                        const size_t nf = eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].fp.size() : (size_t)(round.fpOff[i + 1] - round.fpOff[i]);
+                        for (size_t k = 0; k < nf; k++) std::cerr << " [" << f[k].lo << "," << f[k].hi << "]";
+                        std::cerr << "\n   epochs:";
+                        for (size_t e = 0; e < epochMarks.size(); e++) { std::cerr << " {" << e << ":"; for (auto& q : epochMarks[e].r) std::cerr << " [" << q.first << "," << q.second << ")"; std::cerr << "}"; }
+                        std::cerr << "\n";
+                    }
+                    if (!ok) all = false;
+                }
                 if (all) break;
                 planAndLaunch(ph, ph, false);
             }
@@ -510,7 +522,15 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 // the phase-start result of seed i is exact now: its events are the ones the reference's Process() call has
                 if (cfg.countEvents) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
                 if (cnt <= 1) continue;                                                  // blocksfinder.h:375
-                if (!com.conflicts(r, cnt)) { com.finalize(r, cnt); takeMarks(); if (eIdx[(size_t)i] >= 0) st.jobsUsed++; continue; }
+                if (!com.conflicts(r, cnt)) {
+                    if (debug) {
+                        std::cerr << "   commit E of seed " << (pos + i) << " -> block " << (com.blocksFound + 1) << " (" << cnt << " inst)";
+                        if (eIdx[(size_t)i] >= 0) { const Cand& c = cands[(size_t)eIdx[(size_t)i]]; std::cerr << " from a job: epoch " << c.epoch << " view set " << c.view; }
+                        else std::cerr << " from the round launch";
+                        std::cerr << ", open epoch " << (epochMarks.size() - 1) << "\n";
+                    }
+                    com.finalize(r, cnt); takeMarks(); if (eIdx[(size_t)i] >= 0) st.jobsUsed++; continue;
+                }
                 st.failures++;                                                           // blocksfinder.h:406
                 for (;;) {
                     if (fIdx[(size_t)i] >= 0) {
@@ -526,7 +546,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     uint64_t eb = 0, fb = 0;
                     for (uint64_t k = 0; k < cnt; k++) { uint64_t lo, hi; instRange(g, r[k], lo, hi); eb += hi - lo; }
                     for (auto& in : c.inst) { uint64_t lo, hi; instRange(g, in, lo, hi); fb += hi - lo; }
-                    std::cerr << "   F of seed " << (pos + i) << ": E " << cnt << " inst / " << eb << " pos -> F " << c.inst.size() << " inst / " << fb << " pos\n";
+                    std::cerr << "   F of seed " << (pos + i) << ": E " << cnt << " inst / " << eb << " pos -> F " << c.inst.size() << " inst / " << fb << " pos -> block "
+                              << (com.blocksFound + 1) << " (job of epoch " << c.epoch << ", view set " << c.view << ", open epoch " << (epochMarks.size() - 1) << ")\n";
                 }
                 if (c.inst.size() > 1) { com.finalize(c.inst.data(), c.inst.size()); takeMarks(); }   // blocksfinder.h:408-411
             }

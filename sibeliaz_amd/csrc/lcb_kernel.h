@@ -286,6 +286,12 @@ struct LcbStateT {
     // (bits only go 0 -> 1 and the computation is deterministic). Survives the replay's Clear.
     FieldU fpLo, fpHi;
     uint32_t nFp;
+    // The replay (blocksfinder.h:271-284) re-creates pool entries 0 .. n0-1 exactly as the forward extension had created them
+    // (same occurrences, same order), so they keep their footprint slots. What the backward extension creates afterwards re-uses
+    // the pool indices of the entries the forward extension had created beyond the best point - different instances: they get
+    // slots of their own, pool index + fpShift for indices >= fpSplit (lcb_fp_slot). Sharing the old slot would still be a
+    // superset (one hull over both instances), but such hulls span unrelated regions and void the result at almost any commit.
+    uint32_t fpSplit, fpShift;
     uint32_t instCap;
     // vote table (open addressing): key, accumulated weight, (list ordinal << 16) | step of the last contribution
     int32_t* vKey;
@@ -326,6 +332,15 @@ struct LcbStateT {
     // per-lane event counters (stats mode)
     uint64_t cWalk, cOcc, cCompatCall, cCompatStep, cVote, cPush;
 };
+
+// footprint slot of pool entry i (see LcbStateT::fpSplit)
+template <class ST>
+__device__ __forceinline__ uint32_t lcb_fp_slot(const ST& S, uint32_t i)
+{
+    if (i < S.fpSplit) return i;
+    const uint32_t f = i + S.fpShift;
+    return f < S.instCap ? f : i;      // no room for a slot of its own: it shares the old one (a superset: still exact)
+}
 
 __device__ __forceinline__ uint32_t lcb_hash(int32_t vid, uint32_t shift)
 {
@@ -678,8 +693,9 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                     // steps 1 .. c*64+first-1 read used == 0 (one step of slack keeps the - strand's bit g-1 inside)
                     const uint32_t st = c * 64 + first;
                     const uint32_t ge = st > cur.rem ? (cur.dir > 0 ? cur.g0 + cur.rem : cur.lo) : (cur.dir > 0 ? cur.g0 + st : cur.g0 - st);
-                    atomicMin(&S.fpLo[cur.i], ge);
-                    atomicMax(&S.fpHi[cur.i], ge);
+                    const uint32_t fs = lcb_fp_slot(S, cur.i);
+                    atomicMin(&S.fpLo[fs], ge);
+                    atomicMax(&S.fpHi[fs], ge);
                 }
                 break;
             }
@@ -724,7 +740,7 @@ __device__ inline LcbBest lcb_vote_argmax(const ST& S, bool forward, bool useGoo
 }
 
 // Mailbox words through which wave 0 hands a vote to the helper wavefronts of its workgroup.
-enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_NTOUCH, LCB_MAIL_WORDS = 8 };
+enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_NTOUCH, LCB_MAIL_FPSPLIT, LCB_MAIL_FPSHIFT, LCB_MAIL_WORDS = 8 };
 enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
 
 // Clears the vote-table slots named by the entries [s0, s1) of the touched list (blocksfinder.h:761-766).
@@ -776,6 +792,7 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
         if (S.lane == 0) {
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u);
             S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
+            S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
@@ -1038,8 +1055,9 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                 if (!positive) S.ordKey[S.cur * S.instCap + u - 1] = g;  // compareIdx_ follows the - strand front
                 if (usedS) S.iFlags[cand] |= LCB_FLAG_FRONTFIN;
             }
-            if (g < S.fpLo[cand]) S.fpLo[cand] = g;
-            if (g > S.fpHi[cand]) S.fpHi[cand] = g;
+            const uint32_t fs = lcb_fp_slot(S, cand);
+            if (g < S.fpLo[fs]) S.fpLo[fs] = g;
+            if (g > S.fpHi[fs]) S.fpHi[fs] = g;
             becameGood = before < (int64_t)S.P.minBlock && lcb_real_length(S, cand) >= (int64_t)S.P.minBlock;
         }
         const unsigned long long insM = __ballot(ins);
@@ -1061,14 +1079,18 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             S.iFrontDist[i] = distance; S.iBackDist[i] = distance; S.iLo[i] = lo;
             S.iHi[i] = occ.hi;
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
-            if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }
+            {   // the creating read (the occurrence's own `used` bit was 0)
+                const uint32_t fs = lcb_fp_slot(S, i);
+                if (fs >= S.nFp) { S.fpLo[fs] = g; S.fpHi[fs] = g; }
+                else { if (g < S.fpLo[fs]) S.fpLo[fs] = g; if (g > S.fpHi[fs]) S.fpHi[fs] = g; }
+            }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
             S.goodPos[i] = LCB_NONE16;
             S.touch[nTouch + r] = (uint16_t)i;
         }
         nTouch += m;
         S.nInst += m;
-        if (S.nInst > S.nFp) S.nFp = S.nInst;
+        if (m) { const uint32_t top = lcb_fp_slot(S, S.nInst - 1) + 1; if (top > S.nFp) S.nFp = top; if (S.nInst > S.nFp) S.nFp = S.nInst; }
         LCB_SYNC_IF(LcbCfg<ST::MODE>::INST_LDS && LcbCfg<ST::MODE>::IDX_LDS);
         if (m) lcb_order_merge(S, m);
     }
@@ -1290,7 +1312,7 @@ template <int MODE, bool STATS, bool PROF, int NW, class ST>
 __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t& bestScoreOut)
 {
     int64_t score = 0, bestScore = 0;
-    S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0; S.endInst = 0;
+    S.nBest = 0; S.status = LCB_ST_OK; S.ckN = 0; S.endInst = 0; S.fpSplit = 0xFFFFFFFFu; S.fpShift = 0;
     LCB_MARK(S, 2, 1);
     lcb_path_init<STATS>(S, vid, ch);
     LCB_MARK(S, 2, 2); LCB_MARK(S, 3, S.nInst);
@@ -1336,6 +1358,8 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
         }
         // the state is the one of the best forward point: its good instances are the best instances so far
         if (!S.status && bestScore > 0) lcb_snapshot(S);
+        // pool entries created from here on are new instances, not re-creations: footprint slots of their own (lcb_fp_slot)
+        S.fpSplit = S.nInst; S.fpShift = S.nFp - S.nInst;
     }
     LCB_MARK(S, 2, 4);
     if (!S.status && !dead) {
@@ -1485,6 +1509,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 S.U.tab = sArgs.usedTab;
                 const uint32_t flags = lcb_rfl(S.mail[LCB_MAIL_FLAGS]);
                 S.nTouch = lcb_rfl(S.mail[LCB_MAIL_NTOUCH]);
+                S.fpSplit = lcb_rfl(S.mail[LCB_MAIL_FPSPLIT]); S.fpShift = lcb_rfl(S.mail[LCB_MAIL_FPSHIFT]);
                 S.cWalk = 0;
                 lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
                                      (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW);

@@ -91,7 +91,7 @@ struct OracleProc : LcbProcessor {
                 for (int64_t e = 0; e < k; e++) ri[(size_t)i][(size_t)e] = lcb_instance{buf[e].chr, buf[e].front_idx, buf[e].back_idx, buf[e].positive ? 1u : 0u};
                 rf[(size_t)i].resize((size_t)nfp);
                 for (int64_t e = 0; e < nfp; e++) {
-                    const uint32_t base = (uint32_t)g->chrStart[(size_t)fbuf[e].chr];
+                    const uint32_t base = fbuf[e].chr < 0 ? 0u : (uint32_t)g->chrStart[(size_t)fbuf[e].chr];
                     const uint32_t lo = base + (uint32_t)fbuf[e].lo, hi = base + (uint32_t)fbuf[e].hi;
                     rf[(size_t)i][(size_t)e] = lcb_fp{lo ? lo - 1 : 0u, hi};      // the - strand reads bit g-1
                 }
@@ -217,6 +217,11 @@ int main(int argc, char** argv)
                 (tRound + tJobs + tBig) / 1000);
         fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld; critical path without the reproductions: %lld pushes\n",
                 (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical, (long long)proc.criticalNew);
+        if (getenv("MODEL_DUMP")) {
+            FILE* f = fopen(getenv("MODEL_DUMP"), "w");
+            for (auto& bl : blocks) fprintf(f, "%d\t%llu\t%llu\t%llu\n", bl.id, (unsigned long long)bl.chr, (unsigned long long)bl.start, (unsigned long long)bl.end);
+            fclose(f);
+        }
         // parity of the model itself: the oracle's own FindBlocks on a fresh state
         if (!limit && !getenv("MODEL_NOCHECK")) {
             orc_graph* o = proc.og[0];
@@ -226,6 +231,13 @@ int main(int argc, char** argv)
             int diffs = nb != (int64_t)blocks.size();
             for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
                 if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
+            for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
+                if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) {
+                    fprintf(stderr, "model: first difference at block row %lld: oracle id %d chr %llu [%llu,%llu) vs engine id %d chr %llu [%llu,%llu)\n", (long long)i, ob[i].id,
+                            (unsigned long long)ob[i].chr, (unsigned long long)ob[i].start, (unsigned long long)ob[i].end, blocks[i].id, (unsigned long long)blocks[i].chr,
+                            (unsigned long long)blocks[i].start, (unsigned long long)blocks[i].end);
+                    break;
+                }
             fprintf(stderr, "model: blocks vs the oracle's FindBlocks: %s (%lld vs %zu)\n", diffs ? "DIFFERENT" : "equal", (long long)nb, blocks.size());
             return diffs ? 1 : 0;
         }
