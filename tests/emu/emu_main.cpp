@@ -438,6 +438,24 @@ int main(int argc, char** argv)
                 int64_t score = 0;
                 const int64_t n = orc_process_seed(og, &op, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &score, &octr);
                 bad += compareSeed((int64_t)i, seeds[i], emu.out[i], emu.arena.data(), ref.data(), n, score);
+                if (getenv("EMU_FP_CHECK") && emu.out[i].status == 0) {
+                    // Completeness of the footprint (rule (2) of the engine): with EVERY unused position outside the kernel's
+                    // footprint intervals set to used, Process() must still give this result - it never read those bits as 0.
+                    const LcbSeedOut& o = emu.out[i];
+                    std::vector<uint8_t> keep((size_t)g->nPos(), 0);
+                    for (uint32_t e = 0; e < o.nFp; e++) { const uint2 f = emu.fpArena[o.fpOff + e]; for (uint32_t q = f.x; q <= f.y && q < keep.size(); q++) keep[q] = 1; }
+                    const size_t stride = orc_used_stride();
+                    std::vector<uint8_t*> flipped;
+                    for (int64_t c = 0; c < orc_n_chr(og); c++) {
+                        uint8_t* u = orc_chr_used(og, c);
+                        const uint64_t base = g->chrStart[c];
+                        for (int64_t q = 0; q < orc_chr_n_pos(og, c); q++) if (!keep[(size_t)(base + q)] && !u[(size_t)q * stride]) { u[(size_t)q * stride] = 1; flipped.push_back(&u[(size_t)q * stride]); }
+                    }
+                    int64_t score2 = 0;
+                    const int64_t n2 = orc_process_seed(og, &op, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &score2, nullptr);
+                    for (uint8_t* u : flipped) *u = 0;
+                    if (compareSeed((int64_t)i, seeds[i], o, emu.arena.data(), ref.data(), n2, score2)) { fprintf(stderr, "FAIL: the footprint of seed %zu does not cover what it read (%zu positions outside it were set)\n", i, flipped.size()); bad++; }
+                }
 #if LCB_PATH_SIG
                 {   // the kernel's path signature against the oracle's list of every vertex that was ever part of the path
                     static orc_worker* wk = orc_worker_new(og, &op);

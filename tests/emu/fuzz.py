@@ -4,7 +4,9 @@ code + the product's round engine under the wavefront emulator (emu_check) again
     python tests/emu/fuzz.py <seconds> [first case number]        # log: $LCB_FUZZ_DIR/fuzz.log (default /tmp/lcb_fuzz)
 
 Each case runs `find` with the shipped (non-stats) kernel instantiation and random engine knobs (round size, number of predicted
-views, F prediction, job cap), `seeds-init` with and without event counters, and one multi-wavefront variant (wide or big mode
+views, F prediction, job cap), `seeds-init` / `seeds-final` with the footprint-completeness check (EMU_FP_CHECK: every unused position
+outside a seed's footprint is set to used and the oracle must still reproduce the result), `seeds-init` with event counters, and one
+multi-wavefront variant (wide or big mode
 with helper wavefronts) on the heaviest seeds. Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
 cases inside the CPU suite; the open-ended campaign is this script.
 """
@@ -30,7 +32,8 @@ def case_params(i, small=False):
              "--tandem", str(rnd.choice([0, 0.2])), "--nrun", str(rnd.choice([0, 0.1])), "--chromosomes", str(rnd.choice([1, 1, 3])), "--seed", str(1000 + i)]
     runs = [("find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_VIEWS": rnd.choice(["0", "3", "64"]),
                       "LCB_PREDICT_F": rnd.choice(["1", "2", "3"]), "EMU_CONCURRENCY": rnd.choice(["4", "64", "16384"])}),
-            ("seeds-init", {"EMU_NOSTATS": "1"}), ("seeds-init", {}),
+            ("seeds-init", {"EMU_NOSTATS": "1", "EMU_FP_CHECK": "1", "EMU_LIMIT": "1500"}), ("seeds-final", {"EMU_NOSTATS": "1", "EMU_FP_CHECK": "1", "EMU_LIMIT": "1500"}),
+            ("seeds-init", {}),
             rnd.choice([("medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}),
                         ("medium", {"EMU_NW": "8", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "4", "EMU_LIMIT": "150"})])]
     return synth, (k, b, m, a), runs, (strains, segs)

@@ -164,6 +164,10 @@ def emu_built():
                                             # list seed by seed), the engine's relaxViews rule uses them
                                             ("twogenomes", "seeds-init", {"EMU_LIMIT": "400", "EMU_SIG": "1"}), ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SIG": "1"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_SIG": "1", "EMU_RELAX": "1"}),
+                                            # footprint completeness (EMU_FP_CHECK): every unused position outside a seed's footprint set to used -> same result
+                                            ("nruns_abund", "seeds-init", {"EMU_NOSTATS": "1", "EMU_LIMIT": "700", "EMU_FP_CHECK": "1"}),
+                                            ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150", "EMU_FP_CHECK": "1"}),
+                                            ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150", "EMU_FP_CHECK": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
