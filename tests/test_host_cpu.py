@@ -197,3 +197,25 @@ def test_engine_model_reproduces_the_oracle(built, case_dir, name, relax):
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "engine_model"), c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a)],
                        capture_output=True, text=True, env=dict(os.environ, MODEL_RELAX=relax, MODEL_THREADS="2"))
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("env", [{}, {"LCB_MAX_JOBS": "64", "LCB_EAGER_PHASES": "2"}, {"MODEL_RELAX": "1", "LCB_PREDICT_F": "2"}])
+def test_engine_model_at_scale(built, tmp_path_factory, env):
+    """The round engine over 176 000 seeds (config 2 at a tenth of the segments: the emulator cannot reach this size) with the
+    oracle as the processor: rounds that grow to 256 phases, hundreds of job launches against predicted views, all with the
+    oracle's footprints - the blocks must be the oracle's FindBlocks for every knob set."""
+    import bench
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/engine_model"])
+    work = os.environ.get("LCB_TEST_WORKLOADS") or str(tmp_path_factory.getbasetemp().parent / "lcb_model_workloads")
+    old = os.environ.get("LCB_BENCH_DIR")
+    os.environ["LCB_BENCH_DIR"] = work
+    try:
+        w = bench.ensure_workload("ecoli10_small")
+    finally:
+        if old is None:
+            os.environ.pop("LCB_BENCH_DIR", None)
+        else:
+            os.environ["LCB_BENCH_DIR"] = old
+    r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "engine_model"), w["graph"], w["fasta"], str(w["k"]), str(w["b"]), str(w["m"]), str(w["a"])],
+                       capture_output=True, text=True, env=dict(os.environ, MODEL_THREADS="4", **env))
+    assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
