@@ -154,6 +154,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
     if (rank < 0 || rank >= world) throw LcbError("bad rank");
     if (cfg.countEvents && world > 1) throw LcbError("event counting runs on one rank");
+    if (cfg.relaxViews && (world > 1 || (cfg.exchangeAlways && cfg.allgather))) throw LcbError("relaxViews: the path vertices are not part of the rank exchange yet (one rank only)");
 
     lcb_committer com(g, *p);
     proc.reset();
