@@ -87,18 +87,26 @@ struct KmerTable {
             if (k == 0) return SIZE_MAX;
         }
     }
-    // false: the table is too full (the caller starts over with a larger one)
+    // false: the table is too full (the caller starts over with a larger one). `full` is shared by all threads: once it is
+    // set nobody inserts any more, and a probe sequence never runs past one sweep of the table, so a table that filled up under
+    // the feet of the in-flight chunks cannot spin.
+    std::atomic<bool> full{false};
     bool add(uint64_t kmer, uint32_t bits) {
-        for (size_t h = mix(kmer) & mask;; h = (h + 1) & mask) {
+        if (full.load(std::memory_order_relaxed)) return false;
+        size_t h = mix(kmer) & mask;
+        for (size_t probes = 0; probes <= mask; probes++, h = (h + 1) & mask) {
             uint64_t k = key[h].load(std::memory_order_relaxed);
             if (k == 0) {
                 if (key[h].compare_exchange_strong(k, kmer + 1, std::memory_order_relaxed)) {
-                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 7) return false;
+                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 7) { full.store(true, std::memory_order_relaxed); return false; }
                     k = kmer + 1;
                 }
             }
             if (k == kmer + 1) { val[h].fetch_or(bits, std::memory_order_relaxed); return true; }
+            if ((probes & 1023) == 1023 && full.load(std::memory_order_relaxed)) return false;
         }
+        full.store(true, std::memory_order_relaxed);
+        return false;
     }
 };
 
@@ -159,29 +167,26 @@ int main(int argc, char** argv) {
         for (;; cap <<= 1) {
             tp.reset(new KmerTable(cap));
             KmerTable& table = *tp;
-            bool full = false;
             #pragma omp parallel for schedule(dynamic, 1)
             for (size_t c = 0; c < chunks.size(); c++) {
-                if (full) continue;
+                if (table.full.load(std::memory_order_relaxed)) continue;
                 const std::string& s = rec[chunks[c].rec].seq;
                 forEachKmer(s, k, chunks[c].from, chunks[c].to, [&](size_t p, uint64_t fwd, uint64_t rc) {
                     const int nx = p + k < s.size() ? code(s[p + k]) : -1;
                     const int pv = p > 0 ? code(s[p - 1]) : -1;
                     uint32_t bits = (nx < 0 || pv < 0) ? 0x100 : 0;
-                    bool ok;
                     if (fwd < rc) {
                         if (nx >= 0) bits |= 1u << nx;
                         if (pv >= 0) bits |= 1u << (4 + pv);
-                        ok = table.add(fwd, bits);
+                        table.add(fwd, bits);         // (a refused insert sets table.full: this pass is abandoned)
                     } else {
                         if (pv >= 0) bits |= 1u << (3 - pv);
                         if (nx >= 0) bits |= 1u << (4 + 3 - nx);
-                        ok = table.add(rc, bits);
+                        table.add(rc, bits);
                     }
-                    if (!ok) full = true;
                 });
             }
-            if (!full) break;
+            if (!table.full.load()) break;
         }
         KmerTable& table = *tp;
         PHASE("k-mer table");

@@ -90,3 +90,21 @@ def test_mkgraph_matches_brute_force(built, case, k, tmp_path):
     if k == case.k:       # the committed golden graph is what this tool wrote when the reference produced the goldens
         with gzip.open(os.path.join(case.dir, "graph.bin.gz"), "rb") as f:
             assert f.read() == open(out, "rb").read()
+
+
+def test_mkgraph_low_redundancy_many_threads(built, tmp_path):
+    """A random (low-redundancy) sequence fills the first k-mer table of the parallel build: every thread has to notice,
+    stop inserting and start over with a larger table instead of probing a full table forever; same file for any thread count."""
+    import hashlib
+    import random
+
+    rnd = random.Random(5)
+    fa = tmp_path / "rand.fa"
+    fa.write_text(">r\n" + "".join(rnd.choice("ACGT") for _ in range(3_000_000)) + "\n")
+    digests = set()
+    for threads in (1, 4):
+        out = str(tmp_path / ("g%d.bin" % threads))
+        subprocess.run([os.path.join(ROOT, "sibeliaz_amd", "bin", "lcb-mkgraph"), "-k", "25", "-o", out, str(fa)], check=True, timeout=120,
+                       stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        digests.add(hashlib.md5(open(out, "rb").read()).hexdigest())
+    assert len(digests) == 1
