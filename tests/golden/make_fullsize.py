@@ -4,7 +4,8 @@
 container only (the reference does not exist on the GPU box); the GPU tests regenerate the inputs with the same
 deterministic tools (lcb-synth, lcb-mkgraph) and compare hashes.
 
-    python tests/golden/make_fullsize.py [workdir]        # default /tmp/lcb_fullsize; ~25 min of CPU on 8 cores
+    python tests/golden/make_fullsize.py [workdir [case ...]]   # default /tmp/lcb_fullsize; ~25 min of CPU on 8 cores; named cases only:
+                                                                # the entries of the others are kept as they are
 
 Only hashes, line counts and the banner figures are committed — no reference source, no genome data.
 """
@@ -25,6 +26,9 @@ CASES = [
     ("config2_ecoli10_a150", "ecoli10", 150),
     ("config3_ecoli62_a150", "ecoli62", 150),
     ("config3_ecoli62_a868", "ecoli62", 868),       # a = 2 * N * D = 2 * 62 * 7 (reference README.md:161-175)
+    # configs 4 / 5 (k = 25, many chromosomes, repeat families filtered by a = 150) at the size of a parity test
+    ("config4_primates8_test", "primates8_test", 150),
+    ("config5_mice16_test", "mice16_test", 150),
 ]
 
 
@@ -40,8 +44,12 @@ def main():
     work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/lcb_fullsize"
     os.environ["LCB_BENCH_DIR"] = work
     ref = os.path.join(ROOT, "oracle", "_ref", "sibeliaz-lcb-ref")
-    out = {}
+    only = set(sys.argv[2:])
+    target = os.path.join(ROOT, "tests", "golden", "fullsize.json")
+    out = json.load(open(target)) if only and os.path.exists(target) else {}
     for name, wl, a in CASES:
+        if only and name not in only:
+            continue
         w = bench.ensure_workload(wl)
         od = os.path.join(w["dir"], "ref_a%d" % a)
         gff = os.path.join(od, "blocks_coords.gff")
@@ -62,7 +70,7 @@ def main():
             "coverage": re.search(r"Coverage: ([0-9.]+)", banner).group(1),
         }
         print(name, out[name]["gff_sha256"], out[name]["blocks_found"], flush=True)
-    with open(os.path.join(ROOT, "tests", "golden", "fullsize.json"), "w") as f:
+    with open(target, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
 

@@ -1,5 +1,7 @@
 """GPU parity at the BASELINE.json configurations' stated size (run with -m gpu on an MI355X): config 2 (10 strains, 45 Mbp)
-and config 3 (62 strains, 281 Mbp; a = 150 and a = 2*62*7 = 868, reference README.md:161-175). The inputs are regenerated on
+and config 3 (62 strains, 281 Mbp; a = 150 and a = 2*62*7 = 868, reference README.md:161-175), and the shapes of configs 4 / 5
+(k = 25, 8 strains x 24 chromosomes at 1 % divergence and 16 x 20 at 0.5 %, repeat families of 100 copies under a = 150: long
+paths over few genomes, ten commit conflicts per block) at a size the suite can afford (186 / 217 Mbp). The inputs are regenerated on
 the box with the deterministic tools (lcb-synth seed 1001 / 1002 + lcb-mkgraph) and checked by hash; the expected
 blocks_coords.gff hashes were produced by the UNMODIFIED reference in the build container (tests/golden/make_fullsize.py ->
 tests/golden/fullsize.json). The product path is the C ABI: lcb_graph_load -> lcb_enumerate_seeds -> lcb_find_blocks_ex ->
