@@ -581,9 +581,18 @@ struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 // The voter walks of one vote. The voters are the instances of the touch list that are in the voting list (the good list
 // if it has two entries, else all instances; blocksfinder.h:713). Wave w of nWaves takes the voters with ordinal == w
 // (mod nWaves); all waves accumulate into the shared vote table with atomics, so the split needs no merging.
+// `exact`: the walks stop at vertices of the path (blocksfinder.h:736-741). Where the path set lives in the HBM slot behind an LDS
+// Bloom filter (compact, big, huge) a per-step membership test costs a dependent global round trip for every chunk in which the
+// filter says "maybe" for one lane - with a path of thousands of vertices that is almost every chunk (the filter is a quarter
+// full: a 64-lane chunk sees a false positive with probability > 0.9), and the walks of a vote with 60 voters paid ~100 such
+// round trips. A walk meets a path vertex only at repeats and rearrangements, so the first pass of a vote walks WITHOUT the
+// test (exact = false: only `used` positions and the window bound stop a walk) and the distinct vertices it touched - they are all in
+// the vote table - are checked afterwards, lane-parallel, once (lcb_vote_any_in_path). No hit: no walk can have met a path
+// vertex, the pass is what the reference computes. A hit: the table is cleared and the vote repeated with exact = true.
+// (Footprints of a discarded pass stay: a superset.)  Variants with the path set in LDS always walk exactly.
 template <bool STATS, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
-                                     uint32_t waveId, uint32_t nWaves)
+                                     uint32_t waveId, uint32_t nWaves, bool exact)
 {
     const LcbTables& T = S.T;
     const uint32_t vmask = S.voteCap - 1;
@@ -650,18 +659,23 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
         return w;
     };
     LcbVoter cur, nxt;
-    LcbWalk wcur, wnxt;
+    LcbWalk wcur, wnxt, wahead = LcbWalk{0u, 0u, 0, 0u, false};
     bool have = nextVoter(cur);
     if (have) wcur = issue(cur, 0);
+    bool deep = false;                  // the previous voter's window did not end in its first 64 steps (k = 15: ~120 junctions in b = 200 bp)
     while (have) {
         const bool haveNext = nextVoter(nxt);
         if (haveNext) wnxt = issue(nxt, 0);
         for (uint32_t c = 0;; c++) {
-            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
+            // chunk c + 1 is requested before chunk c is consumed (once the windows are known to be that long)
+            const bool ahead = c > 0 || deep;
+            const LcbWalk w = c == 0 ? wcur : ((c > 1 || deep) ? wahead : issue(cur, c));
+            if (ahead) wahead = issue(cur, c + 1);
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
-            const bool stop = cond && ((w.uw & 1u) != 0 || lcb_path_contains(S, vid));
+            bool stop = cond && (w.uw & 1u) != 0;
+            if (exact && cond && !stop) stop = lcb_path_contains(S, vid);
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
             const unsigned long long endM = failM | stopM;
@@ -697,11 +711,22 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                     atomicMin(&S.fpLo[fs], ge);
                     atomicMax(&S.fpHi[fs], ge);
                 }
+                deep = c > 0;
                 break;
             }
         }
         have = haveNext; cur = nxt; wcur = wnxt;
     }
+}
+
+// Is one of the vertices named by the entries [s0, s1) of the touched list of the vote table in the path? (after a pass with
+// exact = false, see lcb_vote_walk; wave-uniform result)
+template <class ST>
+__device__ inline bool lcb_vote_any_in_path(const ST& S, uint32_t s0, uint32_t s1)
+{
+    bool hit = false;
+    for (uint32_t q = s0 + S.lane; q < s1; q += 64) if (lcb_path_contains(S, S.vKey[S.vTouched[q]])) hit = true;
+    return __ballot(hit) != 0;
 }
 
 // Arg-max over the entries [s0, s1) of the touched list of the vote table, wave-wide: max count; ties -> smallest origin (strand, g) of the
@@ -760,18 +785,78 @@ __device__ inline void lcb_vote_clear(ST& S, uint32_t s0, uint32_t s1)
 // One wave's share of a large vote after the walks: partial arg-max over its slice of the touched list, then (after
 // everyone has read) the clearing of that slice.
 template <int NW, class ST>
-__device__ inline void lcb_vote_reduce_slice(ST& S, bool forward, bool useGood, uint32_t waveId, uint32_t nTouched)
+__device__ inline void lcb_vote_reduce_slice(ST& S, bool forward, bool useGood, uint32_t waveId, uint32_t nTouched, bool exact)
 {
     const uint32_t per = (nTouched + NW - 1) / NW;
     const uint32_t s0 = waveId * per < nTouched ? waveId * per : nTouched, s1 = s0 + per < nTouched ? s0 + per : nTouched;
+    const bool hit = !exact && lcb_vote_any_in_path(S, s0, s1);      // a pass without path stops: is a vertex of this slice in the path?
     const LcbBest b = lcb_vote_argmax(S, forward, useGood, s0, s1);
     if (S.lane == 0) {
         uint32_t* p = S.part + 8 * waveId;
-        p[0] = b.cnt; p[1] = b.keyHi; p[2] = b.keyLo; p[3] = (uint32_t)b.vid; p[4] = b.e;
+        p[0] = b.cnt; p[1] = b.keyHi; p[2] = b.keyLo; p[3] = (uint32_t)b.vid; p[4] = b.e; p[5] = hit ? 1u : 0u;
     }
     __syncthreads();                                           // C: every slice has been read, partials are visible
     lcb_vote_clear(S, s0, s1);
     __syncthreads();                                           // D: the table is clean before wave 0 votes again (possibly on its own)
+}
+
+// One pass of a vote over the voters of the touch list: walks, arg-max, clearing of the table. `hit`: the pass walked without
+// path stops and one of the vertices it touched is in the path (or the touched list is incomplete) - its result is void.
+template <bool STATS, int NW, class ST>
+__device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank, bool exact, bool& ovfAny, bool& hit)
+{
+    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
+    LcbBest b;
+    uint32_t nTouched;
+    hit = false;
+    if (NW > 1 && S.nTouch > 1) {
+        // wake the helper wavefronts: every wave walks its share of the voters
+        if (S.lane == 0) {
+            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u) | (exact ? 16u : 0u);
+            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
+            S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
+            S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
+        }
+        __syncthreads();                                           // A
+        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, NW, exact);
+        __syncthreads();                                           // B: all walks done
+        nTouched = lcb_rfl(*S.vNClaimed);
+        if (nTouched > claimCap) nTouched = claimCap;
+        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
+        if (S.nTouch >= LCB_VOTE_SHARE_MIN) {
+            lcb_vote_reduce_slice<NW>(S, forward, useGood, 0, nTouched, exact);      // contains barriers C and D
+            // final reduction over the NW partial results
+            uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0, pHit = 0;
+            if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; pHit = p[5]; }
+            hit = __ballot(pHit != 0) != 0;
+            b.cnt = lcb_wave_umax(pc);
+            bool c = pc == b.cnt && b.cnt != 0;
+            b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
+            b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
+            const unsigned long long m = __ballot(c);
+            const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+            b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
+            b.e = lcb_rl(pe, w);
+        } else {
+            hit = !exact && lcb_vote_any_in_path(S, 0, nTouched);
+            b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
+            LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+            lcb_vote_clear(S, 0, nTouched);
+        }
+    } else {
+        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1, exact);
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+        nTouched = lcb_rfl(*S.vNClaimed);
+        if (nTouched > claimCap) nTouched = claimCap;
+        hit = !exact && lcb_vote_any_in_path(S, 0, nTouched);
+        b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+        lcb_vote_clear(S, 0, nTouched);
+    }
+    ovfAny = lcb_rfl(*S.vOvf) != 0;
+    if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
+    LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+    return b;
 }
 
 template <bool STATS, bool PROF, int NW, class ST>
@@ -784,53 +869,23 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
     if (PROF) S.pfVote++;
     originInst = 0;
     if (nList == 0 || S.nTouch == 0) return 0;                     // nobody votes: nothing to walk, nothing to clear
-    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
-    LcbBest b;
-    uint32_t nTouched;
-    if (NW > 1 && S.nTouch > 1) {
-        // wake the helper wavefronts: every wave walks its share of the voters
-        if (S.lane == 0) {
-            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u);
-            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
-            S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
-            S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
-        }
-        __syncthreads();                                           // A
-        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, NW);
-        __syncthreads();                                           // B: all walks done
-        nTouched = lcb_rfl(*S.vNClaimed);
-        if (nTouched > claimCap) nTouched = claimCap;
-        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
-        if (S.nTouch >= LCB_VOTE_SHARE_MIN) {
-            lcb_vote_reduce_slice<NW>(S, forward, useGood, 0, nTouched);      // contains barriers C and D
-            // final reduction over the NW partial results
-            uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0;
-            if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; }
-            b.cnt = lcb_wave_umax(pc);
-            bool c = pc == b.cnt && b.cnt != 0;
-            b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
-            b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
-            const unsigned long long m = __ballot(c);
-            const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
-            b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
-            b.e = lcb_rl(pe, w);
-        } else {
-            b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
+    // path set behind a Bloom filter: the first pass walks without path stops and is verified afterwards (lcb_vote_walk)
+    constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
+    const uint64_t cWalk0 = S.cWalk;
+    bool ovfAny = false, hit = false;
+    LcbBest b = lcb_vote_pass<STATS, NW>(S, forward, tryUsed, useGood, nList, flank, !DEFER, ovfAny, hit);
+    if (DEFER && (hit || ovfAny)) {
+        // a touched vertex is in the path (or the table overflowed, so that the touched list is incomplete - a pass with path stops
+        // may touch fewer vertices): the vote as the reference walks it. After an overflow the table may hold stale keys.
+        if (ovfAny) {
+            // (no helper is inside the table: they all wait at barrier A for the next vote)
+            for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
             LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-            lcb_vote_clear(S, 0, nTouched);
         }
-    } else {
-        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1);
-        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-        nTouched = lcb_rfl(*S.vNClaimed);
-        if (nTouched > claimCap) nTouched = claimCap;
-        b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
-        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-        lcb_vote_clear(S, 0, nTouched);
+        if (STATS) S.cWalk = cWalk0;
+        if (PROF) S.pfMaxProbe++;             // (instrumented variant: number of repeated votes)
+        b = lcb_vote_pass<STATS, NW>(S, forward, tryUsed, useGood, nList, flank, true, ovfAny, hit);
     }
-    const bool ovfAny = lcb_rfl(*S.vOvf) != 0;
-    if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
-    LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
     if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
     if (b.cnt == 0) return 0;
     originInst = useGood ? lcb_rfl((uint32_t)S.good[b.e]) : b.e;
@@ -1512,7 +1567,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 S.fpSplit = lcb_rfl(S.mail[LCB_MAIL_FPSPLIT]); S.fpShift = lcb_rfl(S.mail[LCB_MAIL_FPSHIFT]);
                 S.cWalk = 0;
                 lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
-                                     (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW);
+                                     (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW, (flags & 16u) != 0);
                 if (STATS) {
                     const unsigned long long w = (unsigned long long)lcb_wave_sum((int64_t)S.cWalk);
                     if (S.lane == 0 && w) atomicAdd(S.mailWalk, w);
@@ -1523,7 +1578,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                     uint32_t nTouched = lcb_rfl(*S.vNClaimed);
                     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
                     if (nTouched > claimCap) nTouched = claimCap;
-                    lcb_vote_reduce_slice<NW>(S, (flags & 1u) != 0, (flags & 4u) != 0, waveId, nTouched);   // contains barriers C and D
+                    lcb_vote_reduce_slice<NW>(S, (flags & 1u) != 0, (flags & 4u) != 0, waveId, nTouched, (flags & 16u) != 0);   // contains barriers C and D
                 }
             }
         }
