@@ -350,10 +350,11 @@ struct lcb_device_impl {
             if (!stats && seedTrace && hCtr)  // per-seed profile of the slowest seeds of the launch (ticks are 10 ns)
                 for (uint32_t i = 0; i < m; i++)
                     if (hCtr[i].c[0] > 2000)
-                        fprintf(traceFile, "#seed\t%lld\t%u\t%d\tst=%u\tn=%u\tticks=%llu\tpush=%llu\tvote=%llu\tprobe=%llu\tinst=%llu\ttv=%llu\ttp=%llu\tts=%llu\n", (long long)launches, i, hSeeds[i].vid,
+                        fprintf(traceFile, "#seed\t%lld\t%u\t%d\tst=%u\tn=%u\tticks=%llu\tpush=%llu\tvote=%llu\tprobe=%llu\tinst=%llu\ttv=%llu\ttp=%llu\tts=%llu\tcwalk=%llu\tcwaitb=%llu\tcreduce=%llu\tcscan=%llu\tvoters=%llu\tchunks=%llu\ttouch=%llu\n", (long long)launches, i, hSeeds[i].vid,
                             hOut[i].status, hOut[i].nInst, (unsigned long long)hCtr[i].c[0], (unsigned long long)hCtr[i].c[1], (unsigned long long)hCtr[i].c[2],
                             (unsigned long long)hCtr[i].c[3], (unsigned long long)hCtr[i].c[4], (unsigned long long)hCtr[i].c[5], (unsigned long long)hCtr[i].c[6],
-                            (unsigned long long)hCtr[i].c[7]);
+                            (unsigned long long)hCtr[i].c[7], (unsigned long long)hCtr[i].c[8], (unsigned long long)hCtr[i].c[9], (unsigned long long)hCtr[i].c[10],
+                            (unsigned long long)hCtr[i].c[11], (unsigned long long)hCtr[i].c[12], (unsigned long long)hCtr[i].c[13], (unsigned long long)hCtr[i].c[14]);
         }
     }
 };

@@ -22,6 +22,11 @@
 // Neighbouring blocks, which invalidate each other one after the other, are thereby recomputed in ONE launch instead of
 // a chain of launches; a result whose prediction did not come true fails (1) or (2) and is simply computed again at the
 // next stop, where the first missing result always runs against the live state itself, so the loop makes progress.
+// A stop needs ONE result to go on - the first job of its plan, which runs against the live state; everything else the plan
+// launches is speculation. With a processor that has side lanes (LcbProcessor::sideBegin, the product's device) the speculation
+// runs in the background and the stop waits for its one result only: a launch is as long as its longest seed, and the longest
+// job of a plan is usually not the one the commit is waiting for. Background results are taken when the commit reaches their seed,
+// if every predicted mark of their view has come true by then; they are validated like any other result.
 // With world > 1 every launch — a round's speculative launch and every job launch — is dealt round-robin to the ranks and
 // the per-seed results + footprints are all-gathered; every rank then runs the identical dry runs and commit, so all
 // ranks hold the same `used` state and block list without further traffic.
@@ -196,6 +201,34 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<int32_t> eIdx, fIdx;                // per seed of the round: its newest E / F job result in cands, or -1
     std::vector<uint32_t> e0Checked;                // per seed: epochs already checked for its round-launch result
     std::vector<RangeSet> viewSets;                 // predicted mark sets of this round's views
+    // Seeds of the round whose round-launch result has a footprint or instances, ascending. The others - after the first rounds
+    // almost all: their Path::Init found every occurrence used - read no bit as 0 and commit nothing: no commit can void them and
+    // no loop below has to look at them.
+    std::vector<int32_t> liveIdx;
+    auto liveFrom = [&](int64_t i) { return (size_t)(std::lower_bound(liveIdx.begin(), liveIdx.end(), (int32_t)i) - liveIdx.begin()); };
+
+    // ---- asynchronous job batches (side lanes of the processor), one rank only
+    const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !cfg.relaxViews && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
+    struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
+    std::vector<SideJob> sideJobs;                  // of this round
+    std::vector<int32_t> sideE, sideF;              // per seed of the round: its job in flight for E / F (index into sideJobs), or -1
+    std::vector<int> lanePending((size_t)std::max(0, proc.sideLanes()), 0);   // jobs in flight per lane
+    std::vector<int> laneOrder;                     // lanes with a batch in flight, oldest first
+    std::vector<lcb_instance> sInst;
+    std::vector<lcb_fp> sFp;
+    auto laneDone = [&](int lane) {                 // one job of the lane fewer in flight; the last one frees the lane
+        if (--lanePending[(size_t)lane] == 0) {
+            proc.sideRelease(lane);
+            auto it = std::find(laneOrder.begin(), laneOrder.end(), lane);
+            if (it != laneOrder.end()) laneOrder.erase(it);
+        }
+    };
+    auto dropSide = [&](int32_t idx) {
+        SideJob& sj = sideJobs[(size_t)idx];
+        int32_t& ref = (sj.isF ? sideF : sideE)[(size_t)sj.seed];
+        if (ref == idx) ref = -1;
+        if (sj.state == 0) { sj.state = 2; st.sideVoid++; laneDone(sj.lane); }
+    };
 
     // Runs ProcessVertex::Process for n seeds (seed i against view[i]) on ALL ranks: seed i goes to rank i % world, the
     // per-seed results and footprints are all-gathered (sizes first, then the padded payload), so every rank ends with the
@@ -302,6 +335,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         cands.clear(); viewSets.clear();
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
+        liveIdx.clear();
+        for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
+        if (useSide) { sideJobs.clear(); sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
         const int64_t recomputedBefore = st.recomputedSeeds;
 
         // the newest E result of seed i: instances / footprint / provenance
@@ -340,6 +376,37 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         auto eValidNow = [&](int64_t i) -> bool {
             if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV); }
             return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
+        };
+
+        // Every predicted mark of the job's view is true by now - or, inside a dry run, still predicted (simP).
+        auto sidePlausible = [&](const SideJob& sj, const RangeSet* simP) -> bool {
+            if (sj.set < 0) return true;
+            for (auto& q : viewSets[(size_t)sj.set].r) if (!com.allUsed(q.first, q.second) && !(simP && simP->covers(q.first, q.second))) return false;
+            return true;
+        };
+        // The commit needs the E / F of seed i now and a job for it is in flight: its result is taken (waiting for that one job)
+        // if its view came true - at this point every commit the view predicted has either happened or will never happen -,
+        // otherwise the job is dropped. true: a new candidate result is in place (validate it like any other).
+        auto takeSide = [&](int64_t i, bool isF) -> bool {
+            const int32_t ref = (isF ? sideF : sideE)[(size_t)i];
+            if (ref < 0) return false;
+            if (sideJobs[(size_t)ref].state != 0 || !sidePlausible(sideJobs[(size_t)ref], nullptr)) { dropSide(ref); return false; }
+            const SideJob sj = sideJobs[(size_t)ref];
+            sInst.clear(); sFp.clear();
+            const auto tp = std::chrono::steady_clock::now();
+            const int r = proc.sidePoll(sj.lane, sj.k, true, sInst, sFp);
+            st.processMs += msSince(tp);
+            sideJobs[(size_t)ref].state = 1;
+            (isF ? sideF : sideE)[(size_t)i] = -1;
+            laneDone(sj.lane);
+            if (r != 1) { st.sideFailed++; return false; }
+            st.sideTaken++;
+            int32_t& slot = isF ? fIdx[(size_t)i] : eIdx[(size_t)i];
+            if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
+            Cand& c = cands[(size_t)slot];
+            c.epoch = sj.epoch; c.view = sj.set; c.checkedTo = (uint32_t)sj.epoch; c.viewOk = true;
+            c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{}; c.pathV.clear();
+            return true;
         };
 
         // ---- dry run + job launch ---------------------------------------------------------------------------------------
@@ -400,20 +467,34 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 if (!simP.empty()) for (size_t k = 0; k < nf; k++) if (simP.hitsOutside(f[k].lo, f[k].hi, P)) return false;
                 return true;
             };
+            // a job of an earlier plan is in flight for this result and its view still fits what is true or predicted now: no new job
+            auto onItsWay = [&](int64_t j, bool isF) -> bool {
+                if (!useSide) return false;
+                const int32_t ref = (isF ? sideF : sideE)[(size_t)j];
+                if (ref < 0) return false;
+                if (sideJobs[(size_t)ref].state == 0 && sidePlausible(sideJobs[(size_t)ref], &simP)) return true;
+                dropSide(ref);
+                return false;
+            };
             const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
             std::vector<lcb_instance> guess;
+            size_t lv = liveFrom((midPhase ? stopAt : ph0));          // cursor into liveIdx (seeds that are not in it need nothing, commit nothing)
             for (int64_t ph = ph0; ph < lim; ph += phase) {
                 if (jobs.size() >= maxJobs) break;      // enough speculation for one launch (the first job is always there)
                 const int64_t n = std::min<int64_t>(phase, nRound - ph);
                 const bool first = ph == ph0;
+                while (lv < liveIdx.size() && liveIdx[lv] < (first && midPhase ? stopAt : ph)) lv++;
+                size_t lvEnd = lv;
+                while (lvEnd < liveIdx.size() && liveIdx[lvEnd] < ph + n) lvEnd++;
                 if (!(first && midPhase)) {
                     // phase start: which seeds will lack an exact E?
                     bool any = false;
-                    for (int64_t j = ph; j < ph + n; j++) {
+                    for (size_t q = lv; q < lvEnd; q++) {
+                        const int64_t j = liveIdx[q];
                         bool ok;
                         if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size(), &c.pathV); }
                         else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
-                        if (!ok) {
+                        if (!ok && !onItsWay(j, false)) {
                             if (!any) { currentView(); any = true; }
                             jobs.push_back(Job{j, false, (uint32_t)nViews, curSet});
                         }
@@ -421,7 +502,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     if (!first) { for (uint32_t c : simChrList) simChr[c] = 0; simChrList.clear(); }
                 }
                 // ordered commit, simulated with the newest E of each seed as the prediction of its E
-                for (int64_t j = (first && midPhase) ? stopAt : ph; j < ph + n; j++) {
+                for (size_t q = lv; q < lvEnd; q++) {
+                    const int64_t j = liveIdx[q];
                     const lcb_instance* r; uint64_t cnt;
                     eInst(j, r, cnt);
                     if (cnt <= 1) continue;
@@ -434,8 +516,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                         if (have && c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
                     }
                     if (!have) {
-                        currentView();
-                        jobs.push_back(Job{j, true, (uint32_t)nViews, curSet});
+                        if (!onItsWay(j, true)) {
+                            currentView();
+                            jobs.push_back(Job{j, true, (uint32_t)nViews, curSet});
+                        }
                         if (predictF >= 3 && fIdx[(size_t)j] >= 0) {
                             // a stale F (computed against a view that did not come true) is the best guess at hand
                             const Cand& c = cands[(size_t)fIdx[(size_t)j]];
@@ -454,6 +538,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 }
                 for (uint32_t c : simChrList) simChr[c] = 0;
                 simChrList.clear();
+                lv = lvEnd;
             }
             // ---- launch
             if (jobs.empty()) throw LcbError("engine: commit stopped but the dry run found nothing to compute");
@@ -468,18 +553,48 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     std::cerr << "   job " << k << " seed " << (pos + jobs[k].seed) << (jobs[k].isF ? " F" : " E") << " eLongest " << longest << " eCnt " << cnt << " staleF " << (fIdx[(size_t)jobs[k].seed] >= 0 ? (int64_t)fl : -1) << " view " << jobs[k].devView << "\n";
                 }
             st.planMs += msSince(tPlan);
-            const auto tProc = std::chrono::steady_clock::now();
-            if (nViews > 0) { proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size()); st.viewsBuilt += nViews; }
-            (void)tProc;
+            // The results the commit cannot go on without: the F of the stopping seed, or every missing E of the phase that is about to
+            // start. They are the first jobs of the plan and run against the live state.
+            size_t nCrit = 1;
+            if (!midPhase) while (nCrit < jobs.size() && !jobs[nCrit].isF && jobs[nCrit].seed < ph0 + phase && jobs[nCrit].devView == 0) nCrit++;
+            if ((midPhase && jobs[0].seed != stopAt) || jobs[0].devView != 0) throw LcbError("engine: the first job of a plan is not the stop's own");
+            // Side lanes: everything else runs in the background (the oldest batch gives way if no lane is free).
+            int lane = -1;
+            if (useSide && jobs.size() > nCrit) {
+                const auto tp = std::chrono::steady_clock::now();
+                lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
+                if (lane < 0 && !laneOrder.empty()) {
+                    const int old = laneOrder.front();
+                    for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].lane == old && sideJobs[q].state == 0) dropSide((int32_t)q);
+                    lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
+                }
+                st.processMs += msSince(tp);
+            }
+            const size_t nSync = lane >= 0 ? nCrit : jobs.size();
+            if (lane < 0 && nViews > 0) proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size());
+            if (nViews > 0) st.viewsBuilt += nViews;
             // every rank plans the same jobs (same state, same results); the jobs of one launch are independent given their
             // views, so they are dealt to the ranks like a round's seeds and gathered the same way
-            processSharded(sub.data(), subView.data(), (int64_t)sub.size(), tmp, (uint64_t)(pos + stopAt));
+            processSharded(sub.data(), lane >= 0 ? nullptr : subView.data(), (int64_t)nSync, tmp, (uint64_t)(pos + stopAt));
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
             if (midPhase) st.conflictLaunches++;
-            if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views\n";
+            if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views" << (lane >= 0 ? ", all but the first on side lane " + std::to_string(lane) : std::string()) << "\n";
             epochMarks.emplace_back();              // marks from here on belong to the new epoch
             const int32_t epoch = (int32_t)epochMarks.size() - 1;
-            for (size_t k = 0; k < jobs.size(); k++) {
+            if (lane >= 0) {
+                st.sideBatches++; st.sideJobs += (int64_t)(jobs.size() - nCrit);
+                laneOrder.push_back(lane);
+                lanePending[(size_t)lane] = (int)(jobs.size() - nCrit);
+                for (size_t k = nCrit; k < jobs.size(); k++) {
+                    const Job& jb = jobs[k];
+                    if (jb.isF) st.conflictSeeds++;
+                    int32_t& ref = (jb.isF ? sideF : sideE)[(size_t)jb.seed];
+                    if (ref >= 0) dropSide(ref);     // (a job the dry run found unfit was dropped there already)
+                    ref = (int32_t)sideJobs.size();
+                    sideJobs.push_back(SideJob{jb.seed, jb.isF, jb.set, epoch, lane, (int64_t)(k - nCrit), 0});
+                }
+            }
+            for (size_t k = 0; k < nSync; k++) {
                 const Job& jb = jobs[k];
                 if (jb.isF) st.conflictSeeds++;
                 int32_t& slot = jb.isF ? fIdx[(size_t)jb.seed] : eIdx[(size_t)jb.seed];
@@ -497,10 +612,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         for (int64_t ph = 0; ph < nRound; ph += phase) {
             const int64_t n = std::min<int64_t>(phase, nRound - ph);
             // (a) exact phase-start results for every seed of the phase
+            const size_t lv0 = liveFrom(ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
             for (;;) {
                 bool all = true;
-                for (int64_t i = ph; i < ph + n && all; i++) {
-                    const bool ok = eValidNow(i);
+                for (size_t q = lv0; q < lv1 && all; q++) {
+                    const int64_t i = liveIdx[q];
+                    bool ok = eValidNow(i);
+                    if (!ok && useSide && takeSide(i, false)) ok = eValidNow(i);
                     if (debug && getenv("LCB_ENGINE_DEBUG_SEED") && pos + i == atoll(getenv("LCB_ENGINE_DEBUG_SEED"))) {
                         std::cerr << "   [seed " << (pos + i) << "] phase-start verdict " << ok << ", E from " << (eIdx[(size_t)i] >= 0 ? "a job" : "the round launch") << ", e0Checked " << e0Checked[(size_t)i] << ", footprint:";
                         const lcb_fp* f = eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].fp.data() : round.fp.data() + round.fpOff[i];
@@ -516,12 +634,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 planAndLaunch(ph, ph, false);
             }
             // (b) ordered commit (blocksfinder.h:372-414)
-            for (int64_t i = ph; i < ph + n; i++) {
-                if (cfg.progress && (pos + i) % portion == 0) std::cout << '.' << std::flush;
+            if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;
+            // the phase-start result of every seed is exact now: its events are the ones the reference's Process() call has
+            if (cfg.countEvents) for (int64_t i = ph; i < ph + n; i++) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
+            for (size_t q = lv0; q < lv1; q++) {
+                const int64_t i = liveIdx[q];
                 const lcb_instance* r; uint64_t cnt;
                 eInst(i, r, cnt);
-                // the phase-start result of seed i is exact now: its events are the ones the reference's Process() call has
-                if (cfg.countEvents) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
                 if (cnt <= 1) continue;                                                  // blocksfinder.h:375
                 if (!com.conflicts(r, cnt)) {
                     if (debug) {
@@ -538,6 +657,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                         Cand& c = cands[(size_t)fIdx[(size_t)i]];
                         if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV)) break;
                     }
+                    if (useSide && takeSide(i, true)) continue;      // a background result for it has arrived: validate that
                     planAndLaunch(ph, i, true);
                 }
                 const Cand& c = cands[(size_t)fIdx[(size_t)i]];
@@ -554,6 +674,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             }
             com.endPhase();
         }
+        if (useSide) for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].state == 0) dropSide((int32_t)q);   // speculation beyond the round is void
         pos += nRound;
         lastInvalid = (double)(st.recomputedSeeds - recomputedBefore) / (double)nRound;
         if (!fixedRound) {

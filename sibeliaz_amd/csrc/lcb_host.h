@@ -99,6 +99,75 @@ struct LcbProcessor {
     // seeds the processor works on at the same time: a dry run plans about this many jobs per launch (more only queue up)
     virtual int concurrency() const { return 16384; }
     virtual void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) { (void)nViews; (void)marks; (void)nMarks; }
+
+    // ---- asynchronous job batches ("side lanes"), optional. A stop of the ordered commit needs ONE result to go on (the first
+    // job of its plan, computed against the live state); the other jobs of the plan are speculation. A processor with side lanes
+    // runs that speculation in the background - sideBegin returns at once - while the engine computes the one result it waits for
+    // synchronously and goes on committing; a background result is taken (sidePoll) when the commit reaches its seed.
+    // The jobs read the live state while it is being marked: that is exact under the engine's validity rule, because every mark
+    // applied after sideBegin lies in an epoch the rule checks the job's footprint against (a bit read as 1 because of such a mark
+    // is in the true state at the job's turn; a bit read as 0 that has been marked since is inside the footprint).
+    virtual int sideLanes() const { return 0; }          // batches that can be in flight at once (0: no side lanes)
+    // Starts seed i against view[i] (0 = live state, v >= 1 = view v of the nViews predicted views given by marks; the views are
+    // private to the batch). Returns the lane (>= 0), or -1: no lane is free (or the batch does not fit one).
+    virtual int sideBegin(const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
+    {
+        (void)seeds; (void)view; (void)n; (void)nViews; (void)marks; (void)nMarks; return -1;
+    }
+    // Job k of the batch on `lane`: 0 = still running (only if !wait), 1 = done: instances and footprint appended to inst / fp,
+    // 2 = no result (the batch was told to stop, or the job needs a kernel variant the lane does not run).
+    virtual int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp)
+    {
+        (void)lane; (void)k; (void)wait; (void)inst; (void)fp; return 2;
+    }
+    // Nobody will ask for the batch's results any more: its jobs stop at their next step, the lane is free once they have.
+    virtual void sideRelease(int lane) { (void)lane; }
+};
+
+// Side lanes for processors that have none of their own (the test stand-ins: callback, wavefront emulator, oracle model): a
+// batch is computed on the spot with the processor's own buildViews + process and kept until it is released. `delay` > 0 makes a
+// job invisible to the first `delay` non-waiting polls, so that the engine's "not ready yet" paths run too.
+struct LcbEagerSideLanes {
+    struct Lane {
+        bool busy = false, computed = false;
+        std::vector<lcb_seed> seeds; std::vector<uint32_t> view; std::vector<LcbViewMark> marks; int nViews = 0;
+        std::vector<uint64_t> off, fpOff; std::vector<lcb_instance> inst; std::vector<lcb_fp> fp; std::vector<int> polls;
+    };
+    std::vector<Lane> lanes;
+    int delay = 0;
+    // late: a batch is computed when its first result is asked for, against the live state of THAT moment (plus its predicted
+    // marks) - the other extreme of what a background batch that reads the live state while it is being marked can see
+    bool late = false;
+    explicit LcbEagerSideLanes(int n = 0, int d = 0, bool l = false) : lanes((size_t)n), delay(d), late(l) {}
+    void compute(LcbProcessor& p, Lane& L)
+    {
+        if (L.nViews > 0) p.buildViews(L.nViews, L.marks.data(), (int64_t)L.marks.size());
+        p.process(L.seeds.data(), L.view.data(), (int64_t)L.seeds.size(), L.off, L.inst, L.fpOff, L.fp);
+        L.computed = true;
+    }
+    int begin(LcbProcessor& p, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
+    {
+        for (size_t l = 0; l < lanes.size(); l++) {
+            if (lanes[l].busy) continue;
+            Lane& L = lanes[l];
+            L.seeds.assign(seeds, seeds + n); L.view.assign(view, view + n); L.marks.assign(marks, marks + nMarks); L.nViews = nViews;
+            L.busy = true; L.computed = false; L.polls.assign((size_t)n, 0);
+            if (!late) compute(p, L);
+            return (int)l;
+        }
+        return -1;
+    }
+    int poll(LcbProcessor& p, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp)
+    {
+        Lane& L = lanes[(size_t)lane];
+        if (!L.busy) return 2;
+        if (!wait && L.polls[(size_t)k]++ < delay) return 0;
+        if (!L.computed) compute(p, L);
+        inst.insert(inst.end(), L.inst.begin() + L.off[(size_t)k], L.inst.begin() + L.off[(size_t)k + 1]);
+        fp.insert(fp.end(), L.fp.begin() + L.fpOff[(size_t)k], L.fp.begin() + L.fpOff[(size_t)k + 1]);
+        return 1;
+    }
+    void release(int lane) { lanes[(size_t)lane].busy = false; }
 };
 
 // All-gather of a fixed-size buffer across ranks: recv holds world * bytes. Returns 0 on success.
@@ -124,6 +193,7 @@ struct LcbEngineConfig {
                               // footprint or holds an occurrence of one of the path's vertices. Every `used` read of Process() is of one of
                               // these kinds, so the rule is exact; today any such mark voids every later job of the launch.
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
+    bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
 
 struct LcbEngineStats {
@@ -134,6 +204,10 @@ struct LcbEngineStats {
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     int64_t earlyRounds = 0;      // rounds whose launch ran while the previous round was being committed
+    int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)
+    int64_t sideTaken = 0;        // ... results taken when the commit reached their seed (view came true)
+    int64_t sideVoid = 0;         // ... jobs dropped because a mark of their view did not come true, or superseded by a newer plan
+    int64_t sideFailed = 0;       // ... jobs that ended without a result (stopped, or needed another kernel variant)
     double wallMs = 0;
     double processMs = 0, planMs = 0;   // wall time inside the processor (launches + result gathering) / inside the dry runs
     lcb_counters events{};              // countEvents: totals over the phase-start result of every seed + the re-processed result of every conflict

@@ -74,6 +74,7 @@ enum LcbStatus : uint32_t {
     LCB_ST_BEST_OVF = 4,   // result snapshot buffer full
     LCB_ST_ARENA_OVF = 5,  // batch result arena full
     LCB_ST_DIST_OVF = 6,   // path distance does not fit 32 bits (unsupported, > 2 Gbp paths)
+    LCB_ST_ABORTED = 7,    // an asynchronous job batch was told to stop (LcbWork::abort): no result
     LCB_ST_PENDING = 0xFFFFFFFFu,   // header written by the screening kernel for a live seed (the process kernel overwrites it)
 };
 
@@ -124,7 +125,7 @@ struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint32_t pad2;
 #endif
 };
-struct LcbSeedCtr { uint64_t c[8]; };   // lcb_counters order in stats mode, a cheap profile in the instrumented variant
+struct LcbSeedCtr { uint64_t c[16]; };  // [0..8): lcb_counters order in stats mode, a cheap profile in the instrumented variant; [8..16): vote sections (instrumented)
 
 struct LcbWork {               // per-workgroup global-memory workspace slots + the work queue of one launch
     uint8_t* base;
@@ -144,6 +145,7 @@ struct LcbWork {               // per-workgroup global-memory workspace slots + 
     unsigned long long fpBase;
     LcbSeedCtr* ctr;           // per-seed counters (stats / instrumented variants), or null
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
+    const uint32_t* abort;     // asynchronous job batches (device.hip, side lanes): when the word becomes non-zero the seeds give up at their next vote
 #if LCB_PATH_SIG
     int32_t* sigArena;         // path vertices of the seeds with a view (null: not wanted)
     unsigned long long* sigCursor;
@@ -327,8 +329,11 @@ struct LcbStateT {
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
     uint32_t* dbg;             // flight recorder of this workgroup (may be null)
+    const uint32_t* abort;     // stop flag of an asynchronous batch (null: none)
     uint32_t pfPush, pfVote, pfMaxProbe, pfMaxInst;   // cheap per-seed profile of the instrumented variant (wave-uniform)
     uint64_t pfTVote, pfTPush, pfTScore;              // 10 ns ticks spent in the vote / push / score+snapshot sections
+    uint64_t pfTWalk, pfTWaitB, pfTReduce, pfTScan;   // vote sections of wave 0 (10 ns ticks): own walks, wait for the other waves' walks, arg-max + clearing, voter scans
+    uint64_t pfVoters, pfChunks, pfTouchSum;          // voters / 64-step chunks walked by wave 0, sum of the touch-list lengths over the votes
     // per-lane event counters (stats mode)
     uint64_t cWalk, cOcc, cCompatCall, cCompatStep, cVote, cPush;
 };
@@ -590,7 +595,7 @@ struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 // the vote table - are checked afterwards, lane-parallel, once (lcb_vote_any_in_path). No hit: no walk can have met a path
 // vertex, the pass is what the reference computes. A hit: the table is cleared and the vote repeated with exact = true.
 // (Footprints of a discarded pass stay: a superset.)  Variants with the path set in LDS always walk exactly.
-template <bool STATS, class ST>
+template <bool STATS, bool PROF = false, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
                                      uint32_t waveId, uint32_t nWaves, bool exact)
 {
@@ -607,6 +612,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     auto nextVoter = [&](LcbVoter& v) -> bool {
         for (;;) {
             while (pend == 0) {
+                const uint64_t ts0 = PROF ? wall_clock64() : 0;
                 if (scanned) chunkBase += 64;
                 scanned = true;
                 if (chunkBase >= nTouch) return false;
@@ -626,6 +632,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                     }
                 }
                 pend = __ballot(is);
+                if (PROF) S.pfTScan += wall_clock64() - ts0;
             }
             const uint32_t b = (uint32_t)__ffsll((long long)pend) - 1u;
             pend &= pend - 1;
@@ -671,6 +678,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             const bool ahead = c > 0 || deep;
             const LcbWalk w = c == 0 ? wcur : ((c > 1 || deep) ? wahead : issue(cur, c));
             if (ahead) wahead = issue(cur, c + 1);
+            if (PROF) S.pfChunks++;
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
@@ -715,6 +723,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 break;
             }
         }
+        if (PROF) S.pfVoters++;
         have = haveNext; cur = nxt; wcur = wnxt;
     }
 }
@@ -802,7 +811,7 @@ __device__ inline void lcb_vote_reduce_slice(ST& S, bool forward, bool useGood, 
 
 // One pass of a vote over the voters of the touch list: walks, arg-max, clearing of the table. `hit`: the pass walked without
 // path stops and one of the vertices it touched is in the path (or the touched list is incomplete) - its result is void.
-template <bool STATS, int NW, class ST>
+template <bool STATS, int NW, bool PROF = false, class ST>
 __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank, bool exact, bool& ovfAny, bool& hit)
 {
     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
@@ -818,8 +827,12 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
-        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, NW, exact);
+        const uint64_t tw0 = PROF ? wall_clock64() : 0;
+        lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, nList, flank, 0, NW, exact);
+        const uint64_t tw1 = PROF ? wall_clock64() : 0;
         __syncthreads();                                           // B: all walks done
+        const uint64_t tw2 = PROF ? wall_clock64() : 0;
+        if (PROF) { S.pfTWalk += tw1 - tw0; S.pfTWaitB += tw2 - tw1; }
         nTouched = lcb_rfl(*S.vNClaimed);
         if (nTouched > claimCap) nTouched = claimCap;
         if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
@@ -843,8 +856,11 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
             LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
             lcb_vote_clear(S, 0, nTouched);
         }
+        if (PROF) S.pfTReduce += wall_clock64() - tw2;
     } else {
-        lcb_vote_walk<STATS>(S, forward, tryUsed, useGood, nList, flank, 0, 1, exact);
+        const uint64_t tw0 = PROF ? wall_clock64() : 0;
+        lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, nList, flank, 0, 1, exact);
+        if (PROF) S.pfTWalk += wall_clock64() - tw0;
         LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
         nTouched = lcb_rfl(*S.vNClaimed);
         if (nTouched > claimCap) nTouched = claimCap;
@@ -873,7 +889,8 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
     constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
     const uint64_t cWalk0 = S.cWalk;
     bool ovfAny = false, hit = false;
-    LcbBest b = lcb_vote_pass<STATS, NW>(S, forward, tryUsed, useGood, nList, flank, !DEFER, ovfAny, hit);
+    if (PROF) S.pfTouchSum += S.nTouch;
+    LcbBest b = lcb_vote_pass<STATS, NW, PROF>(S, forward, tryUsed, useGood, nList, flank, !DEFER, ovfAny, hit);
     if (DEFER && (hit || ovfAny)) {
         // a touched vertex is in the path (or the table overflowed, so that the touched list is incomplete - a pass with path stops
         // may touch fewer vertices): the vote as the reference walks it. After an overflow the table may hold stale keys.
@@ -884,7 +901,7 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
         }
         if (STATS) S.cWalk = cWalk0;
         if (PROF) S.pfMaxProbe++;             // (instrumented variant: number of repeated votes)
-        b = lcb_vote_pass<STATS, NW>(S, forward, tryUsed, useGood, nList, flank, true, ovfAny, hit);
+        b = lcb_vote_pass<STATS, NW, PROF>(S, forward, tryUsed, useGood, nList, flank, true, ovfAny, hit);
     }
     if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
     if (b.cnt == 0) return 0;
@@ -1309,6 +1326,8 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
     uint32_t oi = 0;
     LCB_MARK(S, 4, S.nRight); LCB_MARK(S, 5, S.nLeft); LCB_MARK(S, 6, 1);
     const uint64_t tv0 = PROF ? wall_clock64() : 0;
+    // an asynchronous batch nobody waits for any more gives up here (the word is read past the L1: another stream writes it)
+    if (S.abort && lcb_rfl(__hip_atomic_load(S.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) { S.status = LCB_ST_ABORTED; return false; }
     int32_t next = lcb_vote<STATS, PROF, NW>(S, FORWARD, false, oi);
     LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
     if (S.status) return false;
@@ -1545,13 +1564,14 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
     S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
+    S.abort = W.abort;
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
     S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;
-    S.nFp = 0;
+    S.pfTWalk = S.pfTWaitB = S.pfTReduce = S.pfTScan = 0; S.pfVoters = S.pfChunks = S.pfTouchSum = 0;
     LCB_WAVE_SYNC();
     if (NW > 1) {
         __syncthreads();           // the LDS tables and sArgs above are initialised
@@ -1596,6 +1616,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         S.nFp = 0;
         int64_t bestScore = 0;
         S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0;
+        S.pfTWalk = S.pfTWaitB = S.pfTReduce = S.pfTScan = 0; S.pfVoters = S.pfChunks = S.pfTouchSum = 0;
         const uint64_t tick0 = PROF ? wall_clock64() : 0;
         const LcbKSeed sd = sArgs.seeds[s];
         const int32_t vid = lcb_rfl(sd.vid), ch = lcb_rfl(sd.ch);
@@ -1660,18 +1681,28 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             c2 = (uint64_t)lcb_wave_sum((int64_t)S.cCompatCall); c3 = (uint64_t)lcb_wave_sum((int64_t)S.cCompatStep);
             c4 = (uint64_t)lcb_wave_sum((int64_t)S.cVote); c5 = (uint64_t)lcb_wave_sum((int64_t)S.cPush);
         }
+        // The header is what the host polls while the kernel is still running (asynchronous batches): everything the seed wrote
+        // - instances, footprints, the other header fields - is made visible system-wide before the status word is.
         if (S.lane == 0) {
             LcbSeedOut* o = sArgs.out + s;
             o->nInst = n;   // kept on ARENA_OVF so the host can track the allocator
-            o->status = S.status; o->bestScore = bestScore; o->arenaOff = off;
+            o->bestScore = bestScore; o->arenaOff = off;
             o->fpOff = fpo; o->nFp = nfp; o->poolInst = S.endInst;
 #if LCB_PATH_SIG
             o->sigOff = sgo; o->nSig = nsg; o->pad2 = 0;
 #endif
+        }
+        __threadfence_system();
+        if (S.lane == 0) {
+            LcbSeedOut* o = sArgs.out + s;
+            __hip_atomic_store(&o->status, (uint32_t)S.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }
-                else { k[0] = ticks; k[1] = S.pfPush; k[2] = S.pfVote; k[3] = S.pfMaxProbe; k[4] = S.pfMaxInst; k[5] = S.pfTVote; k[6] = S.pfTPush; k[7] = S.pfTScore; }
+                else {
+                    k[0] = ticks; k[1] = S.pfPush; k[2] = S.pfVote; k[3] = S.pfMaxProbe; k[4] = S.pfMaxInst; k[5] = S.pfTVote; k[6] = S.pfTPush; k[7] = S.pfTScore;
+                    k[8] = S.pfTWalk; k[9] = S.pfTWaitB; k[10] = S.pfTReduce; k[11] = S.pfTScan; k[12] = S.pfVoters; k[13] = S.pfChunks; k[14] = S.pfTouchSum; k[15] = 0;
+                }
             }
         }
         LCB_MARK(S, 2, 6);

@@ -328,6 +328,16 @@ struct EmuProcessor : LcbProcessor {
     }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
+    // side lanes (EMU_SIDE_LANES=n): a background batch is computed on the spot and handed out job by job, EMU_SIDE_DELAY polls late
+    // (EMU_SIDE_LATE=1: computed when first asked for, against the live state of that moment)
+    LcbEagerSideLanes side{getenv("EMU_SIDE_LANES") ? atoi(getenv("EMU_SIDE_LANES")) : 0, getenv("EMU_SIDE_DELAY") ? atoi(getenv("EMU_SIDE_DELAY")) : 0, getenv("EMU_SIDE_LATE") != nullptr};
+    int sideLanes() const override { return (int)side.lanes.size(); }
+    int sideBegin(const lcb_seed* sd, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks) override
+    {
+        return side.begin(*this, sd, view, n, nViews, marks, nMarks);
+    }
+    int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return side.poll(*this, lane, k, wait, inst, fp); }
+    void sideRelease(int lane) override { side.release(lane); }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { emu->buildViews(nViews, marks, nMarks); }
 };
 

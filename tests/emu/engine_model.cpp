@@ -142,8 +142,8 @@ struct OracleProc : LcbProcessor {
         launches.push_back(L);
         if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (int64_t i = 0; i < n; i++) fprintf(stderr, "   done %lld pushes %lld inst %zu pool %lld\n", (long long)i, (long long)pushes[(size_t)i], ri[(size_t)i].size(), (long long)pool[(size_t)i]);
         if (getenv("MODEL_LOG"))
-            fprintf(stderr, "launch %zu %s n=%lld live=%lld maxPush=%lld sumPush=%lld pool>1024: %lld (maxPush %lld) pool>256: %lld maxPool=%lld\n", launches.size(), L.jobs ? "jobs " : "round",
-                    (long long)L.n, (long long)L.live, (long long)L.maxPush, (long long)L.sumPush, (long long)L.nBig, (long long)L.maxPushBig, (long long)L.nWideOvf, (long long)L.maxPool);
+            fprintf(stderr, "launch %zu %s n=%lld first=%lld live=%lld maxPush=%lld sumPush=%lld pool>1024: %lld (maxPush %lld) pool>256: %lld maxPool=%lld\n", launches.size(), L.jobs ? "jobs " : "round",
+                    (long long)L.n, (long long)(n ? pushes[0] : 0), (long long)L.live, (long long)L.maxPush, (long long)L.sumPush, (long long)L.nBig, (long long)L.maxPushBig, (long long)L.nWideOvf, (long long)L.maxPool);
     }
     void mark(const uint64_t* r, int64_t n) override
     {

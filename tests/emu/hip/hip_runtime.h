@@ -47,7 +47,10 @@ uint64_t emu_collective(int kind, uint64_t value, int arg, const char* file, int
 #define __syncthreads() ((void)emu_collective(EMU_BARRIER, 0, 0, __FILE__, __LINE__))
 
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __HIP_MEMORY_SCOPE_AGENT 1
 template <class T_> static inline void __hip_atomic_store(T_* p, T_ v, int, int) { *p = v; }
+template <class T_> static inline T_ __hip_atomic_load(const T_* p, int, int) { return *p; }
+static inline void __threadfence_system() {}
 static inline uint64_t wall_clock64() { return 0; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
