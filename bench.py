@@ -345,6 +345,7 @@ def main():
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
                        "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]), "early_rounds": int(st["early_rounds"]),
+                       "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())),
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},

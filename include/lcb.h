@@ -94,6 +94,11 @@ typedef struct {
     lcb_counters events;        /* lcb_hooks.count_events: the reference-semantics event counts of the whole FindBlocks (phase-start
                                    Process() of every seed + the re-Process() of every commit conflict), else zero */
     int64_t early_rounds;       /* rounds whose speculative launch ran on the GPU while the host was committing the previous round */
+    int64_t side_batches;       /* asynchronous job batches (side lanes): a stop waits only for the results it cannot go on without */
+    int64_t side_jobs;          /* ... their jobs (also counted in recomputed_seeds) */
+    int64_t side_taken;         /* ... results taken when the commit reached their seed */
+    int64_t side_void;          /* ... jobs dropped: a mark of their view did not come true, superseded, or the round ended */
+    int64_t side_failed;        /* ... jobs that ended without a result (stopped, or needed another kernel variant) */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -139,6 +144,8 @@ typedef struct {
     uint32_t path_cap_max;   /* largest compact path set (a seed that needs more goes to the big variant); default 1 << 20 */
     uint32_t arena;          /* INITIAL capacity of the pinned result arena of a launch, in instances (and footprint intervals);
                                 default 1 << 22; enlarged x4 when a launch fills it (its unlucky seeds run again) */
+    uint32_t side_lanes;     /* asynchronous job batches that can be in flight beside the synchronous launches (own streams, buffers,
+                                workspace slots and predicted views each); default 4; 0xFFFFFFFF = none */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows
@@ -160,6 +167,12 @@ int lcb_device_set_stats_mode(lcb_device* d, int on);
  * capacity is then in offsets[n]). best_score and ctr may be NULL. */
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets,
                       lcb_instance* inst, uint64_t inst_cap, int64_t* best_score, lcb_counters* ctr);
+/* The same, also returning every seed's FOOTPRINT: intervals [lo, hi] of flat positions (pairs of uint32) that cover every position
+ * whose `used` bit the seed's computation read as 0 - what makes the engine's speculation exact (a result stays valid as long as
+ * no bit inside its footprint has been set since). fp_offsets has n+1 entries; interval j of seed i is fp[2*j], fp[2*j+1] for j in
+ * fp_offsets[i] .. fp_offsets[i+1]. On LCB_ERR for lack of room the needed capacities are in offsets[n] / fp_offsets[n]. */
+int lcb_process_seeds_fp(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
+                         uint64_t* fp_offsets, uint32_t* fp, uint64_t fp_cap);
 /* Measured HBM rate of this GPU: STREAM triad over three arrays of `bytes` each, GB/s (the roofline's measured peak). */
 int lcb_device_hbm_triad(lcb_device* d, uint64_t bytes, int reps, double* gb_per_s);
 /* hipEvent-timed duration (ms) and launch count of kernels since the last call (reset on read). */
@@ -220,6 +233,8 @@ typedef struct {
                                    on configs 2 and 3, so off by default) */
     int32_t relax_views;        /* 1 (experimental, needs a library built with -DLCB_PATH_SIG=1; an error otherwise): a predicted mark
                                    that did not come true voids a job's result only if the job can have read it */
+    int32_t sync_jobs;          /* 1: do not use the device's side lanes - every job of a stop's plan runs in one synchronous launch
+                                   (the round-2 engine; for A/B runs and tests) */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

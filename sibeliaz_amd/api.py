@@ -36,7 +36,8 @@ class Stats(C.Structure):
                 ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
-                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [("early_rounds", C.c_int64)]
+                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [("early_rounds", C.c_int64)] + [
+                    (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed")]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -51,16 +52,16 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("overlap", C.c_int32), ("relax_views", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("overlap", C.c_int32), ("relax_views", C.c_int32), ("sync_jobs", C.c_int32)]
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "overlap", "relax_views")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "overlap", "relax_views", "sync_jobs")
 
 
 class DeviceOpts(C.Structure):
     """lcb_device_opts: tuning knobs of a device, 0 = default."""
     _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
-                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena")]
+                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")]
 
 
 class Counters(C.Structure):
@@ -78,7 +79,7 @@ EXPORTS = [
     "lcb_last_error", "lcb_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
     "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
     "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
-    "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_device_kernel_time", "lcb_committer_create",
+    "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_process_seeds_fp", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
     "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
     "lcb_generate_output", "lcb_comm_unique_id", "lcb_comm_create", "lcb_comm_destroy", "lcb_find_blocks_comm", "lcb_find_blocks_gpus",
@@ -127,6 +128,7 @@ def load_library():
     L.lcb_device_set_used.argtypes = [vp, vp, i64]
     L.lcb_device_set_stats_mode.argtypes = [vp, C.c_int]
     L.lcb_process_seeds.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, C.POINTER(Counters)]
+    L.lcb_process_seeds_fp.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, vp, C.c_uint64]
     L.lcb_device_hbm_triad.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.lcb_device_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.lcb_committer_create.restype = vp
@@ -293,6 +295,24 @@ class Device:
                 continue
             raise _err(self.L)
         return offsets, inst[: int(offsets[n])], score, (ctr.as_dict() if counters else None)
+
+    def process_seeds_fp(self, seeds):
+        """process_seeds plus every seed's footprint -> (offsets[n+1], instances, fp_offsets[n+1], fp[m, 2] of flat positions (lo, hi))."""
+        s = np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        n = len(s)
+        offsets, fp_off = np.zeros(n + 1, dtype="<u8"), np.zeros(n + 1, dtype="<u8")
+        cap, fcap = max(1024, 64 * n), max(4096, 256 * n)
+        while True:
+            inst = np.zeros(cap, dtype=INSTANCE_DTYPE)
+            fp = np.zeros((fcap, 2), dtype="<u4")
+            rc = self.L.lcb_process_seeds_fp(self.h, s.ctypes.data, n, offsets.ctypes.data, inst.ctypes.data, cap, fp_off.ctypes.data, fp.ctypes.data, fcap)
+            if rc == 0:
+                break
+            if int(offsets[n]) > cap or int(fp_off[n]) > fcap:
+                cap, fcap = max(cap, int(offsets[n])), max(fcap, int(fp_off[n]))
+                continue
+            raise _err(self.L)
+        return offsets, inst[: int(offsets[n])], fp_off, fp[: int(fp_off[n])]
 
     def hbm_triad(self, nbytes=1 << 30, reps=5):
         """Measured HBM rate (STREAM triad, GB/s)."""

@@ -27,7 +27,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0; cfg.syncJobs = hooks->sync_jobs != 0;
     }
     return cfg;
 }
@@ -134,6 +134,25 @@ int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t*
     LCB_CATCH(LCB_ERR)
 }
 
+int lcb_process_seeds_fp(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
+                         uint64_t* fp_offsets, uint32_t* fp, uint64_t fp_cap)
+{
+    LCB_TRY
+    LCB_NEED(d && (seeds || n == 0) && offsets && fp_offsets && (inst || inst_cap == 0) && (fp || fp_cap == 0), "lcb_process_seeds_fp");
+    std::vector<uint64_t> off, fpOff;
+    std::vector<lcb_instance> res;
+    std::vector<lcb_fp> fps;
+    lcb_device_process_impl(d, seeds, n, off, res, nullptr, nullptr, &fpOff, &fps);
+    memcpy(offsets, off.data(), off.size() * sizeof(uint64_t));
+    memcpy(fp_offsets, fpOff.data(), fpOff.size() * sizeof(uint64_t));
+    if (res.size() > inst_cap || fps.size() > fp_cap) throw LcbError("lcb_process_seeds_fp: inst_cap / fp_cap too small (needed counts are in offsets[n] / fp_offsets[n])");
+    if (!res.empty()) memcpy(inst, res.data(), res.size() * sizeof(lcb_instance));
+    static_assert(sizeof(lcb_fp) == 8, "footprint intervals are pairs of uint32");
+    if (!fps.empty()) memcpy(fp, fps.data(), fps.size() * sizeof(lcb_fp));
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+
 lcb_committer* lcb_committer_create(const lcb_graph* g, const lcb_params* p)
 {
     LCB_TRY
@@ -206,7 +225,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0; cfg.syncJobs = hooks->sync_jobs != 0;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -222,6 +241,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
             stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
+            stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));

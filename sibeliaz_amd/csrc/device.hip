@@ -17,6 +17,8 @@
 
 #include <time.h>
 
+#include <atomic>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -93,33 +95,42 @@ __global__ __launch_bounds__(256) void lcb_mark_kernel(uint32_t* used, const Lcb
     }
 }
 
-// Predicted views are copy-on-write over 4-KB pages of the live bitmap: one workgroup builds one private page — the live
-// page plus the predicted marks of its view that fall into it — and points the view's page table at it. Only pages that a
-// predicted mark touches exist; everything else reads through to the live state (lcb_uword, lcb_kernel.h).
+// Predicted views are copy-on-write over 4-KB pages of the live bitmap. The views of a launch are nested (view v = view v-1 + the
+// marks that first appear in v), so a page has one private VERSION per view that adds marks to it, and a view uses the newest version
+// not younger than itself: one workgroup builds the chain of versions of one page - the first from the live page, each later one
+// from its predecessor - and points the page-table entries of the views each version serves at it. Pages no predicted mark touches
+// have no version: they read through to the live state (lcb_uword, lcb_kernel.h). (Round 2 copied a page once per VIEW that sees it
+// changed: with a few hundred views of dense marks that was quadratic - 4.8 M page copies and a 2-GB pool per config-3 pass.)
 static_assert(LCB_PAGE_SHIFT == 10u, "lcb_build_view_pages_kernel copies one page as 256 threads x 16 bytes");
-struct LcbViewPage { uint32_t view, page, poolPage, pieceBegin, pieceEnd; };   // pieces [pieceBegin, pieceEnd) of the launch's piece list
-struct LcbViewPiece { uint32_t lo, hi; };                                      // bit range inside the page, [lo, hi)
-__global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* live, uint32_t liveWords, uint32_t* viewTab, uint32_t nPages,
-                                                                   const LcbViewPage* entries, const LcbViewPiece* pieces)
+struct LcbViewVersion { uint32_t view, nextView, poolPage, pieceBegin, pieceEnd; };   // serves the views [view, nextView); its new pieces [pieceBegin, pieceEnd)
+struct LcbViewPage { uint32_t page, verBegin, verEnd; };                              // versions [verBegin, verEnd) of the launch's version list, ascending in view
+struct LcbViewPiece { uint32_t lo, hi; };                                             // bit range inside the page, [lo, hi)
+__global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* live, uint32_t poolWords, uint32_t* viewTab, uint32_t nPages,
+                                                                   const LcbViewPage* pages, const LcbViewVersion* versions, const LcbViewPiece* pieces)
 {
-    const LcbViewPage e = entries[blockIdx.x];
-    const uint4* src = (const uint4*)(live + ((size_t)e.page << LCB_PAGE_SHIFT));
-    uint32_t* dstW = live + liveWords + ((size_t)e.poolPage << LCB_PAGE_SHIFT);      // the pool lies behind the live bitmap
-    ((uint4*)dstW)[threadIdx.x] = src[threadIdx.x];            // 256 threads x 16 B = one page
-    __syncthreads();
-    for (uint32_t q = e.pieceBegin; q < e.pieceEnd; q++) {
-        const uint32_t lo = pieces[q].lo, hi = pieces[q].hi;   // hi > lo
-        const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
-        for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 256) {
-            uint32_t m = 0xFFFFFFFFu;
-            if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
-            if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
-            dstW[w] |= m;                                       // pieces of one entry are applied one after the other
-        }
+    const LcbViewPage pg = pages[blockIdx.x];
+    const uint4* src = (const uint4*)(live + ((size_t)pg.page << LCB_PAGE_SHIFT));
+    for (uint32_t v = pg.verBegin; v < pg.verEnd; v++) {
+        const LcbViewVersion e = versions[v];
+        uint32_t* dstW = live + poolWords + ((size_t)e.poolPage << LCB_PAGE_SHIFT);      // the pool lies behind the live bitmap (poolWords: where it starts)
+        ((uint4*)dstW)[threadIdx.x] = src[threadIdx.x];            // 256 threads x 16 B = one page
         __syncthreads();
+        for (uint32_t q = e.pieceBegin; q < e.pieceEnd; q++) {
+            const uint32_t lo = pieces[q].lo, hi = pieces[q].hi;   // hi > lo
+            const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+            for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 256) {
+                uint32_t m = 0xFFFFFFFFu;
+                if (w == w0) m &= 0xFFFFFFFFu << (lo & 31);
+                if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+                dstW[w] |= m;                                       // pieces of one version are applied one after the other
+            }
+            __syncthreads();
+        }
+        // word offset from the live page to this copy (lcb_uword adds it to the word index), for every view the version serves
+        const uint32_t off = poolWords + (e.poolPage << LCB_PAGE_SHIFT) - (pg.page << LCB_PAGE_SHIFT);
+        for (uint32_t t = e.view + threadIdx.x; t < e.nextView; t += 256) viewTab[(size_t)t * nPages + pg.page] = off;
+        src = (const uint4*)dstW;                                   // the next version of the page builds on this one
     }
-    // word offset from the live page to this copy (lcb_uword adds it to the word index)
-    if (threadIdx.x == 0) viewTab[(size_t)e.view * nPages + e.page] = liveWords + (e.poolPage << LCB_PAGE_SHIFT) - (e.page << LCB_PAGE_SHIFT);
 }
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
@@ -150,6 +161,34 @@ const char* modeName(int m) { return m == 3 ? "huge" : (m == 2 ? "big" : (m == 1
 
 }  // namespace
 
+// The predicted views of one launch: a page table per view and a pool of private pages behind the live bitmap.
+struct ViewSpace {
+    uint32_t* tab = nullptr;                     // [(maxViews + 1) * nPages]: word offset from a live page to the view's copy (0 = shared)
+    int lastViews = 0;                           // views whose tables hold entries from the previous build
+    uint32_t poolBasePage = 0;                   // first page of the pool, counted from the end of the live bitmap
+    uint32_t poolPages = 0;                      // its capacity
+    LcbViewPage* dEntries = nullptr; LcbViewVersion* dVersions = nullptr; LcbViewPiece* dPieces = nullptr;
+    size_t entryCap = 0, versionCap = 0, pieceCap = 0;
+};
+
+// An asynchronous job batch (LcbProcessor::sideBegin): its own streams, pinned result buffers, workspace slots and views, so that it
+// runs beside the synchronous launches of the commit. Wide and big kernels only (a job that needs another variant gets no result).
+struct SideLane {
+    hipStream_t sw = nullptr, sb = nullptr;      // the wide and the big kernel of a batch run side by side
+    hipEvent_t w0 = nullptr, w1 = nullptr, b0 = nullptr, b1 = nullptr;
+    LcbKSeed* hSeeds = nullptr; LcbSeedOut* hOut = nullptr; uint4* hArena = nullptr; uint2* hFp = nullptr;
+    uint32_t* hList = nullptr;                   // pinned: ticket -> job index, [cap] for the wide kernel then [cap] for the big one
+    uint32_t* hCtl = nullptr;                    // pinned staging of the control words
+    uint32_t* dCtl = nullptr;                    // device: [0] wide tickets [1] big tickets [2..3] arena [4..5] footprints [6] wide jobs [7] big jobs [8] stop flag
+    uint32_t cap = 0;
+    unsigned long long arenaCap = 0;
+    ViewSpace views;
+    WorkSet wide, big;
+    bool busy = false, released = false, ranW = false, ranB = false;
+    int64_t n = 0;
+    std::vector<lcb_seed> seeds;
+};
+
 struct lcb_device_impl {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -164,12 +203,12 @@ struct lcb_device_impl {
     size_t usedWords = 0;                        // its words (a multiple of the page size)
     uint32_t nPages = 0;
     int maxViews = 0;                            // predicted views (page tables) available per launch
-    uint32_t* dViewTab = nullptr;                // [(maxViews + 1) * nPages]: word offset from a live page to the view's copy (0 = shared)
-    uint32_t poolPages = 0;                      // private pages of the predicted views of the current launch, behind the live bitmap in dUsed
-    int lastViews = 0;                           // views whose tables hold entries from the previous build
+    ViewSpace views;                             // ... of the synchronous launches (its pool lies behind the lanes' pools and grows on demand)
+    std::vector<SideLane> lanes;                 // asynchronous job batches
+    hipStream_t ctlStream = nullptr;             // stop flags of the lanes are written from here
+    uint32_t lanePoolPages = 0;                  // private pages per lane (fixed: the live bitmap cannot move while a lane is running)
+    int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0;
     struct lcb_async_call* async = nullptr;      // the call begun with processBegin and not yet ended
-    LcbViewPage* dEntries = nullptr; LcbViewPiece* dPieces = nullptr;
-    size_t entryCap = 0, pieceCap = 0;
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
     uint32_t* hLive = nullptr;                   // ... copied to the host after the launch, [batchCap + 1]: the last word is their number
@@ -274,6 +313,7 @@ struct lcb_device_impl {
         W.ctr = (stats || prof) ? hCtr : nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
+        W.abort = nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
         if (watchdogS > 0 || screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // unfinished seeds can be named (and a header nobody wrote is noticed)
@@ -418,12 +458,15 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->nPages = (uint32_t)(d->usedWords >> LCB_PAGE_SHIFT);
         // predicted `used` views for the engine's dry-run launches: a page table per view, private pages from a pool that grows on demand
         d->maxViews = (int)o.max_views;
-        d->poolPages = 4096;
-        HIP_CHECK(hipMalloc((void**)&d->dUsed, (d->usedWords + (size_t)d->poolPages * pageWords) * 4));
+        const uint32_t nLanes = o.side_lanes == 0xFFFFFFFFu ? 0u : (o.side_lanes ? o.side_lanes : 4u);
+        d->lanePoolPages = nLanes ? 32768u : 0u;
+        d->views.poolBasePage = nLanes * d->lanePoolPages;
+        d->views.poolPages = 4096;
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, (d->usedWords + ((size_t)d->views.poolBasePage + d->views.poolPages) * pageWords) * 4));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
-        HIP_CHECK(hipMalloc((void**)&d->dViewTab, (size_t)(d->maxViews + 1) * d->nPages * 4));
-        HIP_CHECK(hipMemset(d->dViewTab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
-        d->T.used = d->dUsed; d->T.viewTab = d->dViewTab; d->T.nPages = d->nPages;
+        HIP_CHECK(hipMalloc((void**)&d->views.tab, (size_t)(d->maxViews + 1) * d->nPages * 4));
+        HIP_CHECK(hipMemset(d->views.tab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
+        d->T.used = d->dUsed; d->T.viewTab = d->views.tab; d->T.nPages = d->nPages;
         d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
@@ -478,6 +521,32 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         }
         d->rangeCap = 65536;
         HIP_CHECK(hipHostMalloc((void**)&d->hRanges, (size_t)d->rangeCap * sizeof(LcbMarkRange), hipHostMallocDefault));
+        // side lanes: asynchronous job batches beside the synchronous launches (engine.cpp)
+        HIP_CHECK(hipStreamCreateWithFlags(&d->ctlStream, hipStreamNonBlocking));
+        d->lanes.resize(nLanes);
+        for (uint32_t l = 0; l < nLanes; l++) {
+            SideLane& L = d->lanes[l];
+            HIP_CHECK(hipStreamCreateWithFlags(&L.sw, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&L.sb, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&L.w0, &L.w1, &L.b0, &L.b1}) HIP_CHECK(hipEventCreate(e));
+            L.cap = 2048; L.arenaCap = 1ull << 20;
+            // the host polls these while the kernels run: fine-grained (coherent) pinned memory
+            HIP_CHECK(hipHostMalloc((void**)&L.hSeeds, (size_t)L.cap * sizeof(LcbKSeed), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hOut, (size_t)L.cap * sizeof(LcbSeedOut), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hArena, (size_t)L.arenaCap * sizeof(uint4), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hFp, (size_t)L.arenaCap * sizeof(uint2), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hList, (size_t)2 * L.cap * sizeof(uint32_t), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hCtl, 64, hipHostMallocCoherent));
+            HIP_CHECK(hipMalloc((void**)&L.dCtl, 64));
+            HIP_CHECK(hipMemset(L.dCtl, 0, 64));
+            HIP_CHECK(hipMalloc((void**)&L.views.tab, (size_t)(d->maxViews + 1) * d->nPages * 4));
+            HIP_CHECK(hipMemset(L.views.tab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
+            L.views.poolBasePage = l * d->lanePoolPages; L.views.poolPages = d->lanePoolPages;
+            L.wide = d->ws[1]; L.wide.base = nullptr; L.wide.nSlots = std::max(1u, std::min(o.wide_slots, nCu / 2));
+            d->allocWork(L.wide);
+            L.big = d->ws[2]; L.big.base = nullptr; L.big.nSlots = std::max(1u, std::min(o.big_slots, (nCu * 3) / 8));
+            d->allocWork(L.big);
+        }
     } catch (...) {
         lcb_device_destroy_impl(handle);
         throw;
@@ -486,6 +555,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
 }
 
 static void lcb_device_drop_async(lcb_device_impl* d);
+static void lcb_device_drain_lanes(lcb_device_impl* d);
 
 void lcb_device_destroy_impl(lcb_device* h)
 {
@@ -493,10 +563,12 @@ void lcb_device_destroy_impl(lcb_device* h)
     lcb_device_impl* d = h->impl;
     if (d) {
         lcb_device_drop_async(d);
+        lcb_device_drain_lanes(d);
         if (getenv("LCB_VERBOSE")) {
+            fprintf(stderr, "lcb device %d: side lanes %zu: %lld batches, %lld jobs (%lld plans found no free lane)\n", d->ordinal, d->lanes.size(), (long long)d->sideBatches, (long long)d->sideJobs, (long long)d->sideNoLane);
             fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
-            fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->poolPages);
+            fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->views.poolPages);
             fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
             fprintf(stderr, "   result arena: %llu instances (enlarged %d times)\n", d->arenaCap, d->arenaGrown);
             fprintf(stderr, "   seeds that joined a call's big launch instead of a wide launch in front of it: %lld\n", (long long)d->joinedBig);
@@ -508,9 +580,17 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         for (void* p : d->owned) (void)hipFree(p);
         if (d->dUsed) (void)hipFree(d->dUsed);
-        if (d->dViewTab) (void)hipFree(d->dViewTab);
-        if (d->dEntries) (void)hipFree(d->dEntries);
-        if (d->dPieces) (void)hipFree(d->dPieces);
+        for (SideLane& L : d->lanes) {
+            for (hipStream_t q : {L.sw, L.sb}) if (q) (void)hipStreamDestroy(q);
+            for (hipEvent_t e : {L.w0, L.w1, L.b0, L.b1}) if (e) (void)hipEventDestroy(e);
+            for (void* q : {(void*)L.hSeeds, (void*)L.hOut, (void*)L.hArena, (void*)L.hFp, (void*)L.hList, (void*)L.hCtl}) if (q) (void)hipHostFree(q);
+            for (void* q : {(void*)L.dCtl, (void*)L.views.tab, (void*)L.views.dEntries, (void*)L.views.dVersions, (void*)L.views.dPieces, (void*)L.wide.base, (void*)L.big.base}) if (q) (void)hipFree(q);
+        }
+        if (d->ctlStream) (void)hipStreamDestroy(d->ctlStream);
+        if (d->views.tab) (void)hipFree(d->views.tab);
+        if (d->views.dEntries) (void)hipFree(d->views.dEntries);
+        if (d->views.dPieces) (void)hipFree(d->views.dPieces);
+        if (d->views.dVersions) (void)hipFree(d->views.dVersions);
         if (d->dCursor) (void)hipFree(d->dCursor);
         if (d->dLive) (void)hipFree(d->dLive);
         if (d->hLive) (void)hipHostFree(d->hLive);
@@ -541,7 +621,8 @@ void lcb_device_reset_used_impl(lcb_device* h)
 {
     lcb_device_impl* d = h->impl;
     d->use();
-    if (d->lastViews) { HIP_CHECK(hipMemsetAsync(d->dViewTab + d->nPages, 0, (size_t)d->lastViews * d->nPages * 4, d->stream)); d->lastViews = 0; }
+    lcb_device_drain_lanes(d);
+    if (d->views.lastViews) { HIP_CHECK(hipMemsetAsync(d->views.tab + d->nPages, 0, (size_t)d->views.lastViews * d->nPages * 4, d->stream)); d->views.lastViews = 0; }
     d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
     d->recentBigFrac = 0;
     std::fill(d->hintBits.begin(), d->hintBits.end(), 0ull);
@@ -574,15 +655,14 @@ void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
 }
 
 // Predicted views 1..nViews = live state + the marks with firstView <= v (engine.cpp): views are nested, so a page that a
-// mark of view v touches is private in the views v..nViews, each with the marks up to its own index.
-void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* marks, int64_t nMarks)
+// mark of view v touches is private in the views v..nViews, each with the marks up to its own index. Builds them into the view
+// space V on `stream` (returns after the build kernel has finished). false: the private pages do not fit a pool that cannot grow.
+static bool lcb_build_views_into(lcb_device_impl* d, ViewSpace& V, hipStream_t stream, bool growable, int nViews, const LcbViewMark* marks, int64_t nMarks)
 {
-    lcb_device_impl* d = h->impl;
-    d->use();
     if (nViews < 0 || nViews > d->maxViews) throw LcbError("more predicted views requested than the device holds");
-    if (d->lastViews) HIP_CHECK(hipMemsetAsync(d->dViewTab + d->nPages, 0, (size_t)d->lastViews * d->nPages * 4, d->stream));
-    d->lastViews = nViews;
-    if (nViews == 0 || nMarks == 0) return;
+    if (V.lastViews) HIP_CHECK(hipMemsetAsync(V.tab + d->nPages, 0, (size_t)V.lastViews * d->nPages * 4, stream));
+    V.lastViews = nViews;
+    if (nViews == 0 || nMarks == 0) return true;
     const uint64_t P = d->g->nPos();
     const uint32_t pageBits = 32u << LCB_PAGE_SHIFT;
     struct Piece { uint32_t page, firstView, lo, hi; };
@@ -599,38 +679,57 @@ void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* m
     std::sort(pc.begin(), pc.end(), [](const Piece& x, const Piece& y) { return x.page != y.page ? x.page < y.page : x.firstView < y.firstView; });
     std::vector<LcbViewPiece> pieces(pc.size());
     for (size_t i = 0; i < pc.size(); i++) pieces[i] = LcbViewPiece{pc[i].lo, pc[i].hi};
-    std::vector<LcbViewPage> entries;
+    std::vector<LcbViewPage> entries;                       // one per page that a predicted mark touches
+    std::vector<LcbViewVersion> versions;                   // one per (page, view that adds marks to it)
     for (size_t i = 0; i < pc.size();) {
         size_t j = i;
         while (j < pc.size() && pc[j].page == pc[i].page) j++;
-        size_t upTo = i;                                    // pieces [i, upTo) have firstView <= v
-        for (uint32_t v = pc[i].firstView; v <= (uint32_t)nViews; v++) {
-            while (upTo < j && pc[upTo].firstView <= v) upTo++;
-            entries.push_back(LcbViewPage{v, pc[i].page, (uint32_t)entries.size(), (uint32_t)i, (uint32_t)upTo});
+        const uint32_t verBegin = (uint32_t)versions.size();
+        for (size_t a = i; a < j;) {
+            size_t b = a;
+            while (b < j && pc[b].firstView == pc[a].firstView) b++;
+            if (!versions.empty() && versions.size() > verBegin) versions.back().nextView = pc[a].firstView;
+            versions.push_back(LcbViewVersion{pc[a].firstView, (uint32_t)nViews + 1u, (uint32_t)versions.size(), (uint32_t)a, (uint32_t)b});
+            a = b;
         }
+        entries.push_back(LcbViewPage{pc[i].page, verBegin, (uint32_t)versions.size()});
         i = j;
     }
-    if (entries.size() > d->poolPages) {
-        // the pool lies behind the live bitmap in one allocation (a table entry is a word offset): grow = move the live state
+    if (versions.size() > V.poolPages) {
+        if (!growable) { V.lastViews = 0; return false; }
+        // the pools lie behind the live bitmap in one allocation (a table entry is a word offset): grow = move the live state,
+        // which nobody may be reading
+        lcb_device_drain_lanes(d);
         HIP_CHECK(hipStreamSynchronize(d->stream));
-        uint32_t np = d->poolPages;
-        while (np < entries.size()) np *= 2;
-        if (d->usedWords + ((uint64_t)np << LCB_PAGE_SHIFT) >= (1ull << 32)) throw LcbError("predicted views need more private pages than a 32-bit word offset reaches");
+        uint32_t np = V.poolPages;
+        while (np < versions.size()) np *= 2;
+        if (d->usedWords + (((uint64_t)V.poolBasePage + np) << LCB_PAGE_SHIFT) >= (1ull << 32)) throw LcbError("predicted views need more private pages than a 32-bit word offset reaches");
         uint32_t* nu = nullptr;
-        HIP_CHECK(hipMalloc((void**)&nu, (d->usedWords + ((size_t)np << LCB_PAGE_SHIFT)) * 4));
+        HIP_CHECK(hipMalloc((void**)&nu, (d->usedWords + (((size_t)V.poolBasePage + np) << LCB_PAGE_SHIFT)) * 4));
         HIP_CHECK(hipMemcpy(nu, d->dUsed, d->usedWords * 4, hipMemcpyDeviceToDevice));
         HIP_CHECK(hipFree(d->dUsed));
-        d->dUsed = nu; d->poolPages = np; d->T.used = nu;
+        d->dUsed = nu; V.poolPages = np; d->T.used = nu;
     }
-    if (entries.size() > d->entryCap) { if (d->dEntries) HIP_CHECK(hipFree(d->dEntries)); d->entryCap = entries.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dEntries, d->entryCap * sizeof(LcbViewPage))); }
-    if (pieces.size() > d->pieceCap) { if (d->dPieces) HIP_CHECK(hipFree(d->dPieces)); d->pieceCap = pieces.size() * 2; HIP_CHECK(hipMalloc((void**)&d->dPieces, d->pieceCap * sizeof(LcbViewPiece))); }
-    HIP_CHECK(hipMemcpyAsync(d->dEntries, entries.data(), entries.size() * sizeof(LcbViewPage), hipMemcpyHostToDevice, d->stream));
-    HIP_CHECK(hipMemcpyAsync(d->dPieces, pieces.data(), pieces.size() * sizeof(LcbViewPiece), hipMemcpyHostToDevice, d->stream));
-    hipLaunchKernelGGL(lcb_build_view_pages_kernel, dim3((uint32_t)entries.size()), dim3(256), 0, d->stream, d->dUsed, (uint32_t)d->usedWords, d->dViewTab, d->nPages,
-                       d->dEntries, d->dPieces);
+    if (entries.size() > V.entryCap) { if (V.dEntries) HIP_CHECK(hipFree(V.dEntries)); V.entryCap = entries.size() * 2; HIP_CHECK(hipMalloc((void**)&V.dEntries, V.entryCap * sizeof(LcbViewPage))); }
+    if (versions.size() > V.versionCap) { if (V.dVersions) HIP_CHECK(hipFree(V.dVersions)); V.versionCap = versions.size() * 2; HIP_CHECK(hipMalloc((void**)&V.dVersions, V.versionCap * sizeof(LcbViewVersion))); }
+    if (pieces.size() > V.pieceCap) { if (V.dPieces) HIP_CHECK(hipFree(V.dPieces)); V.pieceCap = pieces.size() * 2; HIP_CHECK(hipMalloc((void**)&V.dPieces, V.pieceCap * sizeof(LcbViewPiece))); }
+    HIP_CHECK(hipMemcpyAsync(V.dEntries, entries.data(), entries.size() * sizeof(LcbViewPage), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(V.dVersions, versions.data(), versions.size() * sizeof(LcbViewVersion), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(V.dPieces, pieces.data(), pieces.size() * sizeof(LcbViewPiece), hipMemcpyHostToDevice, stream));
+    // (the private pages of this view space start poolBasePage pages behind the live bitmap)
+    hipLaunchKernelGGL(lcb_build_view_pages_kernel, dim3((uint32_t)entries.size()), dim3(256), 0, stream, d->dUsed, (uint32_t)(d->usedWords + ((size_t)V.poolBasePage << LCB_PAGE_SHIFT)), V.tab, d->nPages,
+                       V.dEntries, V.dVersions, V.dPieces);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(d->stream));             // the host vectors above are the copy sources
-    d->viewPagesBuilt += (int64_t)entries.size();
+    HIP_CHECK(hipStreamSynchronize(stream));                // the host vectors above are the copy sources
+    d->viewPagesBuilt += (int64_t)versions.size();
+    return true;
+}
+
+void lcb_device_build_views_impl(lcb_device* h, int nViews, const LcbViewMark* marks, int64_t nMarks)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    lcb_build_views_into(d, d->views, d->stream, true, nViews, marks, nMarks);
 }
 
 // Three arrays of `bytes` each, `reps` timed sweeps after one warm-up; returns GB/s (3 x bytes per sweep: two reads, one write).
@@ -998,6 +1097,153 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
     d->wantFp = false;
 }
 
+// ---- side lanes: asynchronous job batches ---------------------------------------------------------------------------------
+// A batch = the speculative jobs of one stop of the ordered commit (engine.cpp). Its jobs run in the wide variant (16 wavefronts
+// per seed), the ones known to need it in the big variant, both kernels at once on the lane's two streams, against the lane's own
+// predicted views. The host does not wait for the kernels: it polls the status word of the one header it needs (the kernels
+// publish a header with a system-scope release after everything else the seed wrote). A job that overflows its variant gets no
+// result here - the engine computes it synchronously (through the whole variant ladder) if the commit turns out to need it.
+
+// kernel time of a finished batch goes into the device's totals; the lane is idle afterwards
+static void lcb_lane_retire(lcb_device_impl* d, SideLane& L)
+{
+    float ms = 0;
+    if (L.ranW) { HIP_CHECK(hipEventSynchronize(L.w1)); HIP_CHECK(hipEventElapsedTime(&ms, L.w0, L.w1)); d->kernelMs += ms; d->launches++; }
+    if (L.ranB) { HIP_CHECK(hipEventSynchronize(L.b1)); HIP_CHECK(hipEventElapsedTime(&ms, L.b0, L.b1)); d->kernelMs += ms; d->launches++; }
+    L.busy = L.released = L.ranW = L.ranB = false;
+}
+
+static bool lcb_lane_finished(SideLane& L)
+{
+    if (L.ranW && hipEventQuery(L.w1) != hipSuccess) return false;
+    if (L.ranB && hipEventQuery(L.b1) != hipSuccess) return false;
+    return true;
+}
+
+static void lcb_lane_stop(lcb_device_impl* d, SideLane& L)
+{
+    if (!L.busy || L.released) return;
+    HIP_CHECK(hipMemsetAsync(L.dCtl + 8, 0xFF, 4, d->ctlStream));    // the jobs give up at their next vote (lcb_extend)
+    L.released = true;
+}
+
+static void lcb_device_drain_lanes(lcb_device_impl* d)
+{
+    for (SideLane& L : d->lanes) if (L.busy) lcb_lane_stop(d, L);
+    if (d->ctlStream) (void)hipStreamSynchronize(d->ctlStream);
+    for (SideLane& L : d->lanes) if (L.busy) { (void)hipStreamSynchronize(L.sw); (void)hipStreamSynchronize(L.sb); lcb_lane_retire(d, L); }
+}
+
+int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
+{
+    lcb_device_impl* d = h->impl;
+    if (d->lanes.empty() || d->stats || d->o.start_mode || n <= 0 || d->hDbg || d->seedTrace || d->forceProf) return -1;
+    d->use();
+    int lane = -1;
+    for (size_t l = 0; l < d->lanes.size() && lane < 0; l++) if (!d->lanes[l].busy) lane = (int)l;
+    for (size_t l = 0; l < d->lanes.size() && lane < 0; l++) if (d->lanes[l].released && lcb_lane_finished(d->lanes[l])) { HIP_CHECK(hipStreamSynchronize(d->ctlStream)); lcb_lane_retire(d, d->lanes[l]); lane = (int)l; }
+    for (size_t l = 0; l < d->lanes.size() && lane < 0; l++)
+        if (d->lanes[l].released) {       // told to stop: its jobs leave at their next vote
+            HIP_CHECK(hipStreamSynchronize(d->ctlStream));
+            HIP_CHECK(hipStreamSynchronize(d->lanes[l].sw)); HIP_CHECK(hipStreamSynchronize(d->lanes[l].sb));
+            lcb_lane_retire(d, d->lanes[l]); lane = (int)l;
+        }
+    if (lane < 0 || n > (int64_t)d->lanes[(size_t)lane].cap) { d->sideNoLane++; return -1; }
+    SideLane& L = d->lanes[(size_t)lane];
+    if (!lcb_build_views_into(d, L.views, L.sw, false, nViews, marks, nMarks)) { d->sideNoLane++; return -1; }
+    // jobs by variant: big for the seeds known to need it, wide for the rest (ticket order = plan order within a kernel)
+    uint32_t nW = 0, nB = 0;
+    uint32_t* listW = L.hList; uint32_t* listB = L.hList + L.cap;
+    L.seeds.assign(seeds, seeds + n);
+    for (int64_t i = 0; i < n; i++) {
+        L.hSeeds[i].vid = seeds[i].vid; L.hSeeds[i].ch = seeds[i].ch; L.hSeeds[i].view = view ? view[i] : 0u; L.hSeeds[i].pad = 0;
+        L.hOut[i].status = LCB_ST_PENDING;
+        uint8_t mode = 1;
+        if (!d->modeHint.empty()) {
+            const uint64_t key = hintKey(seeds[i]);
+            const uint32_t hb = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 48);
+            if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) mode = it->second; }
+        }
+        if (mode >= 3) L.hOut[i].status = LCB_ST_ABORTED;           // the huge variant does not run here: no result
+        else if (mode == 2) listB[nB++] = (uint32_t)i;
+        else listW[nW++] = (uint32_t)i;
+    }
+    memset(L.hCtl, 0, 64);
+    L.hCtl[6] = nW; L.hCtl[7] = nB;
+    HIP_CHECK(hipMemcpyAsync(L.dCtl, L.hCtl, 64, hipMemcpyHostToDevice, L.sw));
+    HIP_CHECK(hipStreamSynchronize(L.sw));          // the control words are in place before either kernel starts
+    LcbTables T = d->T;
+    T.viewTab = L.views.tab;
+    auto start = [&](WorkSet& w, hipStream_t q, hipEvent_t e0, hipEvent_t e1, uint32_t m, uint32_t* list, uint32_t ticketWord, uint32_t countWord) {
+        LcbWork W;
+        W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap; W.instCap = w.instCap; W.voteCap = w.voteCap;
+        W.cursor = L.dCtl + ticketWord; W.cursorBase = 0; W.live = list; W.nLive = L.dCtl + countWord;
+        W.arenaCursor = (unsigned long long*)(L.dCtl + 2); W.arenaBase = 0; W.fpCursor = (unsigned long long*)(L.dCtl + 4); W.fpBase = 0;
+#if LCB_PATH_SIG
+        W.sigArena = nullptr; W.sigCursor = nullptr; W.sigBase = 0; W.sigCap = 0;
+#endif
+        W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8;
+        const uint32_t grid = m < w.nSlots ? m : w.nSlots;
+        HIP_CHECK(hipEventRecord(e0, q));
+        if (w.mode == 2) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        else hipLaunchKernelGGL((lcb_process_kernel<1, false, LCB_NW_WIDE, false>), dim3(grid), dim3(64 * LCB_NW_WIDE), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, q));
+        d->modeSeeds[w.mode] += m;
+    };
+    L.ranW = nW > 0; L.ranB = nB > 0;
+    if (nW) start(L.wide, L.sw, L.w0, L.w1, nW, listW, 0, 6);
+    if (nB) start(L.big, L.sb, L.b0, L.b1, nB, listB, 1, 7);
+    L.busy = true; L.released = false; L.n = n;
+    d->sideBatches++; d->sideJobs += n;
+    return lane;
+}
+
+int lcb_device_side_poll_impl(lcb_device* h, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp)
+{
+    lcb_device_impl* d = h->impl;
+    SideLane& L = d->lanes[(size_t)lane];
+    if (!L.busy || k < 0 || k >= L.n) return 2;
+    volatile uint32_t* st = &L.hOut[k].status;
+    if (*st == LCB_ST_PENDING) {
+        if (!wait) return 0;
+        d->use();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spin = 0; *st == LCB_ST_PENDING; spin++) {
+            if ((spin & 0xFFF) != 0xFFF) continue;
+            if (lcb_lane_finished(L) && *st == LCB_ST_PENDING) throw LcbError("side lane: the kernels finished without processing a job");
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (d->watchdogS > 0 && el > d->watchdogS) throw LcbError("kernel watchdog expired while waiting for a side-lane job (LCB_WATCHDOG_S)");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const LcbSeedOut o = L.hOut[k];
+    if (o.status == LCB_ST_OK) {
+        const uint4* src = L.hArena + o.arenaOff;
+        for (uint32_t e = 0; e < o.nInst; e++) inst.push_back(lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w});
+        const uint2* fs = L.hFp + o.fpOff;
+        for (uint32_t e = 0; e < o.nFp; e++) fp.push_back(lcb_fp{fs[e].x, fs[e].y});
+        return 1;
+    }
+    if (o.status == LCB_ST_DIST_OVF) throw LcbError("a path longer than 2^31 bp is not supported");
+    // an overflow: the next attempt (synchronous, or a later batch) starts in the variant that holds it
+    if (o.status >= LCB_ST_INST_OVF && o.status <= LCB_ST_BEST_OVF) {
+        const bool wasBig = [&]() { for (uint32_t q = 0; q < L.hCtl[7]; q++) if (L.hList[L.cap + q] == (uint32_t)k) return true; return false; }();
+        setHint(d, L.seeds[(size_t)k], (uint8_t)(wasBig ? 3 : 2));
+        d->overflow[wasBig ? 2 : 1][o.status]++;
+    }
+    return 2;
+}
+
+void lcb_device_side_release_impl(lcb_device* h, int lane)
+{
+    lcb_device_impl* d = h->impl;
+    d->use();
+    lcb_lane_stop(d, d->lanes[(size_t)lane]);
+}
+
+int lcb_device_side_lanes_impl(lcb_device* h) { return (int)h->impl->lanes.size(); }
+
 namespace {
 
 // The product's per-rank engine: the HIP kernels on one MI355X.
@@ -1020,6 +1266,13 @@ struct DeviceProcessor : LcbProcessor {
     }
     void mark(const uint64_t* ranges, int64_t n) override { lcb_device_mark_used_impl(dev, ranges, n); }
     void reset() override { lcb_device_reset_used_impl(dev); }
+    int sideLanes() const override { return lcb_device_side_lanes_impl(dev); }
+    int sideBegin(const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks) override
+    {
+        return lcb_device_side_begin_impl(dev, seeds, view, n, nViews, marks, nMarks);
+    }
+    int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return lcb_device_side_poll_impl(dev, lane, k, wait, inst, fp); }
+    void sideRelease(int lane) override { lcb_device_side_release_impl(dev, lane); }
 };
 
 }  // namespace
@@ -1043,5 +1296,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
+        stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
     }
 }

@@ -211,6 +211,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !cfg.relaxViews && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
     std::vector<SideJob> sideJobs;                  // of this round
+    size_t sideScan = 0;                            // jobs before this index are no longer in flight
     std::vector<int32_t> sideE, sideF;              // per seed of the round: its job in flight for E / F (index into sideJobs), or -1
     std::vector<int> lanePending((size_t)std::max(0, proc.sideLanes()), 0);   // jobs in flight per lane
     std::vector<int> laneOrder;                     // lanes with a batch in flight, oldest first
@@ -337,7 +338,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         e0Checked.assign((size_t)nRound, 0);
         liveIdx.clear();
         for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
-        if (useSide) { sideJobs.clear(); sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
+        if (useSide) { sideJobs.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
         const int64_t recomputedBefore = st.recomputedSeeds;
 
         // the newest E result of seed i: instances / footprint / provenance
@@ -387,26 +388,43 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // The commit needs the E / F of seed i now and a job for it is in flight: its result is taken (waiting for that one job)
         // if its view came true - at this point every commit the view predicted has either happened or will never happen -,
         // otherwise the job is dropped. true: a new candidate result is in place (validate it like any other).
+        // the result (sInst, sFp; r = sidePoll's verdict) of a background job becomes the candidate result of its seed
+        auto storeSide = [&](int32_t ref, int r, bool viewChecked) -> bool {
+            const SideJob sj = sideJobs[(size_t)ref];
+            sideJobs[(size_t)ref].state = 1;
+            int32_t& cur = (sj.isF ? sideF : sideE)[(size_t)sj.seed];
+            if (cur == ref) cur = -1;
+            laneDone(sj.lane);
+            if (r != 1) { st.sideFailed++; return false; }
+            st.sideTaken++;
+            int32_t& slot = sj.isF ? fIdx[(size_t)sj.seed] : eIdx[(size_t)sj.seed];
+            if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
+            Cand& c = cands[(size_t)slot];
+            c.epoch = sj.epoch; c.view = sj.set; c.checkedTo = (uint32_t)sj.epoch; c.viewOk = viewChecked || sj.set < 0;
+            c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{}; c.pathV.clear();
+            return true;
+        };
         auto takeSide = [&](int64_t i, bool isF) -> bool {
             const int32_t ref = (isF ? sideF : sideE)[(size_t)i];
             if (ref < 0) return false;
             if (sideJobs[(size_t)ref].state != 0 || !sidePlausible(sideJobs[(size_t)ref], nullptr)) { dropSide(ref); return false; }
-            const SideJob sj = sideJobs[(size_t)ref];
             sInst.clear(); sFp.clear();
             const auto tp = std::chrono::steady_clock::now();
-            const int r = proc.sidePoll(sj.lane, sj.k, true, sInst, sFp);
+            const int r = proc.sidePoll(sideJobs[(size_t)ref].lane, sideJobs[(size_t)ref].k, true, sInst, sFp);
             st.processMs += msSince(tp);
-            sideJobs[(size_t)ref].state = 1;
-            (isF ? sideF : sideE)[(size_t)i] = -1;
-            laneDone(sj.lane);
-            if (r != 1) { st.sideFailed++; return false; }
-            st.sideTaken++;
-            int32_t& slot = isF ? fIdx[(size_t)i] : eIdx[(size_t)i];
-            if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
-            Cand& c = cands[(size_t)slot];
-            c.epoch = sj.epoch; c.view = sj.set; c.checkedTo = (uint32_t)sj.epoch; c.viewOk = true;
-            c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{}; c.pathV.clear();
-            return true;
+            return storeSide(ref, r, true);
+        };
+        // Background jobs that have finished become candidate results like the jobs of a synchronous launch (a dry run then judges
+        // them by their footprints; their lane is free once all its jobs are in). Called at every stop.
+        auto harvestSide = [&]() {
+            const auto tp = std::chrono::steady_clock::now();
+            for (size_t q = sideScan; q < sideJobs.size(); q++) {
+                if (sideJobs[q].state != 0) { if (q == sideScan) sideScan++; continue; }
+                sInst.clear(); sFp.clear();
+                const int r = proc.sidePoll(sideJobs[q].lane, sideJobs[q].k, false, sInst, sFp);
+                if (r != 0) storeSide((int32_t)q, r, false);
+            }
+            st.processMs += msSince(tp);
         };
 
         // ---- dry run + job launch ---------------------------------------------------------------------------------------
@@ -415,6 +433,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // results at hand as predictions, collects every seed that will need a new E or F, and launches them all, each
         // against the predicted state at its turn.
         auto planAndLaunch = [&](int64_t ph0, int64_t stopAt, bool midPhase) {
+            if (useSide) harvestSide();
             const auto tPlan = std::chrono::steady_clock::now();
             flush();                                // processor state == live state
             RangeSet simP;                          // predicted marks on top of the live state
@@ -564,8 +583,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 const auto tp = std::chrono::steady_clock::now();
                 lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
                 if (lane < 0 && !laneOrder.empty()) {
+                    // every lane holds a batch with jobs still running: the oldest one gives way (what it has finished is kept)
                     const int old = laneOrder.front();
-                    for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].lane == old && sideJobs[q].state == 0) dropSide((int32_t)q);
+                    for (size_t q = sideScan; q < sideJobs.size(); q++) if (sideJobs[q].lane == old && sideJobs[q].state == 0) dropSide((int32_t)q);
                     lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
                 }
                 st.processMs += msSince(tp);

@@ -35,6 +35,11 @@ void lcb_device_process_end_impl(lcb_device* d, std::vector<uint64_t>& offsets, 
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
 void lcb_device_build_views_impl(lcb_device* d, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_max_views_impl(lcb_device* d);
+// asynchronous job batches (LcbProcessor::side*, lcb_host.h)
+int lcb_device_side_lanes_impl(lcb_device* d);
+int lcb_device_side_begin_impl(lcb_device* d, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks);
+int lcb_device_side_poll_impl(lcb_device* d, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp);
+void lcb_device_side_release_impl(lcb_device* d, int lane);
 double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);

@@ -41,6 +41,13 @@
 #include <stdint.h>
 
 #define LCB_EMPTY_KEY INT32_MIN
+// A pointer the compiler cannot prove to be a global one (it was merged with a null) is dereferenced with FLAT loads, which wait on
+// two counters and are slower; this says what it is. (Device compiler only: the CPU emulator of the tests sees a plain pointer.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LCB_GLOBAL_U32(p) ((const __attribute__((address_space(1))) uint32_t*)(p))
+#else
+#define LCB_GLOBAL_U32(p) (p)
+#endif
 // The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
 // when the recorder is off. The recorder is what localises a hang on the device (host watchdog, device.hip).
 #define LCB_FLIGHT_RECORDER 1
@@ -363,7 +370,7 @@ __device__ __forceinline__ LcbUsed lcb_used_of(const LcbTables& T, uint32_t view
 // word w of the state (a view costs one more load, of a table entry that stays in the L1/L2 of the CU)
 __device__ __forceinline__ uint32_t lcb_uword(const LcbUsed& U, uint32_t w)
 {
-    if (U.tab) w += U.tab[w >> LCB_PAGE_SHIFT];
+    if (U.tab) w += LCB_GLOBAL_U32(U.tab)[w >> LCB_PAGE_SHIFT];
     return U.live[w];
 }
 
@@ -580,8 +587,11 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 
 // ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
 // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717). Its scalars live in SGPRs.
-struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
-struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
+struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight, page, tabOff; int32_t dir; bool positive; };   // page / tabOff: the view's page-table entry at g0
+// uw: the RAW `used` word of the step and ub its bit - the shift happens where the step is consumed: a use of the loaded word at
+// the place of the load makes the compiler wait for it (and for every load before it) there, which turns the prefetch of the next
+// voter / chunk into a blocking round trip per call
+struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw, ub; bool valid; };
 
 // The voter walks of one vote. The voters are the instances of the touch list that are in the voting list (the good list
 // if it has two entries, else all instances; blocksfinder.h:713). Wave w of nWaves takes the voters with ordinal == w
@@ -607,7 +617,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     const uint32_t nTouch = S.nTouch;
     uint32_t chunkBase = 0, ordinal = 0;
     unsigned long long pend = 0;
-    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
+    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0, fTab = 0;
     bool scanned = false;
     auto nextVoter = [&](LcbVoter& v) -> bool {
         for (;;) {
@@ -629,6 +639,9 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                         fPos = forward ? bp : fp;
                         fLo = S.iLo[fI]; fHi = S.iHi[fI];
                         fW = lcb_absdiff(fp, bp) + 1u;                                       // blocksfinder.h:719
+                        // the page-table entry of the view at the voter's end: its window (a few hundred positions) almost never
+                        // leaves that page, so the walk's `used` reads need no dependent table load
+                        if (S.U.tab && !tryUsed) fTab = LCB_GLOBAL_U32(S.U.tab)[fG >> (5u + LCB_PAGE_SHIFT)];
                     }
                 }
                 pend = __ballot(is);
@@ -642,6 +655,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
             const uint32_t hi = lcb_rl(fHi, b);
             v.weight = lcb_rl(fW, b);
+            v.page = v.g0 >> (5u + LCB_PAGE_SHIFT); v.tabOff = lcb_rl(fTab, b);
             v.positive = (lcb_rl(fFl, b) & LCB_FLAG_POS) != 0;
             v.dir = (forward == v.positive) ? 1 : -1;
             v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
@@ -655,18 +669,22 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
         const uint32_t d = c * 64 + S.lane + 1;
         w.valid = d <= v.rem;                                                               // it.Valid()
         w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
-        w.pos = 0; w.id = 0; w.uw = 0;
+        w.pos = 0; w.id = 0; w.uw = 0; w.ub = 0;
         if (w.valid) {
-            w.pos = T.posPos[w.g];
-            w.id = T.posId[w.g];
             // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
             const uint32_t ub = w.g - (v.positive ? 0u : 1u);
-            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, ub >> 5) >> (ub & 31);
+            const bool wantUsed = !tryUsed && (v.positive || w.g > v.lo);
+            // a predicted view reads through its page table: the entry of the voter's own page came with the voter (nextVoter)
+            uint32_t uwi = ub >> 5;
+            if (wantUsed && S.U.tab) uwi += (uwi >> LCB_PAGE_SHIFT) == v.page ? v.tabOff : LCB_GLOBAL_U32(S.U.tab)[uwi >> LCB_PAGE_SHIFT];
+            w.pos = T.posPos[w.g];
+            w.id = T.posId[w.g];
+            if (wantUsed) { w.uw = S.U.live[uwi]; w.ub = ub & 31u; }
         }
         return w;
     };
     LcbVoter cur, nxt;
-    LcbWalk wcur, wnxt, wahead = LcbWalk{0u, 0u, 0, 0u, false};
+    LcbWalk wcur, wnxt, wahead = LcbWalk{0u, 0u, 0, 0u, 0u, false};
     bool have = nextVoter(cur);
     if (have) wcur = issue(cur, 0);
     bool deep = false;                  // the previous voter's window did not end in its first 64 steps (k = 15: ~120 junctions in b = 200 bp)
@@ -682,7 +700,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
-            bool stop = cond && (w.uw & 1u) != 0;
+            bool stop = cond && ((w.uw >> w.ub) & 1u) != 0;
             if (exact && cond && !stop) stop = lcb_path_contains(S, vid);
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
@@ -1692,10 +1710,13 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             o->sigOff = sgo; o->nSig = nsg; o->pad2 = 0;
 #endif
         }
-        __threadfence_system();
+        // (only in launches whose headers the host polls: the release writes back the L2 of the whole XCD, 8 % of a config-3 pass
+        // when every seed of every launch did it; a synchronous launch is read after its stream has drained)
+        if (S.abort) __threadfence_system();
         if (S.lane == 0) {
             LcbSeedOut* o = sArgs.out + s;
-            __hip_atomic_store(&o->status, (uint32_t)S.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (S.abort) __hip_atomic_store(&o->status, (uint32_t)S.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            else o->status = S.status;
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }

@@ -251,3 +251,48 @@ def test_overlapped_rounds(built, case, overlap):
     summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
     assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
     assert overlap == 1 or finder.stats["early_rounds"] == 0
+
+
+@pytest.mark.parametrize("knobs,dev_opts", [({"sync_jobs": 1}, {}), ({}, {"side_lanes": 1}), ({"max_jobs": 6}, {"side_lanes": 2}),
+                                             ({"round_fixed": 1, "round_phases": 64, "max_views": 3}, {}), ({"predict_f": 1}, {"side_lanes": 3, "wide_slots": 4, "big_slots": 2})])
+def test_side_lanes_on_gpu(built, case, knobs, dev_opts):
+    """Asynchronous job batches: a stop of the ordered commit waits only for the results it cannot go on without, the rest of its
+    plan runs on a side lane (own streams, buffers, slots, views) while the commit goes on and reads/marks the live bitmap. Same
+    blocks as the reference with the lanes off (sync_jobs), with one lane (batches give way to each other), with a tiny job cap,
+    with view starvation in one whole-input round, and with few workgroups per lane."""
+    st, p, dev = _setup(case, **dev_opts)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, **knobs)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+    if knobs.get("sync_jobs"):
+        assert finder.stats["side_batches"] == 0
+    elif finder.stats["recompute_launches"] > 2:
+        assert finder.stats["side_batches"] > 0 and finder.stats["side_jobs"] >= finder.stats["side_taken"]
+    # a second pass on the same device (lanes drained and reused) gives the same blocks
+    blocks2 = finder.FindBlocks(case.m, case.b, device=dev, threads=4, **knobs)
+    assert blocks.tobytes() == blocks2.tobytes()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_footprints_cover_every_read_on_gpu(built, case, mode):
+    """The property behind the engine's exactness rule, on the device, for every kernel variant: a seed's footprint covers every
+    position whose `used` bit its computation read as 0 - so with EVERY other unused position set to used the seed must give the
+    same result (and with the footprint itself unused nothing it read as 0 changed). Checked for the seeds that produce a block."""
+    st, p, dev = _setup(case, start_mode=mode)
+    seeds = st.seeds(4)[:1200]
+    off, inst, fp_off, fp = dev.process_seeds_fp(seeds)
+    n_pos = st.n_positions()
+    words = (n_pos + 31) // 32 + 1
+    picked = [i for i in range(len(seeds)) if off[i + 1] - off[i] > 1][:: max(1, (len(seeds) // 40))][:40]
+    assert picked, "no seed of the case yields a block"
+    for i in picked:
+        bits = np.ones(words * 32, dtype=bool)
+        for lo, hi in fp[int(fp_off[i]):int(fp_off[i + 1])]:
+            bits[int(lo):int(hi) + 1] = False
+        dev.set_used(np.packbits(bits, bitorder="little").view("<u4"))
+        off2, inst2, _, _ = dev.process_seeds_fp(seeds[i:i + 1])
+        assert inst2.tobytes() == inst[int(off[i]):int(off[i + 1])].tobytes(), "seed %d: a read outside its footprint changed the result (variant %d)" % (i, mode)
+    dev.reset_used()

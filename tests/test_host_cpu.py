@@ -168,6 +168,12 @@ def emu_built():
                                             ("nruns_abund", "seeds-init", {"EMU_NOSTATS": "1", "EMU_LIMIT": "700", "EMU_FP_CHECK": "1"}),
                                             ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150", "EMU_FP_CHECK": "1"}),
                                             ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150", "EMU_FP_CHECK": "1"}),
+                                            # asynchronous job batches (side lanes): computed at once / when first asked for (the two extremes of what a batch
+                                            # that reads the live state while it is being marked can see), results visible late, one lane, tiny job cap
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1"}),
+                                            ("tandem4", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "LCB_MAX_JOBS": "16", "EMU_SIDE_DELAY": "2"}),
+                                            ("smallb", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
+                                            ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
