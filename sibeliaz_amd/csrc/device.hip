@@ -462,7 +462,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->lanePoolPages = nLanes ? 32768u : 0u;
         d->views.poolBasePage = nLanes * d->lanePoolPages;
         d->views.poolPages = 4096;
-        HIP_CHECK(hipMalloc((void**)&d->dUsed, (d->usedWords + ((size_t)d->views.poolBasePage + d->views.poolPages) * pageWords) * 4));
+        // (+ 1 guard page: a vote walk that leaves its voter's page reads a few words past the private copy before it repairs the lane)
+        HIP_CHECK(hipMalloc((void**)&d->dUsed, (d->usedWords + ((size_t)d->views.poolBasePage + d->views.poolPages + 1) * pageWords) * 4));
         HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
         HIP_CHECK(hipMalloc((void**)&d->views.tab, (size_t)(d->maxViews + 1) * d->nPages * 4));
         HIP_CHECK(hipMemset(d->views.tab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
@@ -705,7 +706,7 @@ static bool lcb_build_views_into(lcb_device_impl* d, ViewSpace& V, hipStream_t s
         while (np < versions.size()) np *= 2;
         if (d->usedWords + (((uint64_t)V.poolBasePage + np) << LCB_PAGE_SHIFT) >= (1ull << 32)) throw LcbError("predicted views need more private pages than a 32-bit word offset reaches");
         uint32_t* nu = nullptr;
-        HIP_CHECK(hipMalloc((void**)&nu, (d->usedWords + (((size_t)V.poolBasePage + np) << LCB_PAGE_SHIFT)) * 4));
+        HIP_CHECK(hipMalloc((void**)&nu, (d->usedWords + (((size_t)V.poolBasePage + np + 1) << LCB_PAGE_SHIFT)) * 4));
         HIP_CHECK(hipMemcpy(nu, d->dUsed, d->usedWords * 4, hipMemcpyDeviceToDevice));
         HIP_CHECK(hipFree(d->dUsed));
         d->dUsed = nu; V.poolPages = np; d->T.used = nu;

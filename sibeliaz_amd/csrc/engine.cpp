@@ -212,6 +212,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
     std::vector<SideJob> sideJobs;                  // of this round
     size_t sideScan = 0;                            // jobs before this index are no longer in flight
+    int64_t frozenTo = 0;                           // seeds of the round before this index have their final phase-start result
     std::vector<int32_t> sideE, sideF;              // per seed of the round: its job in flight for E / F (index into sideJobs), or -1
     std::vector<int> lanePending((size_t)std::max(0, proc.sideLanes()), 0);   // jobs in flight per lane
     std::vector<int> laneOrder;                     // lanes with a batch in flight, oldest first
@@ -339,6 +340,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         liveIdx.clear();
         for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
         if (useSide) { sideJobs.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
+        frozenTo = 0;
         const int64_t recomputedBefore = st.recomputedSeeds;
 
         // the newest E result of seed i: instances / footprint / provenance
@@ -396,6 +398,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (cur == ref) cur = -1;
             laneDone(sj.lane);
             if (r != 1) { st.sideFailed++; return false; }
+            // The phase-start results of a phase are final once the phase has been validated (the commit below uses them without
+            // another look): a background E that arrives after that is of no use.
+            if (!sj.isF && sj.seed < frozenTo) { st.sideVoid++; return false; }
             st.sideTaken++;
             int32_t& slot = sj.isF ? fIdx[(size_t)sj.seed] : eIdx[(size_t)sj.seed];
             if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
@@ -653,6 +658,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 if (all) break;
                 planAndLaunch(ph, ph, false);
             }
+            frozenTo = ph + n;
             // (b) ordered commit (blocksfinder.h:372-414)
             if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;
             // the phase-start result of every seed is exact now: its events are the ones the reference's Process() call has

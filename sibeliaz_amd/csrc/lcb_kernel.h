@@ -662,45 +662,48 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             return true;
         }
     };
-    // The table reads of a pass (pos, id, used word) are independent and issued together; the first pass of the NEXT
-    // voter is issued before the current one is consumed, so its latency hides behind the LDS work of this one.
+    // The table reads of a chunk (position, id, `used` word) are independent and issued together - UNCONDITIONALLY (lanes beyond the
+    // chromosome end re-read the voter's own end, a view's page-table offset is the voter's: a lane in another page is repaired at the
+    // consumer), so that the chunk is straight-line code with a fixed number of loads: the compiler can then wait for exactly the
+    // loads a consumer needs (s_waitcnt vmcnt(n)) and the requests for the NEXT voter's first chunk and for this voter's next chunk,
+    // issued before the current chunk is consumed, stay in flight behind its LDS work. (With the loads inside `if (valid)` blocks the
+    // number in flight was unknown and every consumer waited for all of them - a round trip per chunk.)
     auto issue = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
         LcbWalk w;
         const uint32_t d = c * 64 + S.lane + 1;
         w.valid = d <= v.rem;                                                               // it.Valid()
-        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
-        w.pos = 0; w.id = 0; w.uw = 0; w.ub = 0;
-        if (w.valid) {
-            // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
-            const uint32_t ub = w.g - (v.positive ? 0u : 1u);
-            const bool wantUsed = !tryUsed && (v.positive || w.g > v.lo);
-            // a predicted view reads through its page table: the entry of the voter's own page came with the voter (nextVoter)
-            uint32_t uwi = ub >> 5;
-            if (wantUsed && S.U.tab) uwi += (uwi >> LCB_PAGE_SHIFT) == v.page ? v.tabOff : LCB_GLOBAL_U32(S.U.tab)[uwi >> LCB_PAGE_SHIFT];
-            w.pos = T.posPos[w.g];
-            w.id = T.posId[w.g];
-            if (wantUsed) { w.uw = S.U.live[uwi]; w.ub = ub & 31u; }
-        }
+        const uint32_t dd = w.valid ? d : 0u;
+        w.g = v.dir > 0 ? v.g0 + dd : v.g0 - dd;
+        // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start: any bit, ignored by the consumer)
+        const uint32_t ub = w.g - ((v.positive || w.g <= v.lo) ? 0u : 1u);
+        const uint32_t uwi = ub >> 5;
+        w.ub = (ub & 31u) | (((uwi >> LCB_PAGE_SHIFT) != v.page) ? 32u : 0u);               // bit 5: not the page v.tabOff belongs to
+        w.pos = T.posPos[w.g];
+        w.id = T.posId[w.g];
+        w.uw = S.U.live[uwi + v.tabOff];                                                    // (tabOff 0 without a view)
         return w;
     };
     LcbVoter cur, nxt;
-    LcbWalk wcur, wnxt, wahead = LcbWalk{0u, 0u, 0, 0u, 0u, false};
+    LcbWalk wcur, wnxt, wahead;
     bool have = nextVoter(cur);
     if (have) wcur = issue(cur, 0);
-    bool deep = false;                  // the previous voter's window did not end in its first 64 steps (k = 15: ~120 junctions in b = 200 bp)
     while (have) {
         const bool haveNext = nextVoter(nxt);
-        if (haveNext) wnxt = issue(nxt, 0);
+        if (!haveNext) nxt = cur;
+        wnxt = issue(nxt, 0);                           // (after the last voter: a repeat of its own first chunk, nobody reads it)
         for (uint32_t c = 0;; c++) {
-            // chunk c + 1 is requested before chunk c is consumed (once the windows are known to be that long)
-            const bool ahead = c > 0 || deep;
-            const LcbWalk w = c == 0 ? wcur : ((c > 1 || deep) ? wahead : issue(cur, c));
-            if (ahead) wahead = issue(cur, c + 1);
+            const LcbWalk w = c == 0 ? wcur : wahead;
+            wahead = issue(cur, c + 1);                 // chunk c + 1 is requested before chunk c is consumed
             if (PROF) S.pfChunks++;
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
-            bool stop = cond && ((w.uw >> w.ub) & 1u) != 0;
+            uint32_t usedBit = 0;
+            if (!tryUsed && cond && (cur.positive || w.g > cur.lo)) {
+                usedBit = (w.uw >> (w.ub & 31u)) & 1u;
+                if (S.U.tab && (w.ub & 32u)) usedBit = lcb_used_bit(S.U, w.g - (cur.positive ? 0u : 1u)) ? 1u : 0u;   // the window left the voter's page (rare)
+            }
+            bool stop = usedBit != 0;
             if (exact && cond && !stop) stop = lcb_path_contains(S, vid);
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
@@ -737,7 +740,6 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                     atomicMin(&S.fpLo[fs], ge);
                     atomicMax(&S.fpHi[fs], ge);
                 }
-                deep = c > 0;
                 break;
             }
         }

@@ -130,6 +130,7 @@ struct Emu {
                     used[page * pageWords + e + (q % pageBits) / 32] |= 1u << (q & 31);
                 }
             }
+        used.resize(used.size() + pageWords);                    // guard page (a vote walk that leaves its voter's page reads a few words past a private copy)
         T.used = used.data(); T.viewTab = viewTab.data();
         nViewsAlloc = nViews;
     }
