@@ -19,13 +19,15 @@ The JSON line also carries
                 this run and is null; `traffic_profiled` quotes the per-launch figure of the committed rocprofv3 --pmc
                 passes of this same command (profiles/r02/pmc_traffic.json) for the default workload.
   cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container) timed
-                on this box's host cores on a BOUNDED sample of the same workload (same generator and parameters, 1/10 of
-                the ancestor's segments; 1/40 for the single-thread run): -t 1, -t 32 (the cap of the reference's wrapper
-                script, sibeliaz:139) and -t 64, median of 3, banner to banner; plus an md5 check of its GFF against ours
-                on the sample. `--full-cpu-baseline` times it on the whole workload instead (minutes).
+                on this box's host cores: once at -t 32 (the cap of the reference's wrapper script, sibeliaz:139) on the WHOLE
+                workload `value` is measured on, its blocks_coords.gff compared (md5) with the timed run's; and on bounded samples
+                of the same workload (same generator and parameters, 1/10 of the ancestor's segments; 1/40 for -t 1), median of
+                3, banner to banner, at -t 1, -t 64 and -t <all hardware threads>. `--sample-cpu-baseline` skips the whole-workload
+                run (the round-2 protocol).
   wall_clock    metric part 2: the whole sibeliaz-lcb process (load, seeds, upload, phase loop, GFF) on the workload.
-For N > 1 launch with torch.distributed.run (one rank per GPU): torch only ships the RCCL unique id and takes the
-max of the step times; the all-gathers of the engine are ncclAllGather calls inside the C++ library (csrc/comm.hip).
+N > 1: either under torch.distributed.run (one rank per GPU: torch only ships the RCCL unique id and takes the max of the step
+times) or called directly (`python bench.py --gpus N`): one process, a persistent lcb_gpus set - one host thread per GPU inside the
+library, ncclCommInitAll. Either way the all-gathers of the engine are ncclAllGather calls inside the C++ library (csrc/comm.hip).
 """
 import argparse
 import hashlib
@@ -157,35 +159,62 @@ def our_gff(w, threads, dev_ordinal=0):
     return os.path.join(out, "blocks_coords.gff")
 
 
-def cpu_baseline(workload, threads, full):
-    """SURVEY.md §8d protocol on a bounded sample: -t 1 / -t 32 / -t 64, median of 3, analyze time banner to banner."""
+def cpu_baseline(workload, threads, full, our_gff_path):
+    """SURVEY.md §8d protocol: the reference at -t 32 on the WHOLE workload (one run; its GFF must equal the timed run's), and on
+    bounded samples at -t 1 / -t 64 / -t <all hardware threads>, median of 3, analyze time banner to banner."""
     host = os.cpu_count() or 1
-    big_name, tiny_name = (workload, SAMPLES[workload][0]) if full else SAMPLES[workload]
-    big, tiny = ensure_workload(big_name), ensure_workload(tiny_name)
-    s_big, s_tiny = n_seeds_of(big, threads), n_seeds_of(tiny, threads)
+    small_name, tiny_name = SAMPLES[workload]
+    whole, small, tiny = ensure_workload(workload), ensure_workload(small_name), ensure_workload(tiny_name)
+    s_whole, s_small, s_tiny = n_seeds_of(whole, threads), n_seeds_of(small, threads), n_seeds_of(tiny, threads)
     per_t = {}
-    gff_ref = None
-    for t, w, s in ((1, tiny, s_tiny), (min(32, host), big, s_big), (min(64, host), big, s_big)):
+
+    def leg(t, w, s, reps, tag):
         runs = []
-        for rep in range(1 if (full and t > 1) else 3):
-            r = run_reference(w, t, "t%d" % t)
+        for rep in range(reps):
+            r = run_reference(w, t, tag)
             if r is None:
                 return None
             runs.append(r)
-            if w is big:
-                gff_ref = r[2]
         an = statistics.median(x[0] for x in runs)
-        per_t[str(t)] = {"seeds_per_s": s / an, "analyze_s_median": an, "wall_s_median": statistics.median(x[1] for x in runs), "runs": len(runs),
-                         "sample": w["desc"], "sample_seeds": s}
-    same = md5(gff_ref) == md5(our_gff(big, threads)) if gff_ref else False
-    # the reported figure is the reference's BEST thread count of the protocol (more threads are slower on this box)
-    best_t = max((t for t in per_t if t != "1"), key=lambda t: per_t[t]["seeds_per_s"])
-    top = per_t[best_t]
-    return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": int(best_t), "kind": "reference",
-            "sample": "%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %s (its fastest of -t 32 / -t 64), median of %d run(s), 'Analyzing' to "
-                      "'Generating' banner %.2f s (includes its serial seed enumeration); host has %d hardware threads" % (big["desc"], best_t, top["runs"], top["analyze_s_median"], host),
-            "threads": per_t, "gff_md5_equal_on_sample": bool(same),
-            "note": "-t 1 is timed on the smaller sample named in threads['1']; the reference's own wrapper caps -t at 32 (sibeliaz:139)"}
+        per_t[tag] = {"threads": t, "seeds_per_s": s / an, "analyze_s_median": an, "wall_s_median": statistics.median(x[1] for x in runs), "runs": len(runs),
+                      "sample": w["desc"], "sample_seeds": s}
+        return runs[-1][2]
+
+    t32 = min(32, host)
+    same_full = None
+    if full:
+        gff_ref = leg(t32, whole, s_whole, 1, "t%d_whole" % t32)
+        if gff_ref is None:
+            return None
+        same_full = md5(gff_ref) == md5(our_gff_path)
+    if leg(1, tiny, s_tiny, 3, "t1_sample") is None:
+        return None
+    gff_small = leg(t32, small, s_small, 3, "t%d_sample" % t32)
+    if gff_small is None:
+        return None
+    for t in sorted({min(64, host), host} - {t32}):
+        if leg(t, small, s_small, 3, "t%d_sample" % t) is None:
+            return None
+    same_small = md5(gff_small) == md5(our_gff(small, threads))
+    top = per_t["t%d_whole" % t32] if full else per_t["t%d_sample" % t32]
+    return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": t32, "kind": "reference",
+            "sample": "%s%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %d, %d run(s), 'Analyzing' to 'Generating' banner %.2f s "
+                      "(includes its serial seed enumeration); host has %d hardware threads" % (
+                          "the WHOLE benchmarked workload, " if full else "", top["sample"], t32, top["runs"], top["analyze_s_median"], host),
+            "gff_md5_equal": same_full if full else bool(same_small), "gff_md5_equal_on_sample": bool(same_small),
+            "legs": per_t,
+            "note": "legs named *_sample run on the bounded samples named in them (1/10 of the segments; 1/40 for -t 1); the reference's own wrapper caps -t at 32 "
+                    "(sibeliaz:139); more threads than that are slower on this input (the legs show it)"}
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the sources of the device code and the engine: the event counts were counted by a build of these."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sibeliaz_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip", ".cpp")):
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(c):
@@ -200,9 +229,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli62")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-cpu-baseline", action="store_true", help="time the reference on the whole workload (minutes) instead of the bounded sample")
+    ap.add_argument("--sample-cpu-baseline", action="store_true", help="time the reference on the bounded samples only (not on the whole workload)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
+    ap.add_argument("--trust-counts", action="store_true", help="use the committed event counts although another build counted them (exploration runs)")
+    ap.add_argument("--write-counts", action="store_true", help="store the counts of this run's counting pass in bench_event_counts.json (with the hash of the sources)")
     ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--device-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: a field of lcb_device_opts (e.g. path_cap=8192)")
@@ -213,10 +244,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        log("bench: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-        if world == 1:
-            sys.exit(2)
+    in_process = world == 1 and args.gpus > 1       # called directly with --gpus N: one process, a persistent lcb_gpus set
+    if world != args.gpus and not in_process and not (world == 1 and args.gpus == 1):
+        log("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        sys.exit(2)
 
     import sibeliaz_amd
 
@@ -247,7 +278,12 @@ def main():
     engine_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.engine_opt}
     if args.overlap:
         engine_opts["overlap"] = 1
-    dev = sibeliaz_amd.Device(storage, params, local_rank, **dev_opts)          # tables now resident in HBM
+    gpus = None
+    if in_process:
+        gpus = sibeliaz_amd.GpuSet(storage, params, list(range(args.gpus)), **dev_opts)      # tables resident in the HBM of every GPU, RCCL initialised
+        dev = None
+    else:
+        dev = sibeliaz_amd.Device(storage, params, local_rank, **dev_opts)          # tables now resident in HBM
     t_upload = time.time() - t
     S = len(seeds)
     log("bench[%d]: P=%d V=%d S=%d load %.2fs seeds %.2fs upload %.2fs" % (rank, storage.n_positions(), storage.GetVerticesNumber(), S, t_load, t_seeds, t_upload))
@@ -262,7 +298,10 @@ def main():
     finder = sibeliaz_amd.BlocksFinder(storage, w["k"])
 
     def step():
-        finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, **engine_opts)
+        if gpus is not None:
+            finder.FindBlocksOnSet(gpus, seeds=seeds, **engine_opts)
+        else:
+            finder.FindBlocks(w["m"], w["b"], device=dev, seeds=seeds, comm=comm, **engine_opts)
         return finder.blocks, dict(finder.stats)
 
     def sync():
@@ -272,7 +311,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dev.kernel_time()
+    if dev is not None:
+        dev.kernel_time()
     sync()
     t0 = time.time()
     last = None
@@ -303,11 +343,16 @@ def main():
         # Process() calls the reference makes (phase-start result of every seed + re-processing of every conflict)
         ctr_file = os.path.join(w["dir"], "counters.json")
         ctr = None
+        n_gpus = args.gpus if in_process else world
+        if gpus is not None and not args.no_roofline:
+            # the counting pass and the triad run on one device: a plain one beside the set (the counts do not depend on the GPU count)
+            dev = sibeliaz_amd.Device(storage, params, 0, **dev_opts)
         if not args.no_roofline:
             # the counts are a property of (input, parameters): the ones of the named workloads are kept in bench_event_counts.json
             # (counted by `bench.py --recount` on the MI355X) so that a default run need not repeat the 3-minute counting pass
             known = json.load(open(os.path.join(ROOT, "bench_event_counts.json"))).get(args.workload) if os.path.exists(os.path.join(ROOT, "bench_event_counts.json")) else None
-            if known and not args.recount and known["lcb_synth"] == w["synth"] and known["seeds"] == S:
+            # they are a property of (input, parameters); a build other than the one that counted them counts them again in this run
+            if known and not args.recount and known["lcb_synth"] == w["synth"] and known["seeds"] == S and (known.get("source_hash") == source_hash() or args.trust_counts):
                 ctr = known["event_counts"]
             elif os.path.exists(ctr_file) and not args.recount:
                 ctr = json.load(open(ctr_file))
@@ -318,35 +363,40 @@ def main():
                 dev.set_stats_mode(False)
                 ctr = {k: int(finder.stats["ev_" + k]) for k in sibeliaz_amd.api.COUNTER_NAMES}
                 json.dump(ctr, open(ctr_file, "w"))
+                if args.write_counts:
+                    allc = json.load(open(os.path.join(ROOT, "bench_event_counts.json"))) if os.path.exists(os.path.join(ROOT, "bench_event_counts.json")) else {}
+                    allc[args.workload] = {"event_counts": ctr, "lcb_synth": w["synth"], "seeds": S, "workload": w["desc"], "source_hash": source_hash(),
+                                           "source": "stats-mode pass of the engine on the MI355X (bench.py --recount --write-counts); reference-semantics counts are a property of input + parameters"}
+                    json.dump(allc, open(os.path.join(ROOT, "bench_event_counts.json"), "w"), indent=1, sort_keys=True)
                 dev.kernel_time()
                 log("bench: stats-mode pass %.1fs: %s" % (time.time() - t, ctr))
         abytes = algorithmic_bytes(ctr) if ctr else 0
         kernel_s_per_step = kernel_ms / 1000.0 / args.steps
         lps = launches / float(args.steps)
         achieved = abytes / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
-        triad = dev.hbm_triad()
+        triad = dev.hbm_triad() if dev is not None else 0.0
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command
         # (scripts/gpu_r2_evidence.sh), committed with the profile summaries; only for the workload they were taken on
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-        if args.workload == "ecoli62" and world == 1 and os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        if args.workload == "ecoli62" and n_gpus == 1 and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+            traffic_src = "profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
         line = {
-            "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": world, "steps": args.steps,
+            "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": w["desc"], "lcb_synth": w["synth"], "seeds": S, "junction_occurrences": storage.n_positions(),
                        "vertices": storage.GetVerticesNumber(), "phase_size": 256,
                        "parallelism": "one seed per workgroup: compact variant (2 wavefronts, 5 workgroups per CU) for launches of many seeds, wide variant (16 wavefronts "
                                       "sharing the votes) for launches of few, big variant for seeds with thousands of instances; speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint "
-                                      "validation; %d GPU(s)%s" % (world, ", every launch dealt to the ranks, ncclAllGather of results" if world > 1 else ""),
+                                      "validation; %d GPU(s)%s" % (n_gpus, ", every launch dealt to the ranks, ncclAllGather of results" if n_gpus > 1 else ", a stop's speculative jobs on side lanes"),
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
                        "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]), "early_rounds": int(st["early_rounds"]),
                        "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
-                       "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())),
+                       "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())) if gpus is None else None,
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
                        "untimed_s": {"load_graph": t_load, "enumerate_seeds": t_seeds, "create_device_upload_tables": t_upload}},
@@ -360,8 +410,11 @@ def main():
                          "note": "latency-bound integer walk: a launch is as long as its longest seed; n_compat_step of the counting pass is an upper bound within 1% "
                                  "(speculative results walk older bitmaps), everything else is exact"},
         }
-        dev.close()
-        if world == 1 and not args.no_cli:
+        if dev is not None:
+            dev.close()
+        if gpus is not None:
+            gpus.close()
+        if n_gpus == 1 and not args.no_cli:
             # metric part 2: wall-clock of the whole drop-in process to blocks_coords.gff
             cli_out = os.path.join(w["dir"], "cli_out")
             t = time.time()
@@ -369,8 +422,8 @@ def main():
                                 "-a", str(w["a"]), "-t", str(args.threads), "-o", cli_out, "--noseq"], capture_output=True, text=True)
             line["wall_clock"] = {"sibeliaz_lcb_process_s": time.time() - t, "rc": r.returncode, "threads": args.threads,
                                   "gff_md5_equal_to_timed_run": r.returncode == 0 and md5(os.path.join(cli_out, "blocks_coords.gff")) == md5(gff)}
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.workload, args.threads, args.full_cpu_baseline)
+        if n_gpus == 1 and not args.no_cpu_baseline and args.workload in SAMPLES:
+            cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff)
             if cb:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

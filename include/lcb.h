@@ -256,6 +256,14 @@ int lcb_find_blocks_comm(const lcb_graph* g, lcb_device* d, lcb_comm* c, const l
 int lcb_find_blocks_gpus(const lcb_graph* g, const int* device_ordinals, int n_devices, const lcb_params* p, const lcb_device_opts* opts,
                          const lcb_seed* seeds, int64_t n_seeds, const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
 
+/* The same with a persistent handle: devices are created, the tables uploaded and RCCL initialised ONCE; every
+ * lcb_gpus_find_blocks is one pass of the phase loop over all the GPUs of the set (what bench.py --gpus N times, and what
+ * sibeliaz-lcb uses with LCB_GPUS=N). always_comm != 0: a set of one GPU still goes through the RCCL exchange path (tests). */
+typedef struct lcb_gpus lcb_gpus;
+lcb_gpus* lcb_gpus_create(const lcb_graph* g, const int* device_ordinals, int n_devices, const lcb_params* p, const lcb_device_opts* opts, int always_comm);
+int lcb_gpus_find_blocks(lcb_gpus* m, const lcb_seed* seeds, int64_t n_seeds, const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);
+void lcb_gpus_destroy(lcb_gpus* m);
+
 /* ---- GenerateOutput (blocksfinder.h:605-670): trimming, blocks_coords.gff (blocksfinder.cpp:141-174) and,
  * if gen_seq, the <out_dir>/<i>.tmp chunk files (blocksfinder.h:533-582). */
 int lcb_generate_output(const lcb_graph* g, int64_t min_block, const lcb_block* blocks, int64_t n_blocks,

@@ -5,5 +5,5 @@ The product is the C-ABI shared library `libsibeliaz_amd.so` (HIP kernels for gf
 the tests, `bench.py` and the multi-GPU driver; names mirror the reference classes they stand for
 (JunctionStorage, BlocksFinder).
 """
-from .api import (LcbError, JunctionStorage, Device, Comm, Committer, BlocksFinder, Params, load_library, lib_path,  # noqa: F401
+from .api import (LcbError, JunctionStorage, Device, GpuSet, Comm, Committer, BlocksFinder, Params, load_library, lib_path,  # noqa: F401
                   SEED_DTYPE, INSTANCE_DTYPE, BLOCK_DTYPE, Hooks)

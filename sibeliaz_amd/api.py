@@ -82,7 +82,7 @@ EXPORTS = [
     "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_process_seeds_fp", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
     "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
-    "lcb_generate_output", "lcb_comm_unique_id", "lcb_comm_create", "lcb_comm_destroy", "lcb_find_blocks_comm", "lcb_find_blocks_gpus",
+    "lcb_generate_output", "lcb_comm_unique_id", "lcb_comm_create", "lcb_comm_destroy", "lcb_find_blocks_comm", "lcb_find_blocks_gpus", "lcb_gpus_create", "lcb_gpus_find_blocks", "lcb_gpus_destroy",
 ]
 
 
@@ -128,7 +128,13 @@ def load_library():
     L.lcb_device_set_used.argtypes = [vp, vp, i64]
     L.lcb_device_set_stats_mode.argtypes = [vp, C.c_int]
     L.lcb_process_seeds.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, C.POINTER(Counters)]
-    L.lcb_process_seeds_fp.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, vp, C.c_uint64]
+    if hasattr(L, "lcb_gpus_create"):
+        L.lcb_gpus_create.restype = vp
+        L.lcb_gpus_create.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+        L.lcb_gpus_find_blocks.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+        L.lcb_gpus_destroy.argtypes = [vp]
+    if hasattr(L, "lcb_process_seeds_fp"):      # (absent from older experiment libraries named by LCB_LIB)
+        L.lcb_process_seeds_fp.argtypes = [vp, vp, i64, vp, vp, C.c_uint64, vp, vp, C.c_uint64]
     L.lcb_device_hbm_triad.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.lcb_device_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.lcb_committer_create.restype = vp
@@ -422,6 +428,28 @@ class Committer:
         return _np_from(p, n.value, np.dtype("<u4"))
 
 
+class GpuSet:
+    """lcb_gpus: several GPUs of this node driven from one process - devices created, tables uploaded and RCCL initialised once."""
+
+    def __init__(self, storage, params, ordinals, always_comm=False, **device_opts):
+        self.L = load_library()
+        self.params = params
+        o = DeviceOpts()
+        for k, v in device_opts.items():
+            setattr(o, k, int(v))
+        ords = (C.c_int * len(ordinals))(*ordinals)
+        self.h = self.L.lcb_gpus_create(storage.h, ords, len(ordinals), C.byref(params), C.byref(o), 1 if always_comm else 0)
+        if not self.h:
+            raise _err(self.L)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcb_gpus_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class BlocksFinder:
     """Sibelia::BlocksFinder (blocksfinder.h:178): FindBlocks on one GPU, then GenerateOutput."""
 
@@ -432,6 +460,24 @@ class BlocksFinder:
         self.blocks = None
         self.stats = None
         self.params = None
+
+    def FindBlocksOnSet(self, gpus, seeds=None, threads=1, **engine):
+        """One pass on a persistent GpuSet (tables resident, RCCL initialised): what bench.py --gpus N times."""
+        self.params = gpus.params
+        hooks = Hooks()
+        hooks.world = 1
+        for k, v in engine.items():
+            if k not in ENGINE_KNOBS:
+                raise TypeError("unknown engine knob %r" % k)
+            setattr(hooks, k, int(v))
+        s = self.storage.seeds(threads) if seeds is None else np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        out, n, st = C.c_void_p(), C.c_int64(), Stats()
+        if self.L.lcb_gpus_find_blocks(gpus.h, s.ctypes.data, len(s), C.byref(hooks), C.byref(out), C.byref(n), C.byref(st)):
+            raise _err(self.L)
+        self.blocks = _np_from(out.value, n.value, BLOCK_DTYPE)
+        self.L.lcb_free(out)
+        self.stats = {f: getattr(st, f) for f, _ in Stats._fields_}
+        return self.blocks
 
     def FindBlocksGpus(self, minBlockSize, maxBranchSize, ordinals, seeds=None, threads=1, device_opts=None, **engine):
         """FindBlocks on several GPUs from this process (one host thread per GPU, RCCL all-gather between them)."""

@@ -301,6 +301,30 @@ int lcb_find_blocks_gpus(const lcb_graph* g, const int* device_ordinals, int n_d
     LCB_CATCH(LCB_ERR)
 }
 
+struct lcb_gpus { lcb_gpus_impl* impl; };
+lcb_gpus* lcb_gpus_create(const lcb_graph* g, const int* device_ordinals, int n_devices, const lcb_params* p, const lcb_device_opts* opts, int always_comm)
+{
+    LCB_TRY
+    if (!g || !device_ordinals || !p) throw LcbError("lcb_gpus_create: null argument");
+    return new lcb_gpus{lcb_gpus_create_impl(g, device_ordinals, n_devices, p, opts, always_comm != 0)};
+    LCB_CATCH(nullptr)
+}
+int lcb_gpus_find_blocks(lcb_gpus* m, const lcb_seed* seeds, int64_t n_seeds, const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats)
+{
+    LCB_TRY
+    LCB_NEED(m && m->impl && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_gpus_find_blocks");
+    std::vector<lcb_block> v;
+    lcb_gpus_find_blocks_impl(m->impl, seeds, n_seeds, tuningOf(hooks), v, stats);
+    return giveBlocks(v, blocks, n_blocks);
+    LCB_CATCH(LCB_ERR)
+}
+void lcb_gpus_destroy(lcb_gpus* m)
+{
+    if (!m) return;
+    try { lcb_gpus_destroy_impl(m->impl); } catch (...) {}
+    delete m;
+}
+
 int lcb_generate_output(const lcb_graph* g, int64_t min_block, const lcb_block* blocks, int64_t n_blocks, int64_t blocks_found,
                         const char* out_dir, int gen_seq, int64_t chunks, int64_t* n_trimmed, double* coverage)
 {

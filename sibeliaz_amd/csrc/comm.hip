@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -35,6 +36,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -52,6 +54,7 @@ Rccl& rccl()
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
@@ -150,50 +153,86 @@ void lcb_comm_fill_config(lcb_comm* c, LcbEngineConfig& cfg)
 }
 
 // BlocksFinder::FindBlocks on n GPUs of this node from ONE process: a device and a host thread per GPU, an RCCL
-// communicator over them (ncclCommInitAll); every thread runs the engine as one rank. Returns rank 0's blocks and stats
+// communicator over them (ncclCommInitAll); every thread runs the engine as one rank. The set is persistent: tables are uploaded
+// and RCCL is initialised once (lcb_gpus_create), every lcb_gpus_find_blocks is one pass. Returns rank 0's blocks and stats
 // (all ranks hold the same; that is checked).
-void lcb_find_blocks_gpus_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts,
-                               const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats)
+struct lcb_gpus_impl {
+    const lcb_graph* g = nullptr;
+    lcb_params p{};
+    std::vector<int> ordinals;
+    std::vector<lcb_device*> dev;
+    std::vector<lcb_comm*> comm;
+    bool broken = false;
+    ~lcb_gpus_impl() { for (auto c : comm) lcb_comm_destroy_impl(c); for (auto d : dev) lcb_device_destroy_impl(d); }
+};
+
+lcb_gpus_impl* lcb_gpus_create_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts, bool alwaysComm)
 {
-    if (n < 1) throw LcbError("lcb_find_blocks_gpus: no devices");
-    std::vector<lcb_device*> dev((size_t)n, nullptr);
-    std::vector<lcb_comm*> comm((size_t)n, nullptr);
+    if (n < 1) throw LcbError("lcb_gpus_create: no devices");
+    std::unique_ptr<lcb_gpus_impl> m(new lcb_gpus_impl());
+    m->g = g; m->p = *p; m->ordinals.assign(ordinals, ordinals + n);
+    m->dev.assign((size_t)n, nullptr); m->comm.assign((size_t)n, nullptr);
+    std::vector<std::string> err((size_t)n);
+    {   // tables are uploaded to all GPUs at the same time
+        std::vector<std::thread> th;
+        for (int r = 0; r < n; r++) th.emplace_back([&, r]() { try { m->dev[(size_t)r] = lcb_device_create_impl(g, p, ordinals[r], opts); } catch (std::exception& e) { err[(size_t)r] = e.what(); } });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < n; r++) if (!err[(size_t)r].empty()) throw LcbError("GPU " + std::to_string(ordinals[r]) + ": " + err[(size_t)r]);
+    }
+    if (n > 1 || alwaysComm) {
+        std::vector<ncclComm_t> cs((size_t)n);
+        RCCL_CHECK(rccl().CommInitAll(cs.data(), n, ordinals));
+        for (int r = 0; r < n; r++) m->comm[(size_t)r] = wrapComm(cs[(size_t)r], ordinals[r], r, n);
+    }
+    return m.release();
+}
+
+void lcb_gpus_destroy_impl(lcb_gpus_impl* m) { delete m; }
+int lcb_gpus_count_impl(const lcb_gpus_impl* m) { return (int)m->dev.size(); }
+
+void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats)
+{
+    const int n = (int)m->dev.size();
     std::vector<std::vector<lcb_block>> out((size_t)n);
     std::vector<lcb_stats> st((size_t)n);
     std::vector<std::string> err((size_t)n);
-    auto cleanup = [&]() { for (auto c : comm) lcb_comm_destroy_impl(c); for (auto d : dev) lcb_device_destroy_impl(d); };
-    try {
-        {   // tables are uploaded to all GPUs at the same time
-            std::vector<std::thread> th;
-            for (int r = 0; r < n; r++) th.emplace_back([&, r]() { try { dev[(size_t)r] = lcb_device_create_impl(g, p, ordinals[r], opts); } catch (std::exception& e) { err[(size_t)r] = e.what(); } });
-            for (auto& t : th) t.join();
-            for (int r = 0; r < n; r++) if (!err[(size_t)r].empty()) throw LcbError("GPU " + std::to_string(ordinals[r]) + ": " + err[(size_t)r]);
-        }
-        if (n > 1 || cfg.exchangeAlways) {
-            std::vector<ncclComm_t> cs((size_t)n);
-            RCCL_CHECK(rccl().CommInitAll(cs.data(), n, ordinals));
-            for (int r = 0; r < n; r++) comm[(size_t)r] = wrapComm(cs[(size_t)r], ordinals[r], r, n);
-        }
-        std::vector<std::thread> th;
-        for (int r = 0; r < n; r++)
-            th.emplace_back([&, r]() {
-                try {
-                    LcbEngineConfig c = cfg;
-                    c.progress = cfg.progress && r == 0;
-                    if (comm[(size_t)r]) lcb_comm_fill_config(comm[(size_t)r], c);
-                    lcb_find_blocks_impl(g, dev[(size_t)r], p, seeds, nSeeds, c, out[(size_t)r], &st[(size_t)r]);
-                } catch (std::exception& e) { err[(size_t)r] = e.what(); }
-            });
-        for (auto& t : th) t.join();
-        for (int r = 0; r < n; r++) if (!err[(size_t)r].empty()) throw LcbError("rank " + std::to_string(r) + ": " + err[(size_t)r]);
-        for (int r = 1; r < n; r++)
-            if (out[(size_t)r].size() != out[0].size() || (out[0].size() && memcmp(out[(size_t)r].data(), out[0].data(), out[0].size() * sizeof(lcb_block)) != 0))
-                throw LcbError("ranks ended with different block lists");
-        blocks.swap(out[0]);
-        if (stats) {
-            *stats = st[0];
-            for (int r = 1; r < n; r++) { stats->kernel_ms = std::max(stats->kernel_ms, st[(size_t)r].kernel_ms); stats->launches = std::max(stats->launches, st[(size_t)r].launches); }
-        }
-    } catch (...) { cleanup(); throw; }
-    cleanup();
+    if (m->broken) throw LcbError("lcb_gpus: the set was stopped by an earlier failure (its communicators were aborted)");
+    std::vector<std::thread> th;
+    std::mutex abortMutex;
+    for (int r = 0; r < n; r++)
+        th.emplace_back([&, r]() {
+            try {
+                LcbEngineConfig c = cfg;
+                c.progress = cfg.progress && r == 0;
+                if (m->comm[(size_t)r]) lcb_comm_fill_config(m->comm[(size_t)r], c);
+                lcb_find_blocks_impl(m->g, m->dev[(size_t)r], &m->p, seeds, nSeeds, c, out[(size_t)r], &st[(size_t)r]);
+            } catch (std::exception& e) {
+                err[(size_t)r] = e.what();
+                // A rank that fails outside the engine's own error exchange (a HIP error, a view pool that cannot grow ...) would leave
+                // the others blocked in their next all-gather and this call in join(): the communicators are aborted, once.
+                std::lock_guard<std::mutex> lock(abortMutex);
+                if (!m->broken && n > 1) {
+                    m->broken = true;
+                    for (auto c : m->comm) if (c && c->comm) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; }
+                }
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < n; r++) if (!err[(size_t)r].empty()) throw LcbError("rank " + std::to_string(r) + ": " + err[(size_t)r]);
+    for (int r = 1; r < n; r++)
+        if (out[(size_t)r].size() != out[0].size() || (out[0].size() && memcmp(out[(size_t)r].data(), out[0].data(), out[0].size() * sizeof(lcb_block)) != 0))
+            throw LcbError("ranks ended with different block lists");
+    blocks.swap(out[0]);
+    if (stats) {
+        *stats = st[0];
+        for (int r = 1; r < n; r++) { stats->kernel_ms = std::max(stats->kernel_ms, st[(size_t)r].kernel_ms); stats->launches = std::max(stats->launches, st[(size_t)r].launches); }
+    }
+}
+
+// the one-shot form (devices, tables and communicator live for one call)
+void lcb_find_blocks_gpus_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts,
+                               const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats)
+{
+    std::unique_ptr<lcb_gpus_impl> m(lcb_gpus_create_impl(g, ordinals, n, p, opts, cfg.exchangeAlways));
+    lcb_gpus_find_blocks_impl(m.get(), seeds, nSeeds, cfg, blocks, stats);
 }

@@ -623,6 +623,7 @@ void lcb_device_reset_used_impl(lcb_device* h)
     lcb_device_impl* d = h->impl;
     d->use();
     lcb_device_drain_lanes(d);
+    lcb_device_drop_async(d);       // (a launch begun for an overlapped round that never ended: the engine threw in between)
     if (d->views.lastViews) { HIP_CHECK(hipMemsetAsync(d->views.tab + d->nPages, 0, (size_t)d->views.lastViews * d->nPages * 4, d->stream)); d->views.lastViews = 0; }
     d->modeHint.clear();          // a new pass starts from scratch: no knowledge carried over from an earlier run
     d->recentBigFrac = 0;

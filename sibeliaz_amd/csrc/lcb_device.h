@@ -58,4 +58,11 @@ int lcb_device_ordinal_impl(lcb_device* d);
 void lcb_find_blocks_gpus_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts,
                                const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);
 
+// a persistent set of GPUs of this node driven from one process (one host thread per GPU inside every pass)
+struct lcb_gpus_impl;
+lcb_gpus_impl* lcb_gpus_create_impl(const lcb_graph* g, const int* ordinals, int n, const lcb_params* p, const lcb_device_opts* opts, bool alwaysComm);
+void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t nSeeds, LcbEngineConfig cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);
+void lcb_gpus_destroy_impl(lcb_gpus_impl* m);
+int lcb_gpus_count_impl(const lcb_gpus_impl* m);
+
 #endif

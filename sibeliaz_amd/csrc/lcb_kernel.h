@@ -587,24 +587,22 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 
 // ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
 // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717). Its scalars live in SGPRs.
-struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight, page, tabOff; int32_t dir; bool positive; };   // page / tabOff: the view's page-table entry at g0
-// uw: the RAW `used` word of the step and ub its bit - the shift happens where the step is consumed: a use of the loaded word at
-// the place of the load makes the compiler wait for it (and for every load before it) there, which turns the prefetch of the next
-// voter / chunk into a blocking round trip per call
-struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw, ub; bool valid; };
 
 // The voter walks of one vote. The voters are the instances of the touch list that are in the voting list (the good list
 // if it has two entries, else all instances; blocksfinder.h:713). Wave w of nWaves takes the voters with ordinal == w
 // (mod nWaves); all waves accumulate into the shared vote table with atomics, so the split needs no merging.
 // `exact`: the walks stop at vertices of the path (blocksfinder.h:736-741). Where the path set lives in the HBM slot behind an LDS
 // Bloom filter (compact, big, huge) a per-step membership test costs a dependent global round trip for every chunk in which the
-// filter says "maybe" for one lane - with a path of thousands of vertices that is almost every chunk (the filter is a quarter
-// full: a 64-lane chunk sees a false positive with probability > 0.9), and the walks of a vote with 60 voters paid ~100 such
-// round trips. A walk meets a path vertex only at repeats and rearrangements, so the first pass of a vote walks WITHOUT the
-// test (exact = false: only `used` positions and the window bound stop a walk) and the distinct vertices it touched - they are all in
-// the vote table - are checked afterwards, lane-parallel, once (lcb_vote_any_in_path). No hit: no walk can have met a path
-// vertex, the pass is what the reference computes. A hit: the table is cleared and the vote repeated with exact = true.
-// (Footprints of a discarded pass stay: a superset.)  Variants with the path set in LDS always walk exactly.
+// filter says "maybe" for one lane - with a path of thousands of vertices that is almost every chunk. A walk meets a path vertex
+// only at repeats and rearrangements, so the first pass of a vote walks WITHOUT the test (exact = false: only `used` positions and
+// the window bound stop a walk) and the distinct vertices it touched - they are all in the vote table - are checked afterwards,
+// lane-parallel, once (lcb_vote_any_in_path). No hit: no walk can have met a path vertex, the pass is what the reference computes.
+// A hit: the table is cleared and the vote repeated with exact = true. (Footprints of a discarded pass stay: a superset.) Variants
+// with the path set in LDS always walk exactly.
+// (Tried and measured slower on the MI355X, profiles/r03: requesting the next chunk of a voter ahead of time with unconditional,
+// straight-line loads - the main wavefront is bound by instruction issue, not by the round trips the prefetch hides.)
+struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
+struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 template <bool STATS, bool PROF = false, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
                                      uint32_t waveId, uint32_t nWaves, bool exact)
@@ -617,12 +615,11 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     const uint32_t nTouch = S.nTouch;
     uint32_t chunkBase = 0, ordinal = 0;
     unsigned long long pend = 0;
-    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0, fTab = 0;
+    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
     bool scanned = false;
     auto nextVoter = [&](LcbVoter& v) -> bool {
         for (;;) {
             while (pend == 0) {
-                const uint64_t ts0 = PROF ? wall_clock64() : 0;
                 if (scanned) chunkBase += 64;
                 scanned = true;
                 if (chunkBase >= nTouch) return false;
@@ -639,13 +636,9 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                         fPos = forward ? bp : fp;
                         fLo = S.iLo[fI]; fHi = S.iHi[fI];
                         fW = lcb_absdiff(fp, bp) + 1u;                                       // blocksfinder.h:719
-                        // the page-table entry of the view at the voter's end: its window (a few hundred positions) almost never
-                        // leaves that page, so the walk's `used` reads need no dependent table load
-                        if (S.U.tab && !tryUsed) fTab = LCB_GLOBAL_U32(S.U.tab)[fG >> (5u + LCB_PAGE_SHIFT)];
                     }
                 }
                 pend = __ballot(is);
-                if (PROF) S.pfTScan += wall_clock64() - ts0;
             }
             const uint32_t b = (uint32_t)__ffsll((long long)pend) - 1u;
             pend &= pend - 1;
@@ -655,56 +648,43 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
             const uint32_t hi = lcb_rl(fHi, b);
             v.weight = lcb_rl(fW, b);
-            v.page = v.g0 >> (5u + LCB_PAGE_SHIFT); v.tabOff = lcb_rl(fTab, b);
             v.positive = (lcb_rl(fFl, b) & LCB_FLAG_POS) != 0;
             v.dir = (forward == v.positive) ? 1 : -1;
             v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
             return true;
         }
     };
-    // The table reads of a chunk (position, id, `used` word) are independent and issued together - UNCONDITIONALLY (lanes beyond the
-    // chromosome end re-read the voter's own end, a view's page-table offset is the voter's: a lane in another page is repaired at the
-    // consumer), so that the chunk is straight-line code with a fixed number of loads: the compiler can then wait for exactly the
-    // loads a consumer needs (s_waitcnt vmcnt(n)) and the requests for the NEXT voter's first chunk and for this voter's next chunk,
-    // issued before the current chunk is consumed, stay in flight behind its LDS work. (With the loads inside `if (valid)` blocks the
-    // number in flight was unknown and every consumer waited for all of them - a round trip per chunk.)
+    // The table reads of a pass (pos, id, used word) are independent and issued together; the first pass of the NEXT
+    // voter is issued before the current one is consumed, so its latency hides behind the LDS work of this one.
     auto issue = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
         LcbWalk w;
         const uint32_t d = c * 64 + S.lane + 1;
         w.valid = d <= v.rem;                                                               // it.Valid()
-        const uint32_t dd = w.valid ? d : 0u;
-        w.g = v.dir > 0 ? v.g0 + dd : v.g0 - dd;
-        // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start: any bit, ignored by the consumer)
-        const uint32_t ub = w.g - ((v.positive || w.g <= v.lo) ? 0u : 1u);
-        const uint32_t uwi = ub >> 5;
-        w.ub = (ub & 31u) | (((uwi >> LCB_PAGE_SHIFT) != v.page) ? 32u : 0u);               // bit 5: not the page v.tabOff belongs to
-        w.pos = T.posPos[w.g];
-        w.id = T.posId[w.g];
-        w.uw = S.U.live[uwi + v.tabOff];                                                    // (tabOff 0 without a view)
+        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
+        w.pos = 0; w.id = 0; w.uw = 0;
+        if (w.valid) {
+            w.pos = T.posPos[w.g];
+            w.id = T.posId[w.g];
+            // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
+            const uint32_t ub = w.g - (v.positive ? 0u : 1u);
+            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, ub >> 5) >> (ub & 31);
+        }
         return w;
     };
     LcbVoter cur, nxt;
-    LcbWalk wcur, wnxt, wahead;
+    LcbWalk wcur, wnxt;
     bool have = nextVoter(cur);
     if (have) wcur = issue(cur, 0);
     while (have) {
         const bool haveNext = nextVoter(nxt);
-        if (!haveNext) nxt = cur;
-        wnxt = issue(nxt, 0);                           // (after the last voter: a repeat of its own first chunk, nobody reads it)
+        if (haveNext) wnxt = issue(nxt, 0);
         for (uint32_t c = 0;; c++) {
-            const LcbWalk w = c == 0 ? wcur : wahead;
-            wahead = issue(cur, c + 1);                 // chunk c + 1 is requested before chunk c is consumed
+            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
             if (PROF) S.pfChunks++;
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
             const int32_t vid = cur.positive ? w.id : -w.id;
-            uint32_t usedBit = 0;
-            if (!tryUsed && cond && (cur.positive || w.g > cur.lo)) {
-                usedBit = (w.uw >> (w.ub & 31u)) & 1u;
-                if (S.U.tab && (w.ub & 32u)) usedBit = lcb_used_bit(S.U, w.g - (cur.positive ? 0u : 1u)) ? 1u : 0u;   // the window left the voter's page (rare)
-            }
-            bool stop = usedBit != 0;
-            if (exact && cond && !stop) stop = lcb_path_contains(S, vid);
+            const bool stop = cond && ((w.uw & 1u) != 0 || (exact && lcb_path_contains(S, vid)));
             const unsigned long long failM = __ballot(!cond);
             const unsigned long long stopM = __ballot(stop);
             const unsigned long long endM = failM | stopM;

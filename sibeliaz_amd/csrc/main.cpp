@@ -137,7 +137,12 @@ int main(int argc, char** argv)
             lcb_hooks hk;
             memset(&hk, 0, sizeof(hk));
             hk.world = 1; hk.progress = 1;
-            if (lcb_find_blocks_gpus(g, ord.data(), nGpus, &p, nullptr, seeds, nSeeds, &hk, &blocks, &nBlocks, &st) != LCB_OK) { fail(); break; }
+            // the same handle bench.py --gpus N times: devices + tables + RCCL once, then one pass
+            lcb_gpus* set = lcb_gpus_create(g, ord.data(), nGpus, &p, nullptr, 0);
+            if (!set) { fail(); break; }
+            const int rc = lcb_gpus_find_blocks(set, seeds, nSeeds, &hk, &blocks, &nBlocks, &st);
+            lcb_gpus_destroy(set);
+            if (rc != LCB_OK) { fail(); break; }
         } else {
             dev = lcb_device_create(g, &p, devEnv && *devEnv ? atoi(devEnv) : 0);
             if (!dev) { fail(); break; }

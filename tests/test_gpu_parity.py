@@ -296,3 +296,18 @@ def test_footprints_cover_every_read_on_gpu(built, case, mode):
         off2, inst2, _, _ = dev.process_seeds_fp(seeds[i:i + 1])
         assert inst2.tobytes() == inst[int(off[i]):int(off[i + 1])].tobytes(), "seed %d: a read outside its footprint changed the result (variant %d)" % (i, mode)
     dev.reset_used()
+
+
+def test_persistent_gpu_set(built, case):
+    """lcb_gpus_create / lcb_gpus_find_blocks / lcb_gpus_destroy: devices, tables and the RCCL communicator live across passes (the handle
+    bench.py --gpus N and sibeliaz-lcb LCB_GPUS=N use) - with the one GPU of the test box, forced through the exchange path; two passes."""
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, threads=4, abundance=case.a)
+    p = sibeliaz_amd.Params.make(case.k, b=case.b, m=case.m)
+    gpus = sibeliaz_amd.GpuSet(st, p, [0], always_comm=True)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    for _ in range(2):
+        blocks = finder.FindBlocksOnSet(gpus, threads=4, exchange_always=1)
+        got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+        assert got == case.golden("pretrim.tsv")
+        assert finder.stats["exchanges"] > 0
+    gpus.close()
