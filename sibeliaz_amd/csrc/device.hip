@@ -44,8 +44,8 @@
 #define LCB_NW_WIDE 16
 #endif
 #ifndef LCB_NW_BIG
-#define LCB_NW_BIG 8
-#endif
+#define LCB_NW_BIG 16         // 16 wavefronts share the votes of the seeds with dozens of voters: -3.5 % on a config-3 pass against 8 (same box,
+#endif                        // profiles/r03/ab_calls_5_to_12.txt), nothing on the k = 25 workloads (their paths have few voters)
 #ifndef LCB_NW_COMPACT
 #define LCB_NW_COMPACT 2      // one helper wavefront: -10 % on the compact launches of the 62-strain workload; 4 brings nothing more
 #endif

@@ -167,6 +167,7 @@ struct Emu {
         else if (noStats && mode == 1 && nw == 16) EMU_RUN(1, false, 16, true);
         else if (noStats && mode == 2 && nw == 1) EMU_RUN(2, false, 1, true);
         else if (noStats && mode == 2 && nw == 8) EMU_RUN(2, false, 8, true);
+        else if (noStats && mode == 2 && nw == 16) EMU_RUN(2, false, 16, true);
         else if (noStats && mode == 3 && nw == 1) EMU_RUN(3, false, 1, true);
         else if (noStats && mode == 3 && nw == 8) EMU_RUN(3, false, 8, true);
         else if (!noStats && mode == 0 && nw == 1) EMU_RUN(0, true, 1, false);
