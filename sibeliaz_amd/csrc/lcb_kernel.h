@@ -885,6 +885,17 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
     if (PROF) S.pfVote++;
     originInst = 0;
     if (nList == 0 || S.nTouch == 0) return 0;                     // nobody votes: nothing to walk, nothing to clear
+#ifndef LCB_COMPACT_HEAVY
+#define LCB_COMPACT_HEAVY 32u
+#endif
+#ifndef LCB_COMPACT_HEAVY_PUSHES
+#define LCB_COMPACT_HEAVY_PUSHES 1024u
+#endif
+    // The compact variant walks a vote with two wavefronts: a path that has dozens of voters and is past a thousand pushes is handed
+    // to the wide variant (16 wavefronts) through the overflow ladder instead of crawling on here at tens of microseconds per vote
+    // and holding up its whole launch. Only the few extreme seeds: the wide variant runs one seed per CU, and with lower thresholds
+    // (24 voters / 32 pushes: 1.2 M seeds of a config-3 pass; 32 / 384: 325 k) the pass was 47 % / 17 % slower (profiles/r03).
+    if (ST::MODE == 0 && NW <= 2 && LCB_COMPACT_HEAVY && S.nTouch >= LCB_COMPACT_HEAVY && S.nRight + S.nLeft >= LCB_COMPACT_HEAVY_PUSHES) { S.status = LCB_ST_INST_OVF; return 0; }
     // path set behind a Bloom filter: the first pass walks without path stops and is verified afterwards (lcb_vote_walk)
     constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
     const uint64_t cWalk0 = S.cWalk;
