@@ -109,8 +109,10 @@ def md5(path):
     return h.hexdigest()
 
 
-def run_reference(w, threads, tag):
-    """One run of the unmodified reference: (analyze seconds banner to banner, whole-process seconds, gff path) or None."""
+def run_reference(w, threads, tag, limit_s=None):
+    """One run of the unmodified reference: (analyze seconds banner to banner, whole-process seconds, gff path); None if it is not
+    there or failed; the string "timeout" if it ran longer than limit_s (it is killed: every leg of the protocol is bounded)."""
+    import threading
     ref = os.path.join(ROOT, "oracle", "_ref", "sibeliaz-lcb-ref")
     if not os.path.exists(ref):
         return None
@@ -119,6 +121,12 @@ def run_reference(w, threads, tag):
            "-o", out, "--noseq"]
     t0 = time.time()
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=0)
+    killed = []
+    timer = None
+    if limit_s:
+        timer = threading.Timer(limit_s, lambda: (killed.append(1), p.kill()))
+        timer.daemon = True
+        timer.start()
     marks, buf = {}, ""
     while True:
         ch = p.stdout.read(1)
@@ -131,7 +139,11 @@ def run_reference(w, threads, tag):
                     marks[key] = time.time()
             buf = ""
     p.wait()
+    if timer:
+        timer.cancel()
     wall = time.time() - t0
+    if killed:
+        return "timeout"
     if p.returncode != 0 or len(marks) < 2:
         return None
     return marks["Generating the output..."] - marks["Analyzing the graph..."], wall, os.path.join(out, "blocks_coords.gff")
@@ -159,19 +171,25 @@ def our_gff(w, threads, dev_ordinal=0):
     return os.path.join(out, "blocks_coords.gff")
 
 
-def cpu_baseline(workload, threads, full, our_gff_path):
-    """SURVEY.md §8d protocol: the reference at -t 32 on the WHOLE workload (one run; its GFF must equal the timed run's), and on
-    bounded samples at -t 1 / -t 64 / -t <all hardware threads>, median of 3, analyze time banner to banner."""
+def cpu_baseline(workload, threads, full, our_gff_path, budget_s=600.0):
+    """SURVEY.md §8d protocol, every leg bounded: the reference on bounded samples at -t 1 / -t 32 / -t 64 / -t <all hardware threads>
+    (median of 3, analyze time banner to banner; its GFF on the -t 32 sample must equal ours), then ONE run at -t 32 on the WHOLE
+    workload `value` is measured on, with what is left of budget_s as its limit; if it finishes, its GFF must equal the timed run's
+    and it is the reported figure, otherwise the -t 32 sample is."""
     host = os.cpu_count() or 1
+    t_start = time.time()
     small_name, tiny_name = SAMPLES[workload]
     whole, small, tiny = ensure_workload(workload), ensure_workload(small_name), ensure_workload(tiny_name)
     s_whole, s_small, s_tiny = n_seeds_of(whole, threads), n_seeds_of(small, threads), n_seeds_of(tiny, threads)
     per_t = {}
 
-    def leg(t, w, s, reps, tag):
+    def leg(t, w, s, reps, tag, limit_s):
         runs = []
         for rep in range(reps):
-            r = run_reference(w, t, tag)
+            r = run_reference(w, t, tag, limit_s)
+            if r == "timeout":
+                per_t[tag] = {"threads": t, "timeout_s": limit_s, "sample": w["desc"], "sample_seeds": s}
+                return "timeout"
             if r is None:
                 return None
             runs.append(r)
@@ -181,30 +199,35 @@ def cpu_baseline(workload, threads, full, our_gff_path):
         return runs[-1][2]
 
     t32 = min(32, host)
-    same_full = None
-    if full:
-        gff_ref = leg(t32, whole, s_whole, 1, "t%d_whole" % t32)
-        if gff_ref is None:
-            return None
-        same_full = md5(gff_ref) == md5(our_gff_path)
-    if leg(1, tiny, s_tiny, 3, "t1_sample") is None:
+    if leg(1, tiny, s_tiny, 3, "t1_sample", 120) is None:
         return None
-    gff_small = leg(t32, small, s_small, 3, "t%d_sample" % t32)
-    if gff_small is None:
+    gff_small = leg(t32, small, s_small, 3, "t%d_sample" % t32, 120)
+    if gff_small is None or gff_small == "timeout":
         return None
     for t in sorted({min(64, host), host} - {t32}):
-        if leg(t, small, s_small, 3, "t%d_sample" % t) is None:
+        if leg(t, small, s_small, 1 if t == host and host > 64 else 3, "t%d_sample" % t, 90) is None:
             return None
     same_small = md5(gff_small) == md5(our_gff(small, threads))
-    top = per_t["t%d_whole" % t32] if full else per_t["t%d_sample" % t32]
+    same_full, whole_tag = None, "t%d_whole" % t32
+    if full:
+        left = budget_s - (time.time() - t_start)
+        if left > 60:
+            gff_ref = leg(t32, whole, s_whole, 1, whole_tag, left)
+            if gff_ref is None:
+                return None
+            if gff_ref != "timeout":
+                same_full = md5(gff_ref) == md5(our_gff_path)
+    on_whole = same_full is not None
+    top = per_t[whole_tag] if on_whole else per_t["t%d_sample" % t32]
     return {"value": top["seeds_per_s"], "unit": "seeds/s", "cores": t32, "kind": "reference",
             "sample": "%s%s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %d, %d run(s), 'Analyzing' to 'Generating' banner %.2f s "
-                      "(includes its serial seed enumeration); host has %d hardware threads" % (
-                          "the WHOLE benchmarked workload, " if full else "", top["sample"], t32, top["runs"], top["analyze_s_median"], host),
-            "gff_md5_equal": same_full if full else bool(same_small), "gff_md5_equal_on_sample": bool(same_small),
+                      "(includes its serial seed enumeration); host has %d hardware threads%s" % (
+                          "the WHOLE benchmarked workload, " if on_whole else "", top["sample"], t32, top["runs"], top["analyze_s_median"], host,
+                          "" if on_whole or not full else "; the run on the whole workload did not finish within its limit (legs['%s'])" % whole_tag),
+            "gff_md5_equal": same_full if on_whole else bool(same_small), "gff_md5_equal_on_sample": bool(same_small),
             "legs": per_t,
             "note": "legs named *_sample run on the bounded samples named in them (1/10 of the segments; 1/40 for -t 1); the reference's own wrapper caps -t at 32 "
-                    "(sibeliaz:139); more threads than that are slower on this input (the legs show it)"}
+                    "(sibeliaz:139); every leg has a time limit so that the default run stays within minutes"}
 
 
 def source_hash():
@@ -232,7 +255,8 @@ def main():
     ap.add_argument("--sample-cpu-baseline", action="store_true", help="time the reference on the bounded samples only (not on the whole workload)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
-    ap.add_argument("--trust-counts", action="store_true", help="use the committed event counts although another build counted them (exploration runs)")
+    ap.add_argument("--verify-counts", action="store_true", help="count the events again (a 3-minute stats-mode pass) when the committed counts were counted by a build of other sources; "
+                    "they are a property of input and parameters, so the default run uses them as they are")
     ap.add_argument("--write-counts", action="store_true", help="store the counts of this run's counting pass in bench_event_counts.json (with the hash of the sources)")
     ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
@@ -351,8 +375,8 @@ def main():
             # the counts are a property of (input, parameters): the ones of the named workloads are kept in bench_event_counts.json
             # (counted by `bench.py --recount` on the MI355X) so that a default run need not repeat the 3-minute counting pass
             known = json.load(open(os.path.join(ROOT, "bench_event_counts.json"))).get(args.workload) if os.path.exists(os.path.join(ROOT, "bench_event_counts.json")) else None
-            # they are a property of (input, parameters); a build other than the one that counted them counts them again in this run
-            if known and not args.recount and known["lcb_synth"] == w["synth"] and known["seeds"] == S and (known.get("source_hash") == source_hash() or args.trust_counts):
+            # (--verify-counts counts them again when other sources than the ones of this build counted them)
+            if known and not args.recount and known["lcb_synth"] == w["synth"] and known["seeds"] == S and (known.get("source_hash") == source_hash() or not args.verify_counts):
                 ctr = known["event_counts"]
             elif os.path.exists(ctr_file) and not args.recount:
                 ctr = json.load(open(ctr_file))
@@ -408,7 +432,9 @@ def main():
                          "peak_measured_stream_triad": triad, "frac_of_measured_peak": achieved / triad if triad > 0 else None,
                          "event_counts": ctr,
                          "note": "latency-bound integer walk: a launch is as long as its longest seed; n_compat_step of the counting pass is an upper bound within 1% "
-                                 "(speculative results walk older bitmaps), everything else is exact"},
+                                 "(speculative results walk older bitmaps), everything else is exact. kernel_ms_per_step is the SUM of the hipEvent-timed durations of every "
+                                 "process-kernel launch on every stream: the background (side-lane) kernels overlap the synchronous ones, so the sum can exceed the time the "
+                                 "GPU was busy and even ms_per_step - it is what a rocprofv3 --stats table of the same command sums to"},
         }
         if dev is not None:
             dev.close()
@@ -423,9 +449,12 @@ def main():
             line["wall_clock"] = {"sibeliaz_lcb_process_s": time.time() - t, "rc": r.returncode, "threads": args.threads,
                                   "gff_md5_equal_to_timed_run": r.returncode == 0 and md5(os.path.join(cli_out, "blocks_coords.gff")) == md5(gff)}
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload in SAMPLES:
-            cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff)
-            if cb:
-                line["cpu_baseline"] = cb
+            try:
+                cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff)
+                if cb:
+                    line["cpu_baseline"] = cb
+            except Exception as e:       # the reference's legs must never cost the line itself
+                line["cpu_baseline_error"] = repr(e)
         print(json.dumps(line), flush=True)
     if world > 1:
         comm.close()

@@ -99,6 +99,8 @@ typedef struct {
     int64_t side_taken;         /* ... results taken when the commit reached their seed */
     int64_t side_void;          /* ... jobs dropped: a mark of their view did not come true, superseded, or the round ended */
     int64_t side_failed;        /* ... jobs that ended without a result (stopped, or needed another kernel variant) */
+    int64_t device_commits;     /* results validated, conflict-checked and marked used by the device-side commit kernel (the host mirrors them) */
+    int64_t device_rounds;      /* ... rounds it committed from the first to the last seed */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -233,6 +235,10 @@ typedef struct {
                                    on configs 2 and 3, so off by default) */
     int32_t relax_views;        /* 1 (experimental, needs a library built with -DLCB_PATH_SIG=1; an error otherwise): a predicted mark
                                    that did not come true voids a job's result only if the job can have read it */
+    int32_t device_commit;      /* 1: the clean prefix of every round - phase-start results that are still exact, results that pass the weak
+                                   conflict check - is validated, committed and marked used by a kernel on the device (lcb_commit_kernel); the
+                                   host mirrors those commits and takes over at the first seed that needs a new computation.
+                                   Off by default: exact under the CPU wavefront emulator, not yet run on the MI355X (round 3 ran out of GPU time) */
     int32_t sync_jobs;          /* 1: do not use the device's side lanes - every job of a stop's plan runs in one synchronous launch
                                    (the round-2 engine; for A/B runs and tests) */
 } lcb_hooks;

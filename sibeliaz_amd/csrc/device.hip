@@ -133,6 +133,10 @@ __global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* liv
     }
 }
 
+// The device-side ordered commit of a round's clean prefix (lcb_commit_body, lcb_kernel.h): one workgroup.
+#define LCB_NW_COMMIT 8
+__global__ __launch_bounds__(64 * LCB_NW_COMMIT) void lcb_commit_kernel(LcbCommitArgs A) { lcb_commit_body<LCB_NW_COMMIT>(A); }
+
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
 __global__ __launch_bounds__(256) void lcb_triad_kernel(float4* a, const float4* b, const float4* c, float s, size_t n)
 {
@@ -208,6 +212,10 @@ struct lcb_device_impl {
     hipStream_t ctlStream = nullptr;             // stop flags of the lanes are written from here
     uint32_t lanePoolPages = 0;                  // private pages per lane (fixed: the live bitmap cannot move while a lane is running)
     int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0;
+    // device-side commit (commitRound): marks of the current round, per-chromosome phase stamps, the round's results of the live seeds
+    uint32_t* dDelta = nullptr; uint32_t* dChrStamp = nullptr; uint32_t* dCommitBuf = nullptr; size_t commitBufWords = 0;
+    uint32_t* hCommitOut = nullptr; size_t commitOutCap = 0;
+    int64_t commitCalls = 0;
     struct lcb_async_call* async = nullptr;      // the call begun with processBegin and not yet ended
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
@@ -587,6 +595,8 @@ void lcb_device_destroy_impl(lcb_device* h)
             for (void* q : {(void*)L.hSeeds, (void*)L.hOut, (void*)L.hArena, (void*)L.hFp, (void*)L.hList, (void*)L.hCtl}) if (q) (void)hipHostFree(q);
             for (void* q : {(void*)L.dCtl, (void*)L.views.tab, (void*)L.views.dEntries, (void*)L.views.dVersions, (void*)L.views.dPieces, (void*)L.wide.base, (void*)L.big.base}) if (q) (void)hipFree(q);
         }
+        for (void* q : {(void*)d->dDelta, (void*)d->dChrStamp, (void*)d->dCommitBuf}) if (q) (void)hipFree(q);
+        if (d->hCommitOut) (void)hipHostFree(d->hCommitOut);
         if (d->ctlStream) (void)hipStreamDestroy(d->ctlStream);
         if (d->views.tab) (void)hipFree(d->views.tab);
         if (d->views.dEntries) (void)hipFree(d->views.dEntries);
@@ -1099,6 +1109,62 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
     d->wantFp = false;
 }
 
+// ---- device-side ordered commit (LcbProcessor::commitRound) ----------------------------------------------------------------
+// The round's results of the live seeds are handed back to the device in one buffer (they were gathered from several launches and
+// kernel variants), the commit kernel walks them against the live bitmap and reports what it committed and where it stopped.
+bool lcb_device_commit_round_impl(lcb_device* h, const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
+                                  const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
+                                  std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
+{
+    lcb_device_impl* d = h->impl;
+    if (d->stats || live.empty() || phase <= 0) return false;
+    d->use();
+    const size_t nLive = live.size();
+    static_assert(sizeof(lcb_instance) == 16 && sizeof(lcb_fp) == 8, "layouts the commit kernel reads");
+    // one device buffer: seedIdx | off | fpOff | committed | result(4) | inst (16-B aligned) | fp
+    auto al4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
+    const size_t wSeed = 0, wOff = al4(wSeed + nLive), wFpOff = al4(wOff + nLive + 1), wCom = al4(wFpOff + nLive + 1), wRes = al4(wCom + nLive),
+                 wInst = al4(wRes + 4), wFp = al4(wInst + 4 * inst.size()), wEnd = al4(wFp + 2 * fp.size());
+    if (wEnd > d->commitBufWords) {
+        if (d->dCommitBuf) HIP_CHECK(hipFree(d->dCommitBuf));
+        d->commitBufWords = wEnd + wEnd / 2;
+        HIP_CHECK(hipMalloc((void**)&d->dCommitBuf, d->commitBufWords * 4));
+    }
+    if (!d->dDelta) {
+        HIP_CHECK(hipMalloc((void**)&d->dDelta, d->usedWords * 4));
+        HIP_CHECK(hipMalloc((void**)&d->dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
+    }
+    if (nLive + 4 > d->commitOutCap) {
+        if (d->hCommitOut) HIP_CHECK(hipHostFree(d->hCommitOut));
+        d->commitOutCap = (nLive + 4) * 2;
+        HIP_CHECK(hipHostMalloc((void**)&d->hCommitOut, d->commitOutCap * 4, hipHostMallocDefault));
+    }
+    HIP_CHECK(hipMemsetAsync(d->dDelta, 0, d->usedWords * 4, d->stream));
+    HIP_CHECK(hipMemsetAsync(d->dChrStamp, 0, ((size_t)d->g->nChr() + 1) * 4, d->stream));
+    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wSeed, live.data(), nLive * 4, hipMemcpyHostToDevice, d->stream));
+    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wOff, off.data(), (nLive + 1) * 4, hipMemcpyHostToDevice, d->stream));
+    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wFpOff, fpOff.data(), (nLive + 1) * 4, hipMemcpyHostToDevice, d->stream));
+    if (!inst.empty()) HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wInst, inst.data(), inst.size() * 16, hipMemcpyHostToDevice, d->stream));
+    if (!fp.empty()) HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wFp, fp.data(), fp.size() * 8, hipMemcpyHostToDevice, d->stream));
+    LcbCommitArgs A;
+    A.chrStart = d->T.chrStart; A.used = d->dUsed; A.delta = d->dDelta; A.chrStamp = d->dChrStamp;
+    A.seedIdx = d->dCommitBuf + wSeed; A.off = d->dCommitBuf + wOff; A.inst = (const uint4*)(d->dCommitBuf + wInst);
+    A.fpOff = d->dCommitBuf + wFpOff; A.fp = (const uint2*)(d->dCommitBuf + wFp);
+    A.nLive = (uint32_t)nLive; A.phase = (uint32_t)phase; A.nPos = d->T.nPos;
+    A.committed = d->dCommitBuf + wCom; A.result = d->dCommitBuf + wRes;
+    hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, d->stream, A);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(d->hCommitOut, d->dCommitBuf + wRes, 16, hipMemcpyDeviceToHost, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    const uint32_t nCom = d->hCommitOut[0];
+    stopAt = d->hCommitOut[1]; stopKind = (int)d->hCommitOut[2];
+    if (nCom > nLive || stopAt > nLive || stopKind < 0 || stopKind > 2) throw LcbError("device commit: inconsistent result");
+    committed.resize(nCom);
+    if (nCom) HIP_CHECK(hipMemcpy(committed.data(), d->dCommitBuf + wCom, (size_t)nCom * 4, hipMemcpyDeviceToHost));
+    d->commitCalls++;
+    return true;
+}
+
 // ---- side lanes: asynchronous job batches ---------------------------------------------------------------------------------
 // A batch = the speculative jobs of one stop of the ordered commit (engine.cpp). Its jobs run in the wide variant (16 wavefronts
 // per seed), the ones known to need it in the big variant, both kernels at once on the lane's two streams, against the lane's own
@@ -1275,6 +1341,11 @@ struct DeviceProcessor : LcbProcessor {
     }
     int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return lcb_device_side_poll_impl(dev, lane, k, wait, inst, fp); }
     void sideRelease(int lane) override { lcb_device_side_release_impl(dev, lane); }
+    bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst, const std::vector<uint32_t>& fpOff,
+                     const std::vector<lcb_fp>& fp, int64_t phase, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
+    {
+        return lcb_device_commit_round_impl(dev, live, off, inst, fpOff, fp, phase, committed, stopAt, stopKind);
+    }
 };
 
 }  // namespace
@@ -1299,5 +1370,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
+        stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds;
     }
 }

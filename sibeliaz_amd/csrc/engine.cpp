@@ -180,11 +180,11 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     int64_t begunN = 0;
     RangeSet sinceBegin;
     double lastInvalid = 1.0;
-    auto takeMarks = [&]() {
+    auto takeMarks = [&](bool alreadyInProcessor = false) {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
             epochMarks.back().add(com.marks[i], com.marks[i + 1]);
             if (begun) sinceBegin.add(com.marks[i], com.marks[i + 1]);
-            pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]);
+            if (!alreadyInProcessor) { pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]); }
         }
         com.marks.clear();
     };
@@ -207,6 +207,11 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<int32_t> liveIdx;
     auto liveFrom = [&](int64_t i) { return (size_t)(std::lower_bound(liveIdx.begin(), liveIdx.end(), (int32_t)i) - liveIdx.begin()); };
 
+    // ---- device-side commit (commitRound of the processor), one rank only
+    const bool useDevCommit = world == 1 && cfg.deviceCommit && !cfg.countEvents && !cfg.overlap && !(cfg.exchangeAlways && cfg.allgather);
+    std::vector<uint32_t> dcOff, dcFpOff, dcCommitted;
+    std::vector<lcb_instance> dcInst;
+    std::vector<lcb_fp> dcFp;
     // ---- asynchronous job batches (side lanes of the processor), one rank only
     const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !cfg.relaxViews && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
@@ -340,7 +345,6 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         liveIdx.clear();
         for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
         if (useSide) { sideJobs.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
-        frozenTo = 0;
         const int64_t recomputedBefore = st.recomputedSeeds;
 
         // the newest E result of seed i: instances / footprint / provenance
@@ -633,12 +637,51 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             }
         };
 
+        // ---- device-side commit of the round's clean prefix ---------------------------------------------
+        // The processor validates and commits in its own `used` state as far as no new computation is needed; the host mirrors
+        // those commits (block ids, BlockInstances, its copy of the bitmap) and takes over at the stop.
+        int64_t donePh = 0;                     // phases [0, donePh) of the round are committed
+        int64_t resumeAt = -1;                  // >= 0: the phase at donePh is validated and committed up to (not including) this seed, which conflicts
+        if (useDevCommit && !early && !liveIdx.empty()) {
+            const auto tp = std::chrono::steady_clock::now();
+            dcOff.assign(1, 0u); dcFpOff.assign(1, 0u); dcInst.clear(); dcFp.clear();
+            for (int32_t i : liveIdx) {
+                dcInst.insert(dcInst.end(), round.inst.begin() + round.off[i], round.inst.begin() + round.off[i + 1]);
+                dcFp.insert(dcFp.end(), round.fp.begin() + round.fpOff[i], round.fp.begin() + round.fpOff[i + 1]);
+                dcOff.push_back((uint32_t)dcInst.size()); dcFpOff.push_back((uint32_t)dcFp.size());
+            }
+            uint32_t stopAt = 0; int stopKind = 0;
+            dcCommitted.clear();
+            flush();                            // (nothing is pending at a round start; the processor's state is the round's)
+            if (proc.commitRound(liveIdx, dcOff, dcInst, dcFpOff, dcFp, phase, dcCommitted, stopAt, stopKind)) {
+                int64_t curPh = -1;
+                for (uint32_t q : dcCommitted) {
+                    const int64_t i = liveIdx[q], ph = i / phase;
+                    if (ph != curPh) { if (curPh >= 0) com.endPhase(); curPh = ph; }
+                    com.finalize(round.inst.data() + round.off[i], round.off[i + 1] - round.off[i]);
+                    takeMarks(true);
+                    st.deviceCommits++;
+                }
+                if (stopKind == 0) { donePh = nRound; if (curPh >= 0) com.endPhase(); st.deviceRounds++; }
+                else {
+                    const int64_t stopSeed = liveIdx[stopAt];
+                    donePh = (stopSeed / phase) * phase;
+                    if (curPh >= 0 && (curPh * phase < donePh || stopKind == 1)) com.endPhase();      // (a stop at a phase start: the previous phase is closed)
+                    if (stopKind == 2) resumeAt = stopSeed;                                                // ... inside a phase: its invalidChr_ stays
+                }
+                if (cfg.progress) for (int64_t i = ((pos + portion - 1) / portion) * portion; i < pos + donePh; i += portion) std::cout << '.' << std::flush;
+            }
+            st.processMs += msSince(tp);
+        }
+        frozenTo = donePh;
+
         // ---- walk the round's phases in order -----------------------------------------------------------------------
-        for (int64_t ph = 0; ph < nRound; ph += phase) {
+        for (int64_t ph = donePh; ph < nRound; ph += phase) {
             const int64_t n = std::min<int64_t>(phase, nRound - ph);
+            const bool resumed = resumeAt >= 0 && ph == donePh;       // the device validated this phase and committed its seeds before resumeAt
             // (a) exact phase-start results for every seed of the phase
-            const size_t lv0 = liveFrom(ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
-            for (;;) {
+            const size_t lv0 = liveFrom(resumed ? resumeAt : ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
+            for (; !resumed;) {
                 bool all = true;
                 for (size_t q = lv0; q < lv1 && all; q++) {
                     const int64_t i = liveIdx[q];
@@ -660,7 +703,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             }
             frozenTo = ph + n;
             // (b) ordered commit (blocksfinder.h:372-414)
-            if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;
+            if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;   // (a resumed phase prints its dots here)
             // the phase-start result of every seed is exact now: its events are the ones the reference's Process() call has
             if (cfg.countEvents) for (int64_t i = ph; i < ph + n; i++) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
             for (size_t q = lv0; q < lv1; q++) {

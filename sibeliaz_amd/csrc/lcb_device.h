@@ -40,6 +40,10 @@ int lcb_device_side_lanes_impl(lcb_device* d);
 int lcb_device_side_begin_impl(lcb_device* d, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_side_poll_impl(lcb_device* d, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp);
 void lcb_device_side_release_impl(lcb_device* d, int lane);
+// device-side ordered commit of a round's clean prefix (LcbProcessor::commitRound)
+bool lcb_device_commit_round_impl(lcb_device* d, const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
+                                  const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
+                                  std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind);
 double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);

@@ -122,6 +122,20 @@ struct LcbProcessor {
     }
     // Nobody will ask for the batch's results any more: its jobs stop at their next step, the lane is free once they have.
     virtual void sideRelease(int lane) { (void)lane; }
+
+    // ---- device-side ordered commit, optional. The clean prefix of a round - phase-start results that are still
+    // exact, results that pass the weak conflict check - is committed where the `used` state lives: the processor walks the round's
+    // live seeds in order (live[q]: index in the round, ascending; the instances inst[off[q] .. off[q+1]) and the footprint
+    // fp[fpOff[q] .. fpOff[q+1]) of each), marks what it commits in ITS state and stops at the first seed that needs a new
+    // computation. committed: the q's it committed, in order; stopAt / stopKind: where and why it stopped (stopKind 0: the whole
+    // round is committed, 1: a phase-start result of the phase that begins at live index stopAt is void, 2: seed stopAt conflicts).
+    // The state must be the one the round was launched against. false: not supported (the engine commits on the host).
+    virtual bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
+                             const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
+                             std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
+    {
+        (void)live; (void)off; (void)inst; (void)fpOff; (void)fp; (void)phase; (void)committed; (void)stopAt; (void)stopKind; return false;
+    }
 };
 
 // Side lanes for processors that have none of their own (the test stand-ins: callback, wavefront emulator, oracle model): a
@@ -193,6 +207,8 @@ struct LcbEngineConfig {
                               // footprint or holds an occurrence of one of the path's vertices. Every `used` read of Process() is of one of
                               // these kinds, so the rule is exact; today any such mark voids every later job of the launch.
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
+    bool deviceCommit = false; // use the processor's commitRound for the clean prefix of every round. Off by default: built and
+                              // exact under the wavefront emulator, but the GPU budget of round 3 was spent before it ran on the MI355X
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
 
@@ -204,6 +220,8 @@ struct LcbEngineStats {
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     int64_t earlyRounds = 0;      // rounds whose launch ran while the previous round was being committed
+    int64_t deviceCommits = 0;    // results committed by the processor itself (commitRound), and ...
+    int64_t deviceRounds = 0;     // ... rounds it committed completely
     int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)
     int64_t sideTaken = 0;        // ... results taken when the commit reached their seed (view came true)
     int64_t sideVoid = 0;         // ... jobs dropped because a mark of their view did not come true, or superseded by a newer plan

@@ -885,17 +885,9 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
     if (PROF) S.pfVote++;
     originInst = 0;
     if (nList == 0 || S.nTouch == 0) return 0;                     // nobody votes: nothing to walk, nothing to clear
-#ifndef LCB_COMPACT_HEAVY
-#define LCB_COMPACT_HEAVY 32u
-#endif
-#ifndef LCB_COMPACT_HEAVY_PUSHES
-#define LCB_COMPACT_HEAVY_PUSHES 1024u
-#endif
-    // The compact variant walks a vote with two wavefronts: a path that has dozens of voters and is past a thousand pushes is handed
-    // to the wide variant (16 wavefronts) through the overflow ladder instead of crawling on here at tens of microseconds per vote
-    // and holding up its whole launch. Only the few extreme seeds: the wide variant runs one seed per CU, and with lower thresholds
-    // (24 voters / 32 pushes: 1.2 M seeds of a config-3 pass; 32 / 384: 325 k) the pass was 47 % / 17 % slower (profiles/r03).
-    if (ST::MODE == 0 && NW <= 2 && LCB_COMPACT_HEAVY && S.nTouch >= LCB_COMPACT_HEAVY && S.nRight + S.nLeft >= LCB_COMPACT_HEAVY_PUSHES) { S.status = LCB_ST_INST_OVF; return 0; }
+    // (Tried and removed, profiles/r03: handing paths with dozens of voters from the compact to the wide variant through the overflow
+    // ladder. With low thresholds 10^5-10^6 seeds of a config-3 pass leave for the one-seed-per-CU wide variant (17-47 % slower); with
+    // 32 voters past 1 024 pushes config 3 gains 1 % and the k = 25 workloads, whose repeat families have a hundred voters, lose 8-28 %.)
     // path set behind a Bloom filter: the first pass walks without path stops and is verified afterwards (lcb_vote_walk)
     constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
     const uint64_t cWalk0 = S.cWalk;
@@ -1762,6 +1754,120 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
         base = lcb_rfl(base);
         if (alive) live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = s;
     }
+}
+
+// ---- device-side ordered commit -----------------------------------------------------
+// The thread-0 section of ProcessVertex::operator() (blocksfinder.h:372-414) with Finalize's MarkUsed (blocksfinder.h:312-332) for
+// the clean prefix of a round: ONE workgroup walks the round's live seeds in order, phase by phase -
+//   (a) phase start: the phase-start result of every live seed of the phase must still be exact: no bit inside its footprint has been
+//       marked since the round was launched (the marks of this round are kept in a second bitmap, `delta`);
+//   (b) ordered commit: a result of more than one instance whose instances touch no used position on the chromosomes committed to
+//       earlier in this phase (the weak check, blocksfinder.h:377-398) is finalised: its [Front, Back) ranges are marked in the live
+//       bitmap (and in delta) and the seed is appended to the committed list -
+// and stops at the first seed that needs a new computation (a void phase-start result, or a conflict: blocksfinder.h:406). The host
+// then assigns the block ids / BlockInstances of the committed seeds (blocksfinder.h:314-329) and goes on from the stop with its
+// planner. Validation is spread over the wavefronts of the workgroup, the commit itself is lane-parallel over instances and words.
+struct LcbCommitArgs {
+    const uint32_t* chrStart;      // [nChr+1]
+    uint32_t* used;                // the live bitmap (marked here)
+    uint32_t* delta;               // marks since the round was launched (cleared by the host before the kernel)
+    uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared by the host
+    const uint32_t* seedIdx;       // [nLive] index of the live seed in the round, ascending
+    const uint32_t* off;           // [nLive+1] into inst
+    const uint4* inst;             // (chr, front idx, back idx, strand)
+    const uint32_t* fpOff;         // [nLive+1] into fp
+    const uint2* fp;               // footprint intervals [lo, hi] over flat positions
+    uint32_t nLive, phase, nPos;   // phase: seeds per phase (256); nPos: positions of the bitmaps
+    uint32_t* committed;           // out: live indices of the committed seeds, in order
+    uint32_t* result;              // out: [0] number of committed seeds, [1] live index of the stop (nLive: none), [2] 0 none / 1 phase start / 2 conflict
+};
+
+// any set bit of `bits` in [a, b)? (bitmap words are read past the L1: other wavefronts mark them with atomics)
+__device__ inline bool lcb_bits_any(const uint32_t* bits, uint32_t a, uint32_t b)
+{
+    if (a >= b) return false;
+    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    for (uint32_t w = wa; w <= wb; w++) {
+        uint32_t v = __hip_atomic_load(bits + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == wa) v &= ma;
+        if (w == wb) v &= mb;
+        if (v) return true;
+    }
+    return false;
+}
+
+__device__ inline void lcb_bits_set(uint32_t* bits, uint32_t a, uint32_t b)
+{
+    if (a >= b) return;
+    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    for (uint32_t w = wa; w <= wb; w++) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (w == wa) m &= 0xFFFFFFFFu << (a & 31);
+        if (w == wb) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+        atomicOr(bits + w, m);
+    }
+}
+
+template <int NW>
+__device__ inline void lcb_commit_body(const LcbCommitArgs& A)
+{
+    __shared__ uint32_t sStop[4];          // [0] void phase-start result seen, [1] first live index of the next phase
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
+    uint32_t nCommitted = 0, stopAt = A.nLive, stopKind = 0;
+    bool marked = false;                   // something was committed in this round (wave-uniform, identical in every wavefront)
+    for (uint32_t lq = 0; lq < A.nLive && !stopKind;) {
+        const uint32_t ph = A.seedIdx[lq] / A.phase;
+        if (tid == 0) { sStop[0] = 0; sStop[1] = A.nLive; }
+        __syncthreads();
+        // the live seeds of this phase: [lq, lqEnd)
+        for (uint32_t q = lq + 1 + tid; q < A.nLive && q <= lq + A.phase; q += nT) if (A.seedIdx[q] / A.phase != ph) { atomicMin(&sStop[1], q); break; }
+        __syncthreads();
+        const uint32_t lqEnd = sStop[1];
+        // (a) every phase-start result of the phase is still exact (nothing to check before the first commit of the round)
+        if (marked) {
+            for (uint32_t q = lq + wave; q < lqEnd; q += NW) {
+                bool hit = false;
+                for (uint32_t k = A.fpOff[q] + lane; k < A.fpOff[q + 1]; k += 64) { const uint2 f = A.fp[k]; if (lcb_bits_any(A.delta, f.x, (f.y < A.nPos ? f.y : A.nPos - 1u) + 1u)) hit = true; }
+                if (__ballot(hit) != 0 && lane == 0) atomicOr(&sStop[0], 1u);
+            }
+            __syncthreads();
+            if (sStop[0]) { stopAt = lq; stopKind = 1; break; }
+        }
+        // (b) ordered commit: wavefront 0, lanes over the instances of a seed
+        if (wave == 0) {
+            for (uint32_t q = lq; q < lqEnd; q++) {
+                const uint32_t o0 = A.off[q], o1 = A.off[q + 1];
+                if (o1 - o0 <= 1) continue;                                              // blocksfinder.h:375
+                bool conflict = false;
+                for (uint32_t k = o0 + lane; k < o1; k += 64) {
+                    const uint4 in = A.inst[k];
+                    if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
+                    const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                    if (lcb_bits_any(A.used, lo, hi)) conflict = true;
+                }
+                if (__ballot(conflict) != 0) { stopAt = q; stopKind = 2; break; }
+                LCB_WAVE_SYNC();
+                for (uint32_t k = o0 + lane; k < o1; k += 64) {                          // Finalize: MarkUsed over [Front, Back)
+                    const uint4 in = A.inst[k];
+                    A.chrStamp[in.x] = ph + 1;
+                    const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                    lcb_bits_set(A.used, lo, hi);
+                    lcb_bits_set(A.delta, lo, hi);
+                }
+                LCB_WAVE_SYNC();
+                if (lane == 0) A.committed[nCommitted] = q;
+                nCommitted++;
+                marked = true;
+            }
+            if (lane == 0) { sStop[2] = marked ? 1u : 0u; sStop[3] = stopKind; }
+        }
+        __syncthreads();
+        marked = sStop[2] != 0;                                                      // what wavefront 0 did is known to all
+        if (sStop[3]) { stopKind = sStop[3]; break; }
+        lq = lqEnd;
+    }
+    if (tid == 0) { A.result[0] = nCommitted; A.result[1] = stopAt; A.result[2] = stopKind; }
 }
 
 #endif

@@ -330,6 +330,25 @@ struct EmuProcessor : LcbProcessor {
     }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
+    // device-side commit (EMU_DEVICE_COMMIT=1): the commit kernel body of lcb_kernel.h, 4 emulated wavefronts, on the emulator's bitmap
+    std::vector<uint32_t> dcDelta, dcStamp, dcCommitted;
+    bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst, const std::vector<uint32_t>& fpOff,
+                     const std::vector<lcb_fp>& fp, int64_t phase, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
+    {
+        if (!getenv("EMU_DEVICE_COMMIT") || live.empty()) return false;
+        static_assert(sizeof(lcb_instance) == sizeof(uint4) && sizeof(lcb_fp) == sizeof(uint2), "layouts the commit kernel reads");
+        dcDelta.assign(emu->usedWords, 0u); dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign(live.size(), 0u);
+        uint32_t result[4] = {0, 0, 0, 0};
+        LcbCommitArgs A;
+        A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.delta = dcDelta.data(); A.chrStamp = dcStamp.data();
+        A.seedIdx = (const uint32_t*)live.data(); A.off = off.data(); A.inst = (const uint4*)inst.data(); A.fpOff = fpOff.data(); A.fp = (const uint2*)fp.data();
+        A.nLive = (uint32_t)live.size(); A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
+        A.committed = dcCommitted.data(); A.result = result;
+        emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
+        committed.assign(dcCommitted.begin(), dcCommitted.begin() + result[0]);
+        stopAt = result[1]; stopKind = (int)result[2];
+        return true;
+    }
     // side lanes (EMU_SIDE_LANES=n): a background batch is computed on the spot and handed out job by job, EMU_SIDE_DELAY polls late
     // (EMU_SIDE_LATE=1: computed when first asked for, against the live state of that moment)
     LcbEagerSideLanes side{getenv("EMU_SIDE_LANES") ? atoi(getenv("EMU_SIDE_LANES")) : 0, getenv("EMU_SIDE_DELAY") ? atoi(getenv("EMU_SIDE_DELAY")) : 0, getenv("EMU_SIDE_LATE") != nullptr};
@@ -523,6 +542,7 @@ int main(int argc, char** argv)
                 cfg.overlap = !getenv("EMU_NO_OVERLAP");    // the early launch of the next round (off by default in the product) is exercised here
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls
                 cfg.relaxViews = getenv("EMU_RELAX") != nullptr;   // needs the -DLCB_PATH_SIG=1 build
+                cfg.deviceCommit = getenv("EMU_DEVICE_COMMIT") != nullptr;   // the commit kernel body under the emulator (needs EMU_NO_OVERLAP, EMU_NOSTATS)
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -533,7 +553,9 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
-                fprintf(stderr, "       early rounds %lld\n", (long long)es.earlyRounds);
+                fprintf(stderr, "       early rounds %lld | device-side commit: %lld results, %lld whole rounds | side lanes: %lld batches, %lld jobs, %lld taken\n", (long long)es.earlyRounds,
+                        (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken);
+                if (getenv("EMU_DEVICE_COMMIT") && es.rounds > 1 && es.deviceCommits == 0) { fprintf(stderr, "device-side commit asked for but nothing was committed there\n"); return 1; }
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);
