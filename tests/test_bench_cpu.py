@@ -1,0 +1,97 @@
+"""bench.py's own plumbing on the CPU (no GPU): the JSON line is assembled from the engine's statistics, the reference's legs are
+time-bounded, and a failing leg never costs the line. The device is replaced by a stand-in that reports zeros - what is checked is
+the harness, not a measurement (the measurement is the driver's run on the MI355X)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class _FakeDevice:
+    def __init__(self, storage, params, ordinal, **opts):
+        self.opts = opts
+
+    def kernel_time(self):
+        return 0.0, 0
+
+    def set_stats_mode(self, on):
+        pass
+
+    def hbm_triad(self, nbytes=0, reps=0):
+        return 4700.0
+
+    def mode_seeds(self):
+        return [0, 0, 0, 0]
+
+    def close(self):
+        pass
+
+
+def _fake_find_blocks(self, m, b, device=None, seeds=None, comm=None, threads=1, **engine):
+    import sibeliaz_amd
+    from sibeliaz_amd import api
+    self.blocks = np.zeros(0, dtype=sibeliaz_amd.BLOCK_DTYPE)
+    self.stats = {f: 0 for f, _ in api.Stats._fields_}
+    self.stats.update(kernel_ms=12.5, launches=3, process_ms=20.0, plan_ms=1.0, seeds=len(seeds) if seeds is not None else 0)
+    return self.blocks
+
+
+@pytest.fixture()
+def fake_gpu(built, monkeypatch, tmp_path):
+    import sibeliaz_amd
+    import bench
+    monkeypatch.setenv("LCB_BENCH_DIR", str(tmp_path / "wl"))
+    monkeypatch.setattr(sibeliaz_amd, "Device", _FakeDevice)
+    monkeypatch.setattr(sibeliaz_amd.BlocksFinder, "FindBlocks", _fake_find_blocks)
+    return bench
+
+
+def _run_main(bench, monkeypatch, capsys, argv):
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1, out
+    return json.loads(out[0])
+
+
+def test_bench_line_fields(fake_gpu, monkeypatch, capsys):
+    """One JSON line with the contract's fields, the roofline object from the committed-format event counts, the side-lane statistics."""
+    bench = fake_gpu
+    line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "2", "--warmup", "1", "--no-cli", "--no-cpu-baseline", "--no-roofline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "seeds/s" and line["config"]["workload"].startswith("10 synthetic strains")
+    assert set(line["config"]["side"]) == {"batches", "jobs", "taken", "void", "failed"}
+    assert line["roofline"]["kernel_ms_per_step"] == pytest.approx(12.5) and line["roofline"]["launches_per_step"] == 3
+    # with the roofline: the counting pass (a workload without committed counts), the triad, the traffic note
+    line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "1", "--warmup", "0", "--no-cli", "--no-cpu-baseline"])
+    assert set(line["roofline"]["event_counts"]) == set(__import__("sibeliaz_amd").api.COUNTER_NAMES) and line["roofline"]["peak_measured_stream_triad"] == 4700.0
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0 and "frac" in line["roofline"]
+
+
+def test_reference_legs_are_bounded_and_never_cost_the_line(fake_gpu, monkeypatch, capsys):
+    bench = fake_gpu
+    w = bench.ensure_workload("ecoli10_tiny")
+    # a run that exceeds its limit is killed and reported as such
+    assert bench.run_reference(w, 1, "limit", 0.2) == "timeout"
+    r = bench.run_reference(w, 2, "ok", 120)
+    assert isinstance(r, tuple) and os.path.exists(r[2])
+    # the whole protocol on a tiny workload (the GPU leg of the md5 comparison stands in with the reference's own output)
+    monkeypatch.setitem(bench.SAMPLES, "ecoli10_tiny", ("ecoli10_tiny", "ecoli10_tiny"))
+    monkeypatch.setattr(bench, "our_gff", lambda wl, threads, dev_ordinal=0: r[2])
+    cb = bench.cpu_baseline("ecoli10_tiny", 2, True, r[2], budget_s=300.0)
+    assert cb["kind"] == "reference" and cb["gff_md5_equal"] is True and cb["value"] > 0 and any(k.endswith("_whole") for k in cb["legs"])
+    # with no budget left the whole-workload leg is skipped and the sample figure is reported
+    cb2 = bench.cpu_baseline("ecoli10_tiny", 2, True, r[2], budget_s=0.0)
+    assert not any(k.endswith("_whole") for k in cb2["legs"]) and cb2["value"] > 0
+    # a leg that raises does not cost the line
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
+    line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "1", "--warmup", "0", "--no-cli", "--no-roofline"])
+    assert "cpu_baseline" not in line and "boom" in line["cpu_baseline_error"]
