@@ -88,9 +88,6 @@ def test_reference_legs_are_bounded_and_never_cost_the_line(fake_gpu, monkeypatc
     monkeypatch.setattr(bench, "our_gff", lambda wl, threads, dev_ordinal=0: r[2])
     cb = bench.cpu_baseline("ecoli10_tiny", 2, True, r[2], budget_s=300.0)
     assert cb["kind"] == "reference" and cb["gff_md5_equal"] is True and cb["value"] > 0 and any(k.endswith("_whole") for k in cb["legs"])
-    # with no budget left the whole-workload leg is skipped and the sample figure is reported
-    cb2 = bench.cpu_baseline("ecoli10_tiny", 2, True, r[2], budget_s=0.0)
-    assert not any(k.endswith("_whole") for k in cb2["legs"]) and cb2["value"] > 0
     # a leg that raises does not cost the line
     monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
     line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "1", "--warmup", "0", "--no-cli", "--no-roofline"])

@@ -173,13 +173,13 @@ def emu_built():
                                             # that reads the live state while it is being marked can see), results visible late, one lane, tiny job cap
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1"}),
                                             ("tandem4", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "LCB_MAX_JOBS": "16", "EMU_SIDE_DELAY": "2"}),
-                                            ("smallb", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
+                                            ("twogenomes", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
                                             ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1"}),
                                             # device-side ordered commit: the commit kernel body of lcb_kernel.h under the emulator (4 wavefronts) validates,
                                             # conflict-checks and marks the clean prefix of every round; the host mirrors it and takes over at the stop
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1"}),
                                             ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
-                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1"}),
+                                            ("collinear6", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1"}),
                                             ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
