@@ -46,6 +46,40 @@ struct OracleProc : LcbProcessor {
     std::unordered_map<uint64_t, std::pair<std::vector<lcb_instance>, int64_t>> last;
     int64_t recomputed = 0, identical = 0, identicalPushes = 0, recomputedPushes = 0, launchesLongestIdentical = 0;
     int64_t criticalNew = 0;       // critical path if no launch had to wait for a seed that merely reproduces its previous result
+    // Virtual clock in pushes (a synchronous launch lasts as long as its longest seed; enough workgroups for every seed of a launch) and
+    // side lanes on it (MODEL_SIDE_LANES=n): a background batch starts at the clock of its sideBegin, job k is done `pushes of k` later;
+    // waiting for a job moves the clock to its finish. The clock at the end is the critical path of the asynchronous engine.
+    int64_t now = 0, sideWaited = 0, sidePushes = 0;
+    bool inSide = false;
+    std::vector<int64_t> lastPushes;
+    struct Lane { bool busy = false; int64_t start = 0; std::vector<int64_t> dur; std::vector<uint64_t> off, fpOff; std::vector<lcb_instance> inst; std::vector<lcb_fp> fp; };
+    std::vector<Lane> lanes;
+    int sideLanes() const override { return (int)lanes.size(); }
+    int sideBegin(const lcb_seed* seeds, const uint32_t* view, int64_t n, int nv, const LcbViewMark* marks, int64_t nMarks) override
+    {
+        for (size_t l = 0; l < lanes.size(); l++) {
+            if (lanes[l].busy) continue;
+            Lane& L = lanes[l];
+            if (nv > 0) buildViews(nv, marks, nMarks);
+            inSide = true;
+            process(seeds, view, n, L.off, L.inst, L.fpOff, L.fp);
+            inSide = false;
+            L.dur = lastPushes; L.start = now; L.busy = true;
+            return (int)l;
+        }
+        return -1;
+    }
+    int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override
+    {
+        Lane& L = lanes[(size_t)lane];
+        if (!L.busy) return 2;
+        const int64_t ready = L.start + L.dur[(size_t)k];
+        if (now < ready) { if (!wait) return 0; sideWaited += ready - now; now = ready; }
+        inst.insert(inst.end(), L.inst.begin() + L.off[(size_t)k], L.inst.begin() + L.off[(size_t)k + 1]);
+        fp.insert(fp.end(), L.fp.begin() + L.fpOff[(size_t)k], L.fp.begin() + L.fpOff[(size_t)k + 1]);
+        return 1;
+    }
+    void sideRelease(int lane) override { lanes[(size_t)lane].busy = false; }
 
     void setRange(orc_graph* o, uint64_t lo, uint64_t hi, std::vector<uint8_t*>* undo)
     {
@@ -139,6 +173,9 @@ struct OracleProc : LcbProcessor {
             if (longestIdentical) launchesLongestIdentical++;
             criticalNew += longestNew;
         }
+        lastPushes = pushes;
+        if (inSide) { sidePushes += L.sumPush; return; }       // a background batch: not a launch the commit waits for
+        now += L.maxPush;
         launches.push_back(L);
         if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (int64_t i = 0; i < n; i++) fprintf(stderr, "   done %lld pushes %lld inst %zu pool %lld\n", (long long)i, (long long)pushes[(size_t)i], ri[(size_t)i].size(), (long long)pool[(size_t)i]);
         if (getenv("MODEL_LOG"))
@@ -175,6 +212,7 @@ int main(int argc, char** argv)
         proc.op.k = k; proc.op.min_block = m; proc.op.max_branch = b; proc.op.max_flank = b; proc.op.looking_depth = 8;
         proc.stride = (int)orc_used_stride();
         proc.conc = envInt("MODEL_CONCURRENCY", 1280);
+        proc.lanes.resize((size_t)envInt("MODEL_SIDE_LANES", 0));
         char err[512];
         const char* fa[1] = {fasta.c_str()};
         for (int t = 0; t < threads; t++) {
@@ -215,6 +253,9 @@ int main(int argc, char** argv)
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
                 (tRound + tJobs + tBig) / 1000);
+        fprintf(stderr, "model: virtual clock (pushes; a synchronous launch = its longest seed, a background job is ready its own pushes after its batch began): %lld | side lanes %zu: "
+                        "%lld batches, %lld jobs (%lld taken, %lld dropped), %lld pushes of background work, the commit waited %lld pushes for background jobs\n",
+                (long long)proc.now, proc.lanes.size(), (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.sideVoid, (long long)proc.sidePushes, (long long)proc.sideWaited);
         fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld; critical path without the reproductions: %lld pushes\n",
                 (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical, (long long)proc.criticalNew);
         if (getenv("MODEL_DUMP")) {
