@@ -1,0 +1,38 @@
+# First GPU call of the next round (prepared at the end of round 3, when no GPU time was left):
+#  1. the device-side commit kernel on the MI355X for the first time: its parity tests, then A/B on config 3 / config 2 / the k = 25 shapes;
+#  2. the reference at -t 32 on the k = 25 test-size shapes beside the whole sibeliaz-lcb process (<= 0.5 x);
+#  3. the bench line of the default build with the bounded CPU-baseline protocol.
+mkdir -p gpurun_out/r4a
+O=gpurun_out/r4a
+export LCB_WATCHDOG_S=300
+LCB_TEST_DEVICE_COMMIT=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -x -k "device_side_commit" > $O/pytest_device_commit.log 2>&1; grep -E "passed|failed" $O/pytest_device_commit.log | tail -2
+run() {
+  local v=$1; shift
+  LCB_VERBOSE=1 timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline "$@" > $O/$v.json 2> $O/$v.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("$O/$v.json")); c = d["config"]
+    print("$v: %.0f seeds/s, %.1f ms, kernel(sum) %.1f ms, launches %s stops %s jobs %s host %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"]["launches_per_step"], c["job_launches"], c["jobs"], c["host_ms_per_step"]))
+except Exception as e:
+    print("$v: FAILED", e); print(open("$O/$v.err").read()[-800:])
+PY
+}
+for w in ecoli62 ecoli10 primates8_test mice16_test; do
+run host_commit_$w --workload $w
+run device_commit_$w --workload $w --engine-opt device_commit=1
+done
+python - <<'PY'
+import os, subprocess, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
+for wl in ("primates8_test", "mice16_test"):
+    w = bench.ensure_workload(wl)
+    r = bench.run_reference(w, 32, "t32", 600)
+    t = time.time()
+    p = subprocess.run([os.path.join(bench.BIN, "sibeliaz-lcb"), "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]), "-a", str(w["a"]), "-t", "32", "-o", os.path.join(w["dir"], "cli"), "--noseq"], capture_output=True, text=True)
+    ours = time.time() - t
+    same = isinstance(r, tuple) and bench.md5(r[2]) == bench.md5(os.path.join(w["dir"], "cli", "blocks_coords.gff"))
+    print("%s: reference -t 32 whole process %s s (analyze %s s) | sibeliaz-lcb on the MI355X whole process %.1f s rc %d | gff equal %s" % (wl, "%.1f" % r[1] if isinstance(r, tuple) else r, "%.1f" % r[0] if isinstance(r, tuple) else "-", ours, p.returncode, same))
+PY
+timeout 2000 python bench.py --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-1500 $O/bench_n1.json

@@ -311,3 +311,21 @@ def test_persistent_gpu_set(built, case):
         assert got == case.golden("pretrim.tsv")
         assert finder.stats["exchanges"] > 0
     gpus.close()
+
+
+@pytest.mark.skipif(not os.environ.get("LCB_TEST_DEVICE_COMMIT"), reason="the device-side commit kernel is opt-in until it has run on an MI355X (set LCB_TEST_DEVICE_COMMIT=1)")
+@pytest.mark.parametrize("knobs", [{}, {"sync_jobs": 1}, {"round_fixed": 1, "round_phases": 1}, {"round_fixed": 1, "round_phases": 64, "max_jobs": 8}])
+def test_device_side_commit_on_gpu(built, case, knobs):
+    """lcb_hooks.device_commit: the clean prefix of every round is validated, conflict-checked and marked used by lcb_commit_kernel; the
+    host mirrors it and takes over at the first seed that needs a new computation. Same blocks and conflict count as the reference;
+    something must actually have been committed on the device."""
+    st, p, dev = _setup(case)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, device_commit=1, **knobs)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+    assert finder.stats["device_commits"] > 0
+    blocks2 = finder.FindBlocks(case.m, case.b, device=dev, threads=4, device_commit=1, **knobs)
+    assert blocks.tobytes() == blocks2.tobytes()
