@@ -1,0 +1,114 @@
+// commit_check — TEST-ONLY: the device-side commit kernel body (lcb_commit_body, lcb_kernel.h) on the wavefront emulator against a
+// plain sequential restatement of what it has to do (the thread-0 section of ProcessVertex::operator(), blocksfinder.h:372-414, over
+// a round's results: phase-start validation against the round's marks, weak conflict check, MarkUsed), on random rounds:
+//   commit_check [cases] [seed]
+// Random chromosomes, pre-marked bits, live seeds with 0-5 instances and footprints around them, tiny phases (so that a case has many
+// phase boundaries, conflicts inside phases and void phase-start results). Compared: the committed list, where and why it stopped,
+// the live bitmap and the per-chromosome stamps' effect (through the conflicts).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "emu_runtime.h"
+#include "lcb_kernel.h"
+
+namespace {
+
+bool anyBit(const std::vector<uint32_t>& b, uint32_t lo, uint32_t hi) { for (uint32_t q = lo; q < hi; q++) if ((b[q >> 5] >> (q & 31)) & 1u) return true; return false; }
+void setBits(std::vector<uint32_t>& b, uint32_t lo, uint32_t hi) { for (uint32_t q = lo; q < hi; q++) b[q >> 5] |= 1u << (q & 31); }
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const int cases = argc > 1 ? atoi(argv[1]) : 300;
+    std::mt19937 rng(argc > 2 ? (unsigned)atoi(argv[2]) : 12345u);
+    auto rnd = [&](uint32_t n) { return n ? (uint32_t)(rng() % n) : 0u; };
+    int bad = 0;
+    long commits = 0, stops1 = 0, stops2 = 0, clean = 0;
+    for (int c = 0; c < cases; c++) {
+        const uint32_t nChr = 1 + rnd(6), phase = 1u << rnd(4);                       // 1 .. 8 seeds per phase
+        std::vector<uint32_t> chrStart(1, 0);
+        for (uint32_t i = 0; i < nChr; i++) chrStart.push_back(chrStart.back() + 40 + rnd(600));
+        const uint32_t nPos = chrStart.back(), words = nPos / 32 + 2;
+        std::vector<uint32_t> used(words, 0), delta(words, 0), stamp(nChr + 1, 0);
+        for (uint32_t k = rnd(4); k > 0; k--) { const uint32_t a = rnd(nPos); setBits(used, a, std::min(nPos, a + 1 + rnd(30))); }
+        const uint32_t nRound = 8 + rnd(120);
+        std::vector<uint32_t> seedIdx, off(1, 0), fpOff(1, 0);
+        std::vector<uint4> inst;
+        std::vector<uint2> fp;
+        const uint32_t density = 1 + rnd(4);
+        for (uint32_t s = 0; s < nRound; s++) {
+            if (rnd(4) >= density) continue;                                          // a dead seed: not in the live list
+            const uint32_t cnt = rnd(6);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t chr = rnd(nChr), len = chrStart[chr + 1] - chrStart[chr], a = rnd(len), b = std::min(len - 1, a + rnd(40));
+                const bool pos = rnd(2) != 0;
+                inst.push_back(uint4{chr, pos ? a : b, pos ? b : a, pos ? 1u : 0u});
+                const uint32_t lo = chrStart[chr] + a, hi = chrStart[chr] + b;
+                fp.push_back(uint2{lo > 5 ? lo - rnd(6) : lo, std::min(nPos - 1, hi + rnd(6))});
+            }
+            for (uint32_t k = rnd(3); k > 0; k--) { const uint32_t a = rnd(nPos); fp.push_back(uint2{a, std::min(nPos - 1, a + rnd(12))}); }
+            if (rnd(8) == 0) fp.push_back(uint2{rnd(nPos), 0xFFFFFFF0u});             // an over-wide interval (clamped by the kernel)
+            seedIdx.push_back(s); off.push_back((uint32_t)inst.size()); fpOff.push_back((uint32_t)fp.size());
+        }
+        const uint32_t nLive = (uint32_t)seedIdx.size();
+        if (!nLive) { c--; continue; }
+        if (inst.empty()) inst.push_back(uint4{0, 0, 0, 0});
+        if (fp.empty()) fp.push_back(uint2{0, 0});
+        // ---- the sequential restatement
+        std::vector<uint32_t> rUsed = used, rDelta(words, 0), rStamp(nChr + 1, 0), rCommitted;
+        uint32_t rStop = nLive, rKind = 0;
+        for (uint32_t lq = 0; lq < nLive && !rKind;) {
+            const uint32_t ph = seedIdx[lq] / phase;
+            uint32_t lqEnd = lq;
+            while (lqEnd < nLive && seedIdx[lqEnd] / phase == ph) lqEnd++;
+            for (uint32_t q = lq; q < lqEnd && !rKind; q++)
+                for (uint32_t k = fpOff[q]; k < fpOff[q + 1]; k++)
+                    if (anyBit(rDelta, fp[k].x, std::min(fp[k].y, nPos - 1) + 1)) { rStop = lq; rKind = 1; break; }
+            if (rKind) break;
+            for (uint32_t q = lq; q < lqEnd; q++) {
+                if (off[q + 1] - off[q] <= 1) continue;
+                bool conflict = false;
+                for (uint32_t k = off[q]; k < off[q + 1]; k++) {
+                    const uint4 in = inst[k];
+                    if (rStamp[in.x] != ph + 1) continue;
+                    const uint32_t base = chrStart[in.x], lo = base + std::min(in.y, in.z), hi = base + std::max(in.y, in.z);
+                    if (anyBit(rUsed, lo, hi)) conflict = true;
+                }
+                if (conflict) { rStop = q; rKind = 2; break; }
+                for (uint32_t k = off[q]; k < off[q + 1]; k++) {
+                    const uint4 in = inst[k];
+                    rStamp[in.x] = ph + 1;
+                    const uint32_t base = chrStart[in.x], lo = base + std::min(in.y, in.z), hi = base + std::max(in.y, in.z);
+                    setBits(rUsed, lo, hi); setBits(rDelta, lo, hi);
+                }
+                rCommitted.push_back(q);
+            }
+            lq = lqEnd;
+        }
+        // ---- the kernel body under the emulator (2, 4 or 8 wavefronts)
+        std::vector<uint32_t> committed(nLive, 0xFFFFFFFFu);
+        uint32_t result[4] = {0, 0, 0, 0};
+        LcbCommitArgs A;
+        A.chrStart = chrStart.data(); A.used = used.data(); A.delta = delta.data(); A.chrStamp = stamp.data();
+        A.seedIdx = seedIdx.data(); A.off = off.data(); A.inst = inst.data(); A.fpOff = fpOff.data(); A.fp = fp.data();
+        A.nLive = nLive; A.phase = phase; A.nPos = nPos; A.committed = committed.data(); A.result = result;
+        const int nw = c % 3;
+        if (nw == 0) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
+        else if (nw == 1) emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
+        else emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
+        bool ok = result[0] == rCommitted.size() && result[1] == rStop && result[2] == rKind && used == rUsed && delta == rDelta;
+        for (size_t i = 0; ok && i < rCommitted.size(); i++) ok = committed[i] == rCommitted[i];
+        if (!ok) {
+            bad++;
+            if (bad <= 5) fprintf(stderr, "case %d (nLive %u, phase %u, %d waves): kernel committed %u stop %u kind %u | expected %zu stop %u kind %u | bitmap %s\n", c, nLive, phase,
+                                  nw == 0 ? 2 : (nw == 1 ? 4 : 8), result[0], result[1], result[2], rCommitted.size(), rStop, rKind, used == rUsed ? "equal" : "DIFFERENT");
+        }
+        commits += (long)rCommitted.size(); stops1 += rKind == 1; stops2 += rKind == 2; clean += rKind == 0;
+    }
+    fprintf(stderr, "commit_check: %d cases, %ld commits, %ld rounds committed completely, %ld stops at a phase start, %ld stops at a conflict, %d mismatches\n", cases, commits, clean, stops1, stops2, bad);
+    return bad ? 1 : 0;
+}

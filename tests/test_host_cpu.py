@@ -232,3 +232,12 @@ def test_engine_model_at_scale(built, tmp_path_factory, env):
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "engine_model"), w["graph"], w["fasta"], str(w["k"]), str(w["b"]), str(w["m"]), str(w["a"])],
                        capture_output=True, text=True, env=dict(os.environ, MODEL_THREADS="4", **env))
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
+
+
+def test_device_commit_kernel_on_random_rounds(built):
+    """lcb_commit_body (the device-side ordered commit) on the wavefront emulator with 2 / 4 / 8 wavefronts against a plain
+    sequential restatement of blocksfinder.h:372-414 over random rounds: committed list, stop position and kind, the live bitmap."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/commit_check"])
+    for seed in ("1", "2026"):
+        r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "commit_check"), "300", seed], capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 mismatches" in r.stderr, r.stderr[-1500:]
