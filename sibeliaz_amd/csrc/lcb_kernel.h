@@ -63,11 +63,7 @@
 //   mode 3 "huge":    everything in the global workspace, capacities chosen (and grown) by the host
 // IC instances, VC vote slots, BW Bloom words (0 = none), PC path-set slots in LDS (0 = global workspace)
 template <int MODE> struct LcbCfg;
-#ifndef LCB_COMPACT_VC
-#define LCB_COMPACT_VC 1024
-#define LCB_COMPACT_BW 256
-#endif
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = LCB_COMPACT_VC, BW = LCB_COMPACT_BW, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; };
 template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; };
 template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; };
@@ -250,28 +246,13 @@ __device__ __forceinline__ uint32_t lcb_wave_umin(uint32_t v) { return ~lcb_wave
 #define LCB_FLAG_FRONTFIN 4u
 #define LCB_FLAG_BITS 3u       // iFlags = (chromosome << 3) | flags
 
-// Big variant, optional (build with -DLCB_BIG_HOT=<n>, a round-3 candidate that is NOT in the shipped build): the fields of
-// the first n pool entries live in LDS, the rest in the workgroup's HBM slot. The pool of a long path grows to thousands of
-// instances that are never removed (path.h:684) while the instances that are extended, voted and scored at every step are the
-// initial ones — the lowest pool indices (profiles/r02/launch_trace_analysis.md).
-#ifndef LCB_BIG_HOT
-#define LCB_BIG_HOT 0u
-#endif
-template <class T> struct LcbHotCold {
-    T* hot; T* cold;
-    __device__ __forceinline__ T& operator[](uint32_t i) const { return i < LCB_BIG_HOT ? hot[i] : cold[i]; }
-};
-template <class T, bool SPLIT> struct LcbFieldSel { typedef T* type; };
-template <class T> struct LcbFieldSel<T, true> { typedef LcbHotCold<T> type; };
-template <class T> __device__ __forceinline__ void lcb_field_set(T*& f, T* hot, T* cold) { (void)hot; f = cold; }
-template <class T> __device__ __forceinline__ void lcb_field_set(LcbHotCold<T>& f, T* hot, T* cold) { f.hot = hot; f.cold = cold; }
-
 template <int MODE_>
 struct LcbStateT {
     static constexpr int MODE = MODE_;
-    static constexpr bool SPLIT = MODE_ == 2 && LCB_BIG_HOT > 0u;
-    typedef typename LcbFieldSel<uint32_t, SPLIT>::type FieldU;
-    typedef typename LcbFieldSel<int32_t, SPLIT>::type FieldI;
+    // (Keeping the fields of the first pool entries of the big variant in LDS, -DLCB_BIG_HOT of round 2, was measured in round 3:
+    // -1 % - the HBM-resident fields are not what makes the big variant slow - and removed.)
+    typedef uint32_t* FieldU;
+    typedef int32_t* FieldI;
     LcbTables T;
     LcbUsed U;                 // the `used` state this seed reads
     LcbKParams P;
@@ -1533,12 +1514,10 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.ck = (uint32_t*)(slot + L.ck); S.ckN = S.ckInst = S.ckGood = S.ckPath = 0; S.ckFlank = 0;
     uint32_t* instBase;
     uint32_t instStride;                                           // words between the instance field arrays
-    constexpr uint32_t HOT = LcbStateT<MODE>::SPLIT ? LCB_BIG_HOT : 0u;
-    __shared__ uint32_t sHot[HOT ? 11u * HOT : 1u];
     uint32_t *fpBase;
     if (INST_LDS) { instBase = sInst; instStride = IC; fpBase = sFp; }
     else { instBase = (uint32_t*)(slot + L.inst); instStride = W.instCap; fpBase = (uint32_t*)(slot + L.fp); }
-    lcb_field_set(S.fpLo, sHot + 9u * HOT, fpBase); lcb_field_set(S.fpHi, sHot + 10u * HOT, fpBase + instStride);
+    S.fpLo = fpBase; S.fpHi = fpBase + instStride;
     if (IDX_LDS) {
         S.instCap = IC;
         S.ordKey = sOrdKey; S.ordIdx = sOrdIdx; S.good = sGood; S.goodPos = sGoodPos; S.touch = sTouch;
@@ -1557,12 +1536,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.bloomShift = BW ? 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u : 0u;
     for (uint32_t h = threadIdx.x; h < BW; h += 64 * NW) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
-    lcb_field_set(S.iFrontG, sHot, instBase); lcb_field_set(S.iBackG, sHot + HOT, instBase + instStride);
-    lcb_field_set(S.iFrontPos, sHot + 2u * HOT, instBase + 2 * instStride); lcb_field_set(S.iBackPos, sHot + 3u * HOT, instBase + 3 * instStride);
-    lcb_field_set(S.iLo, sHot + 4u * HOT, instBase + 4 * instStride); lcb_field_set(S.iHi, sHot + 5u * HOT, instBase + 5 * instStride);
-    lcb_field_set(S.iFlags, sHot + 6u * HOT, instBase + 6 * instStride);
-    lcb_field_set(S.iFrontDist, (int32_t*)(sHot + 7u * HOT), (int32_t*)(instBase + 7 * instStride));
-    lcb_field_set(S.iBackDist, (int32_t*)(sHot + 8u * HOT), (int32_t*)(instBase + 8 * instStride));
+    S.iFrontG = instBase; S.iBackG = instBase + instStride;
+    S.iFrontPos = instBase + 2 * instStride; S.iBackPos = instBase + 3 * instStride;
+    S.iLo = instBase + 4 * instStride; S.iHi = instBase + 5 * instStride;
+    S.iFlags = instBase + 6 * instStride;
+    S.iFrontDist = (int32_t*)(instBase + 7 * instStride);
+    S.iBackDist = (int32_t*)(instBase + 8 * instStride);
     S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);

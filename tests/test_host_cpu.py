@@ -131,7 +131,6 @@ def test_cli_usage_errors(built, case, tmp_path):
 EMU = os.path.join(ROOT, "tests", "emu", "build", "emu_check")
 EMU_SHARE = os.path.join(ROOT, "tests", "emu", "build", "emu_check_share8")   # tiny LCB_VOTE_SHARE_MIN: all-waves reduce/clear path
 EMU_SIG = os.path.join(ROOT, "tests", "emu", "build", "emu_check_sig")        # -DLCB_PATH_SIG=1: path signatures for the engine's relaxViews rule
-EMU_HOT = os.path.join(ROOT, "tests", "emu", "build", "emu_check_hot8")       # -DLCB_BIG_HOT=8: hot / cold split of the big variant's instance fields
 
 
 @pytest.fixture(scope="session")
@@ -159,8 +158,6 @@ def emu_built():
                                             # predicted `used` views spanning many copy-on-write pages (the EMU_SHARE build has 128-position pages)
                                             ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
-                                            # round-3 candidate of the big variant (-DLCB_BIG_HOT): fields of the first 8 pool entries in LDS, the rest in the slot
-                                            ("twogenomes", "big", {"EMU_LIMIT": "400", "EMU_HOT": "1"}), ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "300", "EMU_HOT": "1"}),
                                             # round-3 candidate (-DLCB_PATH_SIG=1): the kernels report the path's vertices (checked against the oracle's
                                             # list seed by seed), the engine's relaxViews rule uses them
                                             ("twogenomes", "seeds-init", {"EMU_LIMIT": "400", "EMU_SIG": "1"}), ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SIG": "1"}),
@@ -189,7 +186,7 @@ def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
     from tests.conftest import Case
     c = Case(name, case_dir)
-    exe = EMU_SHARE if env.get("EMU_SHARE") else (EMU_HOT if env.get("EMU_HOT") else (EMU_SIG if env.get("EMU_SIG") else emu_built))
+    exe = EMU_SHARE if env.get("EMU_SHARE") else (EMU_SIG if env.get("EMU_SIG") else emu_built)
     r = subprocess.run([exe, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
                        env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
