@@ -186,9 +186,10 @@ def cpu_baseline(workload, threads, full, our_gff_path, budget_s=600.0):
     def leg(t, w, s, reps, tag, limit_s):
         runs = []
         for rep in range(reps):
-            r = run_reference(w, t, tag, limit_s)
+            limit = max(10.0, min(limit_s, budget_s - (time.time() - t_start)))     # no leg outlives the budget of the whole protocol
+            r = run_reference(w, t, tag, limit)
             if r == "timeout":
-                per_t[tag] = {"threads": t, "timeout_s": limit_s, "sample": w["desc"], "sample_seeds": s}
+                per_t[tag] = {"threads": t, "timeout_s": limit, "sample": w["desc"], "sample_seeds": s}
                 return "timeout"
             if r is None:
                 return None
