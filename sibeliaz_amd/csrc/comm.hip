@@ -10,7 +10,16 @@
 // librccl is opened on first use (dlopen), so the library loads — and everything single-GPU works — where RCCL is absent.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>) && !defined(LCB_LOCAL_RCCL_DECLS)
 #include <rccl/rccl.h>
+#else
+// A ROCm installation without RCCL's development headers still builds the library: these are the few declarations of RCCL's
+// public C ABI that this file binds with dlsym.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+#endif
 
 #include <cstring>
 #include <mutex>
