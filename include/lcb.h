@@ -101,6 +101,7 @@ typedef struct {
     int64_t side_failed;        /* ... jobs that ended without a result (stopped, or needed another kernel variant) */
     int64_t device_commits;     /* results validated, conflict-checked and marked used by the device-side commit kernel (the host mirrors them) */
     int64_t device_rounds;      /* ... rounds it committed from the first to the last seed */
+    int64_t early_critical;     /* stops whose own jobs were computed while the host planned the rest (lcb_hooks.early_critical) */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -241,6 +242,10 @@ typedef struct {
                                    Off by default: exact under the CPU wavefront emulator, not yet run on the MI355X (round 3 ran out of GPU time) */
     int32_t sync_jobs;          /* 1: do not use the device's side lanes - every job of a stop's plan runs in one synchronous launch
                                    (the round-2 engine; for A/B runs and tests) */
+    int32_t early_critical;     /* 1 (with side lanes): the results a stop cannot go on without - the re-processing of the stopping seed, or
+                                   the missing phase-start results of the phase about to start - are launched BEFORE the dry run that plans
+                                   the rest of the stop's jobs, which then runs in the shadow of that kernel instead of in front of it.
+                                   Off by default: written after round 3 had used up its GPU time; exact under the CPU wavefront emulator */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

@@ -1,11 +1,14 @@
 # First GPU call of the next round (prepared at the end of round 3, when no GPU time was left):
-#  1. the device-side commit kernel on the MI355X for the first time: its parity tests, then A/B on config 3 / config 2 / the k = 25 shapes;
+#  1. the early critical launch (lcb_hooks.early_critical: a stop's own jobs computed while the host plans the rest; expected: the dry-run
+#     time, ~1.8 s of a config-3 pass, leaves the critical path) and the device-side commit kernel on the MI355X for the first time: their
+#     parity tests, then A/B on config 3 / config 2 / the k = 25 shapes;
 #  2. the reference at -t 32 on the k = 25 test-size shapes beside the whole sibeliaz-lcb process (<= 0.5 x);
 #  3. the bench line of the default build with the bounded CPU-baseline protocol.
 mkdir -p gpurun_out/r4a
 O=gpurun_out/r4a
 export LCB_WATCHDOG_S=300
-LCB_TEST_DEVICE_COMMIT=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -x -k "device_side_commit" > $O/pytest_device_commit.log 2>&1; grep -E "passed|failed" $O/pytest_device_commit.log | tail -2
+LCB_TEST_EARLY_CRITICAL=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "early_critical" > $O/pytest_early_critical.log 2>&1; grep -E "passed|failed" $O/pytest_early_critical.log | tail -2
+LCB_TEST_DEVICE_COMMIT=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "device_side_commit" > $O/pytest_device_commit.log 2>&1; grep -E "passed|failed" $O/pytest_device_commit.log | tail -2
 run() {
   local v=$1; shift
   LCB_VERBOSE=1 timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline "$@" > $O/$v.json 2> $O/$v.err
@@ -19,8 +22,10 @@ except Exception as e:
 PY
 }
 for w in ecoli62 ecoli10 primates8_test mice16_test; do
-run host_commit_$w --workload $w
+run base_$w --workload $w
+run early_critical_$w --workload $w --engine-opt early_critical=1
 run device_commit_$w --workload $w --engine-opt device_commit=1
+run both_$w --workload $w --engine-opt early_critical=1 --engine-opt device_commit=1
 done
 python - <<'PY'
 import os, subprocess, sys, time

@@ -1051,7 +1051,9 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
 // begin: the seeds that start in the compact variant are enqueued (second set of host buffers, nothing is waited for) against
 // the live `used` state of this moment — later marks and launches are ordered behind it on the stream; end: waits for that
 // launch, takes its results, then runs whatever is left (seeds with a hint for another variant, overflows) like a normal call.
-struct lcb_async_call { ProcAcc A; std::vector<int64_t> list; uint32_t m = 0; bool screen = false, launched = false; };
+// anySize (the engine's early critical launch: the results a stop cannot go on without are computed while the host plans the
+// rest): calls of few seeds too; the first launch is then the one a synchronous call would start with (wide, or big).
+struct lcb_async_call { ProcAcc A; std::vector<int64_t> list; uint32_t m = 0; int mode = 0; bool screen = false, launched = false; };
 
 static void lcb_device_drop_async(lcb_device_impl* d)
 {
@@ -1060,23 +1062,26 @@ static void lcb_device_drop_async(lcb_device_impl* d)
     d->async = nullptr;
 }
 
-bool lcb_device_process_begin_impl(lcb_device* h, const lcb_seed* seeds, int64_t n)
+bool lcb_device_process_begin_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, bool anySize)
 {
     lcb_device_impl* d = h->impl;
-    if (d->stats || d->async || n > (int64_t)d->batchCap || n <= (int64_t)d->o.wide_threshold || d->o.start_mode > 1) return false;
+    if (d->stats || d->async || n <= 0 || n > (int64_t)d->batchCap) return false;
+    if (!anySize && (n <= (int64_t)d->o.wide_threshold || d->o.start_mode > 1)) return false;
     if (d->hDbg || d->seedTrace || d->forceProf) return false;     // (the instrumented variants share one profile buffer)
     d->use();
     std::unique_ptr<lcb_async_call> c(new lcb_async_call());
     c->A.ownSeeds.assign(seeds, seeds + n);
     accInit(d, c->A, c->A.ownSeeds.data(), n, nullptr, nullptr, nullptr, nullptr, true);
-    c->list.swap(c->A.todo[0]);
+    if (anySize) for (int m = 3; m >= 0; m--) if (!c->A.todo[m].empty()) c->mode = m;       // the variant a synchronous call would launch first
+    c->list.swap(c->A.todo[c->mode]);
     c->m = (uint32_t)c->list.size();
     if (c->m) {
         d->wantFp = true;
         d->swapBufs();
         fillSeeds(d, c->A, c->list, 0, c->m);
         c->screen = c->m >= d->o.screen_min;
-        try { d->launch(d->ws[0], c->m, c->screen, false); } catch (...) { d->swapBufs(); d->wantFp = false; throw; }
+        if (c->mode >= 2) d->bigRetries += c->m;
+        try { d->launch(d->ws[c->mode], c->m, c->screen, false); } catch (...) { d->swapBufs(); d->wantFp = false; throw; }
         d->swapBufs();
         d->wantFp = false;
         c->launched = true;
@@ -1098,9 +1103,10 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
     if (c->launched) {
         d->swapBufs();
         try {
-            const uint32_t grid = c->m < d->ws[0].nSlots ? c->m : d->ws[0].nSlots;
-            d->finishLaunch(d->ws[0], c->m, grid, false, d->ev2, d->ev3);
-            gatherBatch(d, c->A, c->list, 0, c->m, c->screen, 0);
+            WorkSet& ws = d->ws[c->mode];
+            const uint32_t grid = c->m < ws.nSlots ? c->m : ws.nSlots;
+            d->finishLaunch(ws, c->m, grid, false, d->ev2, d->ev3);
+            gatherBatch(d, c->A, c->list, 0, c->m, c->screen, c->mode);
         } catch (...) { d->swapBufs(); d->wantFp = false; throw; }
         d->swapBufs();
     }
@@ -1327,7 +1333,7 @@ struct DeviceProcessor : LcbProcessor {
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
     int concurrency() const override { return lcb_device_concurrency_impl(dev); }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { lcb_device_build_views_impl(dev, nViews, marks, nMarks); }
-    bool processBegin(const lcb_seed* seeds, int64_t n) override { return lcb_device_process_begin_impl(dev, seeds, n); }
+    bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize) override { return lcb_device_process_begin_impl(dev, seeds, n, anySize); }
     void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
         lcb_device_process_end_impl(dev, off, inst, fpOff, fp);
@@ -1370,6 +1376,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
-        stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds;
+        stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
     }
 }

@@ -193,7 +193,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     if (portion == 0) portion = 1;
     if (cfg.progress) std::cout << '[' << std::flush;
 
-    Results mine, round, tmp;
+    Results mine, round, tmp, tmp2;
     std::vector<lcb_seed> sub;
     std::vector<uint32_t> subView;
     std::vector<unsigned char> sendBuf, recvBuf;
@@ -214,6 +214,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<lcb_fp> dcFp;
     // ---- asynchronous job batches (side lanes of the processor), one rank only
     const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !cfg.relaxViews && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
+    // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs
+    const bool useEarly = useSide && cfg.earlyCritical && !cfg.overlap;
+    std::vector<lcb_seed> earlySeeds;
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
     std::vector<SideJob> sideJobs;                  // of this round
     size_t sideScan = 0;                            // jobs before this index are no longer in flight
@@ -504,6 +507,16 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 dropSide(ref);
                 return false;
             };
+            // Early critical launch: the stop's own jobs - the F of the stopping seed, or the missing E of the phase that is about to
+            // start - run against the live state and are known before anything is simulated; their computation begins here and the
+            // dry run below runs in its shadow.
+            size_t nEarly = 0;                       // the first nEarly jobs of the plan were begun ahead of it
+            auto beginEarly = [&]() {
+                const auto tp = std::chrono::steady_clock::now();
+                if (proc.processBegin(earlySeeds.data(), (int64_t)earlySeeds.size(), true)) nEarly = earlySeeds.size();
+                st.processMs += msSince(tp);
+            };
+            if (useEarly && midPhase) { earlySeeds.assign(1, seeds[pos + stopAt]); beginEarly(); }
             const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
             std::vector<lcb_instance> guess;
             size_t lv = liveFrom((midPhase ? stopAt : ph0));          // cursor into liveIdx (seeds that are not in it need nothing, commit nothing)
@@ -528,6 +541,11 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                         }
                     }
                     if (!first) { for (uint32_t c : simChrList) simChr[c] = 0; simChrList.clear(); }
+                    else if (useEarly && !jobs.empty() && nViews == 0) {
+                        earlySeeds.clear();
+                        for (auto& jb : jobs) earlySeeds.push_back(seeds[pos + jb.seed]);
+                        beginEarly();
+                    }
                 }
                 // ordered commit, simulated with the newest E of each seed as the prediction of its E
                 for (size_t q = lv; q < lvEnd; q++) {
@@ -600,11 +618,27 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 st.processMs += msSince(tp);
             }
             const size_t nSync = lane >= 0 ? nCrit : jobs.size();
+            if (nEarly) {
+                // the stop's own jobs are on their way since before the dry run (nothing has touched the processor's state since)
+                if (nEarly != nCrit) throw LcbError("engine: the jobs begun ahead of the plan are not the stop's own");
+                const auto tp = std::chrono::steady_clock::now();
+                proc.processEnd(tmp.off, tmp.inst, tmp.fpOff, tmp.fp);
+                st.processMs += msSince(tp);
+                st.earlyCritical++;
+            }
             if (lane < 0 && nViews > 0) proc.buildViews(nViews, vmarks.data(), (int64_t)vmarks.size());
             if (nViews > 0) st.viewsBuilt += nViews;
             // every rank plans the same jobs (same state, same results); the jobs of one launch are independent given their
             // views, so they are dealt to the ranks like a round's seeds and gathered the same way
-            processSharded(sub.data(), lane >= 0 ? nullptr : subView.data(), (int64_t)nSync, tmp, (uint64_t)(pos + stopAt));
+            if (!nEarly) processSharded(sub.data(), lane >= 0 ? nullptr : subView.data(), (int64_t)nSync, tmp, (uint64_t)(pos + stopAt));
+            else if (nSync > nCrit) {
+                // no lane took the rest of the plan: it runs now, and its results follow the early ones
+                processSharded(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(nSync - nCrit), tmp2, (uint64_t)(pos + stopAt));
+                const uint64_t i0 = tmp.inst.size(), f0 = tmp.fp.size();
+                tmp.inst.insert(tmp.inst.end(), tmp2.inst.begin(), tmp2.inst.end());
+                tmp.fp.insert(tmp.fp.end(), tmp2.fp.begin(), tmp2.fp.end());
+                for (size_t k = 1; k <= nSync - nCrit; k++) { tmp.off.push_back(i0 + tmp2.off[k]); tmp.fpOff.push_back(f0 + tmp2.fpOff[k]); }
+            }
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
             if (midPhase) st.conflictLaunches++;
             if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views" << (lane >= 0 ? ", all but the first on side lane " + std::to_string(lane) : std::string()) << "\n";

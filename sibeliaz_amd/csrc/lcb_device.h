@@ -29,7 +29,7 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
                              std::vector<std::vector<int32_t>>* pathSink = nullptr);   // -DLCB_PATH_SIG=1 builds: sorted |id| of every seed's path vertices   // stats mode: the counters of every seed
 // The same for a call whose first launch overlaps with host work: begin enqueues it against the live state of this moment (false:
 // not applicable, use the synchronous call), end waits and completes it.
-bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n);
+bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, bool anySize = false);
 void lcb_device_process_end_impl(lcb_device* d, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOffsets,
                                  std::vector<lcb_fp>& fp);
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).

@@ -89,8 +89,10 @@ struct LcbProcessor {
     std::vector<std::vector<int32_t>>* pathSink = nullptr;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
     // Optional: start process(seeds, view 0) now, against the state of this moment (marks applied later must not reach it),
-    // and collect it with processEnd — the engine commits the previous round in between. false = not supported / not applicable.
-    virtual bool processBegin(const lcb_seed* seeds, int64_t n) { (void)seeds; (void)n; return false; }
+    // and collect it with processEnd — the engine commits the previous round in between (anySize = false: only calls large
+    // enough to be worth it), or plans the rest of a stop's jobs while the results the stop needs are computed (anySize = true).
+    // false = not supported / not applicable.
+    virtual bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize = false) { (void)seeds; (void)n; (void)anySize; return false; }
     virtual void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp)
     {
         (void)off; (void)inst; (void)fpOff; (void)fp; throw LcbError("processEnd without processBegin");
@@ -152,6 +154,7 @@ struct LcbEagerSideLanes {
     // late: a batch is computed when its first result is asked for, against the live state of THAT moment (plus its predicted
     // marks) - the other extreme of what a background batch that reads the live state while it is being marked can see
     bool late = false;
+    int64_t cap = 0;          // > 0: batches of more jobs are refused (the device refuses batches beyond its lanes' capacity)
     explicit LcbEagerSideLanes(int n = 0, int d = 0, bool l = false) : lanes((size_t)n), delay(d), late(l) {}
     void compute(LcbProcessor& p, Lane& L)
     {
@@ -161,6 +164,7 @@ struct LcbEagerSideLanes {
     }
     int begin(LcbProcessor& p, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
     {
+        if (cap > 0 && n > cap) return -1;
         for (size_t l = 0; l < lanes.size(); l++) {
             if (lanes[l].busy) continue;
             Lane& L = lanes[l];
@@ -209,6 +213,7 @@ struct LcbEngineConfig {
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
     bool deviceCommit = false; // use the processor's commitRound for the clean prefix of every round. Off by default: built and
                               // exact under the wavefront emulator, but the GPU budget of round 3 was spent before it ran on the MI355X
+    bool earlyCritical = false; // begin the stop's own jobs before the dry run that plans the rest (processBegin(anySize) / processEnd); needs side lanes
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
 
@@ -222,6 +227,7 @@ struct LcbEngineStats {
     int64_t earlyRounds = 0;      // rounds whose launch ran while the previous round was being committed
     int64_t deviceCommits = 0;    // results committed by the processor itself (commitRound), and ...
     int64_t deviceRounds = 0;     // ... rounds it committed completely
+    int64_t earlyCritical = 0;    // stops whose own jobs ran while the rest was planned
     int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)
     int64_t sideTaken = 0;        // ... results taken when the commit reached their seed (view came true)
     int64_t sideVoid = 0;         // ... jobs dropped because a mark of their view did not come true, or superseded by a newer plan

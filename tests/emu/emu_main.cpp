@@ -311,9 +311,10 @@ struct EmuProcessor : LcbProcessor {
     // begin / end (the engine overlaps the next round's launch with this round's commit): the emulated launch must see the
     // state of the moment of the begin, so the live bitmap is snapshotted there and the seeds run against the snapshot at the end
     std::vector<lcb_seed> begunSeeds; std::vector<uint32_t> begunUsed; bool begunValid = false;
-    bool processBegin(const lcb_seed* sd, int64_t n) override
+    bool processBegin(const lcb_seed* sd, int64_t n, bool anySize) override
     {
-        if (getenv("EMU_NO_OVERLAP")) return false;
+        if (getenv("EMU_NO_OVERLAP") && !anySize) return false;
+        if (begunValid) return false;               // (one call in flight, like the device)
         begunSeeds.assign(sd, sd + n);
         begunUsed.assign(emu->used.begin(), emu->used.begin() + emu->usedWords);
         begunValid = true;
@@ -355,6 +356,7 @@ struct EmuProcessor : LcbProcessor {
     int sideLanes() const override { return (int)side.lanes.size(); }
     int sideBegin(const lcb_seed* sd, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks) override
     {
+        if (getenv("EMU_SIDE_CAP")) side.cap = atoll(getenv("EMU_SIDE_CAP"));      // larger batches are refused: their jobs run synchronously
         return side.begin(*this, sd, view, n, nViews, marks, nMarks);
     }
     int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return side.poll(*this, lane, k, wait, inst, fp); }
@@ -543,6 +545,7 @@ int main(int argc, char** argv)
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls
                 cfg.relaxViews = getenv("EMU_RELAX") != nullptr;   // needs the -DLCB_PATH_SIG=1 build
                 cfg.deviceCommit = getenv("EMU_DEVICE_COMMIT") != nullptr;   // the commit kernel body under the emulator (needs EMU_NO_OVERLAP, EMU_NOSTATS)
+                cfg.earlyCritical = getenv("EMU_EARLY_CRITICAL") != nullptr; // the stop's own jobs begun before the dry run (needs side lanes, EMU_NO_OVERLAP, EMU_NOSTATS)
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -555,6 +558,8 @@ int main(int argc, char** argv)
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
                 fprintf(stderr, "       early rounds %lld | device-side commit: %lld results, %lld whole rounds | side lanes: %lld batches, %lld jobs, %lld taken\n", (long long)es.earlyRounds,
                         (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken);
+                fprintf(stderr, "       early critical launches %lld\n", (long long)es.earlyCritical);
+                if (getenv("EMU_EARLY_CRITICAL") && es.recomputeLaunches > 0 && es.earlyCritical == 0) { fprintf(stderr, "early critical launches asked for but none happened\n"); return 1; }
                 if (getenv("EMU_DEVICE_COMMIT") && es.rounds > 1 && es.deviceCommits == 0) { fprintf(stderr, "device-side commit asked for but nothing was committed there\n"); return 1; }
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,

@@ -329,3 +329,24 @@ def test_device_side_commit_on_gpu(built, case, knobs):
     assert finder.stats["device_commits"] > 0
     blocks2 = finder.FindBlocks(case.m, case.b, device=dev, threads=4, device_commit=1, **knobs)
     assert blocks.tobytes() == blocks2.tobytes()
+
+
+@pytest.mark.skipif(not os.environ.get("LCB_TEST_EARLY_CRITICAL"), reason="the early critical launch is opt-in until it has run on an MI355X (set LCB_TEST_EARLY_CRITICAL=1)")
+@pytest.mark.parametrize("knobs,dev_opts", [({}, {}), ({"max_jobs": 6}, {"side_lanes": 1}), ({"round_fixed": 1, "round_phases": 1}, {}), ({}, {"start_mode": 3}),
+                                            ({"round_fixed": 1, "round_phases": 64}, {"wide_slots": 8, "big_slots": 8})])
+def test_early_critical_launch_on_gpu(built, case, knobs, dev_opts):
+    """lcb_hooks.early_critical: the results a stop cannot go on without (the re-processing of the stopping seed, the missing phase-start
+    results of the phase about to start) are launched before the dry run that plans the rest of the stop's jobs (an asynchronous first
+    launch in the wide or big variant, lcb_device_process_begin with anySize) and collected after the side batch has been started.
+    Same blocks and conflict count as the reference - with the default options, one lane and a tiny job cap, one-phase rounds, every
+    seed forced into the big variant, and lanes so small that batches are refused (the rest of a plan then runs synchronously)."""
+    st, p, dev = _setup(case, **dev_opts)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    for _ in range(2):
+        blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, early_critical=1, **knobs)
+        got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+        assert got == case.golden("pretrim.tsv")
+        assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+        if finder.stats["recompute_launches"] > 0 and not dev_opts.get("start_mode"):
+            assert finder.stats["early_critical"] > 0

@@ -178,6 +178,11 @@ def emu_built():
                                             ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
                                             ("collinear6", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1"}),
                                             ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1"}),
+                                            # early critical launch (lcb_hooks.early_critical): the stop's own jobs are begun before the dry run that plans the
+                                            # rest; with a lane for the rest, with batches the lanes refuse (the rest then runs synchronously behind the early jobs)
+                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
+                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4"}),
+                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
