@@ -4,7 +4,8 @@
 // (blocksfinder.h:461-503) and the std::sort at blocksfinder.h:517. Every signed vertex v is
 // independent, so vertices are processed by an OpenMP team over the CSR occurrence lists; the
 // sort key (count desc, rank asc, resolve asc — Bundle::operator<, blocksfinder.h:195-208) is
-// a total order (distinct resolve per bundle), so the result does not depend on the algorithm.
+// a total order (distinct resolve per bundle), so the result does not depend on the algorithm: the
+// sort runs on all threads too (sorted runs + pairwise merges).
 #include <omp.h>
 
 #include <algorithm>
@@ -77,5 +78,15 @@ void lcb_enumerate_seeds_impl(const lcb_graph& g, int threads, std::vector<lcb_s
     out.clear();
     out.reserve(total);
     for (auto& p : part) out.insert(out.end(), p.begin(), p.end());
-    std::sort(out.begin(), out.end(), seedLess);
+    // blocksfinder.h:517 on all threads: sorted runs, then pairwise merges (the order is total, so the result is std::sort's)
+    const size_t n = out.size();
+    int runs = 1;
+    while (runs * 2 <= threads && n / (size_t)(runs * 2) >= 65536) runs *= 2;
+    auto cut = [&](int r) { return out.begin() + (ptrdiff_t)(n * (size_t)r / (size_t)runs); };
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int r = 0; r < runs; r++) std::sort(cut(r), cut(r + 1), seedLess);
+    for (int w = 1; w < runs; w *= 2) {
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+        for (int r = 0; r < runs; r += 2 * w) std::inplace_merge(cut(r), cut(r + w), cut(r + 2 * w), seedLess);
+    }
 }
