@@ -149,6 +149,9 @@ typedef struct {
                                 default 1 << 22; enlarged x4 when a launch fills it (its unlucky seeds run again) */
     uint32_t side_lanes;     /* asynchronous job batches that can be in flight beside the synchronous launches (own streams, buffers,
                                 workspace slots and predicted views each); default 4; 0xFFFFFFFF = none */
+    uint32_t stream_priority;/* 1: the stream of the synchronous launches (the results the commit waits for) gets the highest HIP stream
+                                priority and the side lanes' streams the lowest, so that speculation that fills the machine does not delay a
+                                needed result; default 0 = all streams alike (not measured yet) */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows

@@ -438,7 +438,11 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.wide_threshold) o.wide_threshold = 2 * o.wide_slots;
         if (!o.screen_min) o.screen_min = 2048;
         if (o.path_cap & (o.path_cap - 1)) throw LcbError("lcb_device_opts.path_cap must be a power of two");
-        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        // lcb_device_opts.stream_priority: needed results ahead of speculation (numerically lower = higher priority)
+        int prioLow = 0, prioHigh = 0;
+        if (o.stream_priority) HIP_CHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+        if (o.stream_priority) HIP_CHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prioHigh));
+        else HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&d->ev0));
         HIP_CHECK(hipEventCreate(&d->ev1));
         HIP_CHECK(hipEventCreate(&d->ev2));
@@ -535,8 +539,13 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->lanes.resize(nLanes);
         for (uint32_t l = 0; l < nLanes; l++) {
             SideLane& L = d->lanes[l];
-            HIP_CHECK(hipStreamCreateWithFlags(&L.sw, hipStreamNonBlocking));
-            HIP_CHECK(hipStreamCreateWithFlags(&L.sb, hipStreamNonBlocking));
+            if (o.stream_priority) {
+                HIP_CHECK(hipStreamCreateWithPriority(&L.sw, hipStreamNonBlocking, prioLow));
+                HIP_CHECK(hipStreamCreateWithPriority(&L.sb, hipStreamNonBlocking, prioLow));
+            } else {
+                HIP_CHECK(hipStreamCreateWithFlags(&L.sw, hipStreamNonBlocking));
+                HIP_CHECK(hipStreamCreateWithFlags(&L.sb, hipStreamNonBlocking));
+            }
             for (hipEvent_t* e : {&L.w0, &L.w1, &L.b0, &L.b1}) HIP_CHECK(hipEventCreate(e));
             L.cap = 2048; L.arenaCap = 1ull << 20;
             // the host polls these while the kernels run: fine-grained (coherent) pinned memory
