@@ -27,6 +27,7 @@ run early_critical_$w --workload $w --engine-opt early_critical=1
 run device_commit_$w --workload $w --engine-opt device_commit=1
 run both_$w --workload $w --engine-opt early_critical=1 --engine-opt device_commit=1
 run early_prio_$w --workload $w --engine-opt early_critical=1 --device-opt stream_priority=1
+run early_jobs512_$w --workload $w --engine-opt early_critical=1 --engine-opt max_jobs=512
 done
 python - <<'PY'
 import os, subprocess, sys, time
