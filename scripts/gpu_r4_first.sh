@@ -28,6 +28,7 @@ run device_commit_$w --workload $w --engine-opt device_commit=1
 run both_$w --workload $w --engine-opt early_critical=1 --engine-opt device_commit=1
 run early_prio_$w --workload $w --engine-opt early_critical=1 --device-opt stream_priority=1
 run early_jobs512_$w --workload $w --engine-opt early_critical=1 --engine-opt max_jobs=512
+run early_round1024_$w --workload $w --engine-opt early_critical=1 --engine-opt round_phases=1024 --device-opt batch=262144    # fewer round launches = fewer tails (a launch is as long as its longest seed)
 done
 python - <<'PY'
 import os, subprocess, sys, time
