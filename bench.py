@@ -432,8 +432,9 @@ def main():
                          "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps, "bytes_per_seed": abytes / S,
                          "peak_measured_stream_triad": triad, "frac_of_measured_peak": achieved / triad if triad > 0 else None,
                          "event_counts": ctr,
-                         "note": "latency-bound integer walk: a launch is as long as its longest seed; n_compat_step of the counting pass is an upper bound within 1% "
-                                 "(speculative results walk older bitmaps), everything else is exact. kernel_ms_per_step is the SUM of the hipEvent-timed durations of every "
+                         "note": "latency-bound integer walk: a launch is as long as its longest seed; the event counts of the named workloads are the CPU oracle's at full size "
+                                 "(bench_event_counts.json; a stats-mode pass of the device reproduces them, n_compat_call / n_compat_step as upper bounds within 0.02%: "
+                                 "speculative results walk older bitmaps). kernel_ms_per_step is the SUM of the hipEvent-timed durations of every "
                                  "process-kernel launch on every stream: the background (side-lane) kernels overlap the synchronous ones, so the sum can exceed the time the "
                                  "GPU was busy and even ms_per_step - it is what a rocprofv3 --stats table of the same command sums to"},
         }

@@ -66,9 +66,10 @@ int main(int argc, char** argv)
     int64_t nb = orc_generate_output(g, p.min_block, blocks, n, st.blocks_found, outDir, &cov, err, sizeof(err));
     if (nb < 0) { fprintf(stderr, "error: %s\n", err); return 1; }
     printf("Blocks found: %lld\nCoverage: %.2f\n", (long long)nb, cov);
-    fprintf(stderr, "oracle: seeds=%lld analyze_s=%.3f seeds_per_s=%.1f walk=%llu occ=%llu compat_call=%llu compat_step=%llu inst_out=%llu failures=%lld\n",
+    fprintf(stderr, "oracle: seeds=%lld analyze_s=%.3f seeds_per_s=%.1f walk=%llu occ=%llu compat_call=%llu compat_step=%llu inst_out=%llu vote=%llu push=%llu process=%llu failures=%lld\n",
             (long long)S, sec, (double)S / sec, (unsigned long long)ctr.n_walk, (unsigned long long)ctr.n_occ,
-            (unsigned long long)ctr.n_compat_call, (unsigned long long)ctr.n_compat_step, (unsigned long long)ctr.n_inst_out, (long long)st.failures);
+            (unsigned long long)ctr.n_compat_call, (unsigned long long)ctr.n_compat_step, (unsigned long long)ctr.n_inst_out,
+            (unsigned long long)ctr.n_vote, (unsigned long long)ctr.n_push, (unsigned long long)ctr.n_process, (long long)st.failures);
     if (dump) {
         mkdir(dump, 0755);
         char fn[4096];

@@ -560,7 +560,7 @@ int main(int argc, char** argv)
                         (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken);
                 fprintf(stderr, "       early critical launches %lld\n", (long long)es.earlyCritical);
                 if (getenv("EMU_EARLY_CRITICAL") && es.recomputeLaunches > 0 && es.earlyCritical == 0) { fprintf(stderr, "early critical launches asked for but none happened\n"); return 1; }
-                if (getenv("EMU_DEVICE_COMMIT") && es.rounds > 1 && es.deviceCommits == 0) { fprintf(stderr, "device-side commit asked for but nothing was committed there\n"); return 1; }
+                if (getenv("EMU_DEVICE_COMMIT") && es.rounds > 1 && es.blocksFound > 0 && es.deviceCommits == 0) { fprintf(stderr, "device-side commit asked for but nothing was committed there\n"); return 1; }
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);
