@@ -92,3 +92,37 @@ def test_reference_legs_are_bounded_and_never_cost_the_line(fake_gpu, monkeypatc
     monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom")))
     line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "1", "--warmup", "0", "--no-cli", "--no-roofline"])
     assert "cpu_baseline" not in line and "boom" in line["cpu_baseline_error"]
+
+
+def test_committed_event_counts_are_the_oracles_at_full_size(built, tmp_path_factory):
+    """bench_event_counts.json is the numerator of the roofline (9 N_walk + 15 N_occ + 16 N_compat_call + N_compat_step +
+    13 N_inst_out). Its counts are the CPU oracle's from runs at full size; config 2 (1.9 M seeds, half a minute of oracle time) is repeated
+    here - counts, conflict count and the hash of the oracle's GFF (= the reference's, tests/golden/fullsize.json). The config-3 line of
+    the file was made the same way (27 minutes of one thread: profiles/r03/README.md)."""
+    import hashlib
+    import subprocess
+    import bench
+    work = os.environ.get("LCB_TEST_WORKLOADS") or str(tmp_path_factory.getbasetemp().parent / "lcb_model_workloads")
+    old = os.environ.get("LCB_BENCH_DIR")
+    os.environ["LCB_BENCH_DIR"] = work
+    try:
+        w = bench.ensure_workload("ecoli10")
+    finally:
+        if old is None:
+            os.environ.pop("LCB_BENCH_DIR", None)
+        else:
+            os.environ["LCB_BENCH_DIR"] = old
+    out = str(tmp_path_factory.mktemp("orc10"))
+    r = subprocess.run([os.path.join(ROOT, "oracle", "lcb_oracle"), "--graph", w["graph"], w["fasta"], "-k", str(w["k"]), "-b", str(w["b"]), "-m", str(w["m"]),
+                        "-a", str(w["a"]), "-o", out, "--noseq"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    line = [ln for ln in r.stderr.splitlines() if ln.startswith("oracle:")][-1]
+    kv = dict(x.split("=") for x in line.split()[1:])
+    known = json.load(open(os.path.join(ROOT, "bench_event_counts.json")))["ecoli10"]
+    assert known["lcb_synth"] == w["synth"] and known["seeds"] == int(kv["seeds"])
+    for name, key in (("n_walk", "walk"), ("n_occ", "occ"), ("n_compat_call", "compat_call"), ("n_compat_step", "compat_step"), ("n_inst_out", "inst_out"),
+                      ("n_vote", "vote"), ("n_push", "push"), ("n_process", "process")):
+        assert known["event_counts"][name] == int(kv[key]), name
+    assert known["failures"] == int(kv["failures"])
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["config2_ecoli10_a150"]
+    assert hashlib.sha256(open(os.path.join(out, "blocks_coords.gff"), "rb").read()).hexdigest() == full["gff_sha256"]
