@@ -4,6 +4,8 @@
 #     parity tests, then A/B on config 3 / config 2 / the k = 25 shapes;
 #  2. the reference at -t 32 on the k = 25 test-size shapes beside the whole sibeliaz-lcb process (<= 0.5 x);
 #  3. the bench line of the default build with the bounded CPU-baseline protocol.
+# Before the call (build container): `python sibeliaz_amd/build.py variant nwc4 -DLCB_NW_COMPACT=4` (the compact variant with four wavefronts:
+# round 2 measured it on the 62-strain workload only; the k = 25 shapes vote with ~15 voters per vote, 7-8 chunks per wavefront at two)
 mkdir -p gpurun_out/r4a
 O=gpurun_out/r4a
 export LCB_WATCHDOG_S=300
@@ -30,6 +32,9 @@ run early_prio_$w --workload $w --engine-opt early_critical=1 --device-opt strea
 run early_jobs512_$w --workload $w --engine-opt early_critical=1 --engine-opt max_jobs=512
 run early_round1024_$w --workload $w --engine-opt early_critical=1 --engine-opt round_phases=1024 --device-opt batch=262144    # fewer round launches = fewer tails (a launch is as long as its longest seed)
 done
+if [ -f sibeliaz_amd/libsibeliaz_amd_nwc4.so ]; then
+for w in primates8_test mice16_test ecoli10; do LCB_LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_nwc4.so run nwc4_$w --workload $w; done
+fi
 python - <<'PY'
 import os, subprocess, sys, time
 sys.path.insert(0, os.getcwd())
