@@ -80,6 +80,26 @@ struct OracleProc : LcbProcessor {
         return 1;
     }
     void sideRelease(int lane) override { lanes[(size_t)lane].busy = false; }
+    // the engine's early critical launch (MODEL_EARLY=1): computed at the begin (nothing changes the state before the end), handed out at the end
+    bool begun = false;
+    int64_t bReady = 0;
+    std::vector<uint64_t> bOff, bFpOff; std::vector<lcb_instance> bInst; std::vector<lcb_fp> bFp;
+    bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize) override
+    {
+        if (!anySize || begun) return false;
+        const int64_t t0 = now;
+        process(seeds, nullptr, n, bOff, bInst, bFpOff, bFp);
+        bReady = now; now = t0;                 // on the virtual clock the launch runs beside whatever the engine does until the end
+        begun = true;
+        return true;
+    }
+    void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
+    {
+        if (!begun) throw LcbError("processEnd without processBegin");
+        begun = false;
+        if (now < bReady) now = bReady;
+        off = bOff; inst = bInst; fpOff = bFpOff; fp = bFp;
+    }
 
     void setRange(orc_graph* o, uint64_t lo, uint64_t hi, std::vector<uint8_t*>* undo)
     {
@@ -227,6 +247,7 @@ int main(int argc, char** argv)
         if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
         cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
         cfg.relaxViews = envInt("MODEL_RELAX", 0) != 0;
+        cfg.earlyCritical = envInt("MODEL_EARLY", 0) != 0;
         std::vector<lcb_block> blocks;
         LcbEngineStats es;
         const auto t0 = std::chrono::steady_clock::now();
@@ -250,6 +271,7 @@ int main(int argc, char** argv)
         fprintf(stderr, "model: %zu seeds, %zu blocks, failures %lld, rounds %lld, job launches %lld (%lld jobs, %lld used), conflict launches %lld, over-predicted %lld, %.1f s\n",
                 seeds.size(), blocks.size(), (long long)es.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds, (long long)es.jobsUsed,
                 (long long)es.conflictLaunches, (long long)es.overPredicted, sec);
+        if (cfg.earlyCritical) fprintf(stderr, "model: early critical launches %lld of %lld stops\n", (long long)es.earlyCritical, (long long)es.recomputeLaunches);
         fprintf(stderr, "model: host ms: engine %.0f = processor %.0f + dry runs %.0f + commit / validation / other %.0f\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs);
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,

@@ -214,7 +214,8 @@ def test_engine_model_reproduces_the_oracle(built, case_dir, name, relax):
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
 
 
-@pytest.mark.parametrize("env", [{}, {"LCB_MAX_JOBS": "64", "LCB_EAGER_PHASES": "2"}, {"MODEL_RELAX": "1", "LCB_PREDICT_F": "2"}])
+@pytest.mark.parametrize("env", [{}, {"LCB_MAX_JOBS": "64", "LCB_EAGER_PHASES": "2"}, {"MODEL_RELAX": "1", "LCB_PREDICT_F": "2"},
+                                 {"MODEL_SIDE_LANES": "2", "MODEL_EARLY": "1"}])      # asynchronous job batches on a virtual clock + the early critical launch
 def test_engine_model_at_scale(built, tmp_path_factory, env):
     """The round engine over 176 000 seeds (config 2 at a tenth of the segments: the emulator cannot reach this size) with the
     oracle as the processor: rounds that grow to 256 phases, hundreds of job launches against predicted views, all with the
