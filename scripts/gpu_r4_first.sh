@@ -23,14 +23,11 @@ except Exception as e:
     print("$v: FAILED", e); print(open("$O/$v.err").read()[-800:])
 PY
 }
+# one load of the workload, every variant one pass on the same box (scripts/ab_engine.py); the blocks of all variants must be equal
+V="base early:early_critical=1 dc:device_commit=1 both:early_critical=1,device_commit=1 early_prio:early_critical=1,dev.stream_priority=1 \
+early_jobs512:early_critical=1,max_jobs=512 early_round1024:early_critical=1,round_phases=1024,dev.batch=262144 base_again"
 for w in ecoli62 ecoli10 primates8_test mice16_test; do
-run base_$w --workload $w
-run early_critical_$w --workload $w --engine-opt early_critical=1
-run device_commit_$w --workload $w --engine-opt device_commit=1
-run both_$w --workload $w --engine-opt early_critical=1 --engine-opt device_commit=1
-run early_prio_$w --workload $w --engine-opt early_critical=1 --device-opt stream_priority=1
-run early_jobs512_$w --workload $w --engine-opt early_critical=1 --engine-opt max_jobs=512
-run early_round1024_$w --workload $w --engine-opt early_critical=1 --engine-opt round_phases=1024 --device-opt batch=262144    # fewer round launches = fewer tails (a launch is as long as its longest seed)
+  timeout 900 python scripts/ab_engine.py --workload $w $V > $O/ab_$w.txt 2> $O/ab_$w.err; cat $O/ab_$w.txt; tail -3 $O/ab_$w.err
 done
 if [ -f sibeliaz_amd/libsibeliaz_amd_nwc4.so ]; then
 for w in primates8_test mice16_test ecoli10; do LCB_LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_nwc4.so run nwc4_$w --workload $w; done

@@ -126,3 +126,19 @@ def test_committed_event_counts_are_the_oracles_at_full_size(built, tmp_path_fac
     assert known["failures"] == int(kv["failures"])
     full = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["config2_ecoli10_a150"]
     assert hashlib.sha256(open(os.path.join(out, "blocks_coords.gff"), "rb").read()).hexdigest() == full["gff_sha256"]
+
+
+def test_ab_driver_runs_every_variant_once_loaded(fake_gpu, monkeypatch, capsys):
+    """scripts/ab_engine.py (same-box A/B of engine / device knobs with one load of the workload): variants are parsed into engine and
+    device options, a device is shared by the variants with equal device options, one summary line per variant."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ab_engine", os.path.join(ROOT, "scripts", "ab_engine.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    assert ab.parse_variant("x:early_critical=1,dev.stream_priority=1,max_jobs=64") == ("x", {"stream_priority": 1}, {"early_critical": 1, "max_jobs": 64})
+    assert ab.parse_variant("base") == ("base", {}, {})
+    monkeypatch.setattr(sys, "argv", ["ab_engine.py", "--workload", "ecoli10_tiny", "--threads", "2", "base", "early:early_critical=1", "prio:dev.stream_priority=1"])
+    ab.main()
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out[0].startswith("ecoli10_tiny:") and [ln.split(":")[0] for ln in out[1:]] == ["base", "early", "prio"]
+    assert "DIFFER" not in "".join(out)
