@@ -6,6 +6,8 @@
 #  3. the bench line of the default build with the bounded CPU-baseline protocol.
 # Before the call (build container): `python sibeliaz_amd/build.py variant nwc4 -DLCB_NW_COMPACT=4` (the compact variant with four wavefronts:
 # round 2 measured it on the 62-strain workload only; the k = 25 shapes vote with ~15 voters per vote, 7-8 chunks per wavefront at two)
+# and `python sibeliaz_amd/build.py variant ahead -DLCB_PUSH_AHEAD=1` (the compact variant's pushes as a software pipeline: a push waits for no
+# global load of its own; exact under the emulator, 155 instead of 143 VGPRs, same occupancy).
 mkdir -p gpurun_out/r4a
 O=gpurun_out/r4a
 export LCB_WATCHDOG_S=300
@@ -29,6 +31,9 @@ early_jobs512:early_critical=1,max_jobs=512 early_round1024:early_critical=1,rou
 for w in ecoli62 ecoli10 primates8_test mice16_test; do
   timeout 900 python scripts/ab_engine.py --workload $w $V > $O/ab_$w.txt 2> $O/ab_$w.err; cat $O/ab_$w.txt; tail -3 $O/ab_$w.err
 done
+if [ -f sibeliaz_amd/libsibeliaz_amd_ahead.so ]; then
+for w in ecoli62 primates8_test mice16_test ecoli10; do LCB_LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_ahead.so run ahead_$w --workload $w; run stock_$w --workload $w; done
+fi
 if [ -f sibeliaz_amd/libsibeliaz_amd_nwc4.so ]; then
 for w in primates8_test mice16_test ecoli10; do LCB_LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_nwc4.so run nwc4_$w --workload $w; done
 fi

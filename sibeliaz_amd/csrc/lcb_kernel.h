@@ -41,6 +41,12 @@
 #include <stdint.h>
 
 #define LCB_EMPTY_KEY INT32_MIN
+// Experiment (round 3, not measured yet, off): the pushes of an edge batch in the compact variant run as a software pipeline - the
+// occurrence records of edge l+2, the chromosome bounds and `used` words of edge l+1 and the home slot of vertex l+1 in the path set are
+// requested before edge l is pushed, so that a push waits for no global load of its own (see lcb_extend).
+#ifndef LCB_PUSH_AHEAD
+#define LCB_PUSH_AHEAD 0
+#endif
 // A pointer the compiler cannot prove to be a global one (it was merged with a null) is dereferenced with FLAT loads, which wait on
 // two counters and are slower; this says what it is. (Device compiler only: the CPU emulator of the tests sees a plain pointer.)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -315,6 +321,7 @@ struct LcbStateT {
     int32_t ckFlank;
     // wave-uniform scalars
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
+    uint32_t lastIns;                // slot of the path set the newest insert wrote (a home slot read before that insert is stale if it is this one)
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
     uint32_t* dbg;             // flight recorder of this workgroup (may be null)
     const uint32_t* abort;     // stop flag of an asynchronous batch (null: none)
@@ -474,6 +481,49 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
         }
     }
     S.nPath++;
+    S.lastIns = h;
+    LCB_SYNC_IF(PL);
+}
+
+// The probe of a push with the home slot's key already at hand (key0 = pKeys[hash(vid)], possibly read one push earlier): walks the
+// chain to vid or to the first empty slot - where vid goes if it is not in the set, so the insert needs no probe of its own.
+template <bool PROF, class ST>
+__device__ inline bool lcb_path_probe_from(ST& S, int32_t vid, int32_t key0, uint32_t& slot)
+{
+    uint32_t h = lcb_hash(vid, S.pathShift);
+    const uint32_t mask = S.pathCap - 1;
+    uint32_t probe = 0;
+    int32_t k = key0;
+    while (k != vid && k != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; k = S.pKeys[h]; }
+    if (PROF && probe > S.pfMaxProbe) S.pfMaxProbe = probe;
+    slot = h;
+    return k == vid;
+}
+
+// lcb_path_insert with the empty slot already found (lcb_path_probe_from). Wave-uniform; lane 0 writes.
+template <class ST>
+__device__ inline void lcb_path_insert_at(ST& S, int32_t vid, uint32_t h)
+{
+    if ((S.nPath + 1) * 2 > S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
+#ifdef LCB_EMU_HIP_RUNTIME_H
+    // (builds of the CPU wavefront emulator only: the slot found with a key that was read one push ahead must still be empty)
+    if (S.pKeys[h] != LCB_EMPTY_KEY) { fprintf(stderr, "emu: lcb_path_insert_at would overwrite an occupied slot of the path set\n"); abort(); }
+#endif
+    constexpr bool PL = LcbCfg<ST::MODE>::PC != 0;
+    LCB_SYNC_IF(PL);               // every lane has finished probing before lane 0 publishes the key
+#if LCB_PATH_SIG
+    if (S.sig) { if (S.nSig < S.sigCap && S.lane == 0) S.sig[S.nSig] = vid; S.nSig++; }
+#endif
+    if (S.lane == 0) {
+        S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
+        if (LcbCfg<ST::MODE>::BW) {
+            const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
+            S.bloom[a >> 5] |= 1u << (a & 31);
+            S.bloom[b >> 5] |= 1u << (b & 31);
+        }
+    }
+    S.nPath++;
+    S.lastIns = h;
     LCB_SYNC_IF(PL);
 }
 
@@ -961,24 +1011,36 @@ struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posI
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
 // rec0: the occurrence records o0 + lane of the pushed vertex, already loaded by the caller.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
+// What the caller of a push may have requested ahead of it (LCB_PUSH_AHEAD, compact variant): the finished first chunk of occurrences
+// and the key in the home slot of the pushed vertex.
+struct LcbPushAhead { LcbOcc occ; int32_t key0; uint32_t home; };
+
 template <bool BACK, bool STATS, bool PROF, class ST>
-__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
+__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0, const LcbPushAhead* ahead = nullptr)
 {
     const LcbTables& T = S.T;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
     const uint32_t o0 = E.o0, o1 = E.o1;
     // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
-    LcbOcc occ = lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
-    bool inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
-    if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
+    LcbOcc occ = ahead ? ahead->occ : lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
+    uint32_t slot = 0;
+    bool inPath;
+    if (ahead) {
+        // (a key read before the newest insert wrote that very slot is stale: read it again)
+        const int32_t key0 = ahead->home != S.lastIns ? ahead->key0 : S.pKeys[ahead->home];
+        inPath = lcb_path_probe_from<PROF>(S, vertex, key0, slot);
+    } else {
+        inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
+        if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
+    }
     if (inPath) return false;
     const uint32_t length = lcb_absdiff(E.posN, E.posIt);
     const int32_t ech = E.ech;
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
     if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
     const int32_t distance = (int32_t)dist64;
-    lcb_path_insert(S, vertex);
+    if (ahead) lcb_path_insert_at(S, vertex, slot); else lcb_path_insert(S, vertex);
     if (S.status) return false;
 
     const int64_t B = S.P.maxBranch;
@@ -1302,6 +1364,19 @@ __device__ __forceinline__ LcbEdge lcb_edge_of(const LcbEdgeBatch& b, uint32_t l
     return e;
 }
 
+// LCB_PUSH_AHEAD: what the push of edge l of the batch will need, requested now (rec = the occurrence records of its first chunk).
+template <class ST>
+__device__ __forceinline__ LcbPushAhead lcb_push_ahead(const ST& S, const LcbEdgeBatch& b, uint32_t l, const uint4& rec)
+{
+    LcbPushAhead a;
+    const uint32_t p0 = lcb_rl(b.o0, l), p1 = lcb_rl(b.o1, l);
+    a.occ = lcb_finish_occ(S.T, S.U, rec, p0 + S.lane < p1);
+    const int32_t idN = lcb_rl(b.idN, l);
+    a.home = lcb_hash(lcb_rl(b.itPos, l) != 0 ? idN : -idN, S.pathShift);
+    a.key0 = S.pKeys[a.home];
+    return a;
+}
+
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
 template <bool FORWARD, bool STATS, bool PROF, int NW, class ST>
 __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
@@ -1332,13 +1407,24 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
             if (nE == 0) break;                                      // defensive: a voted vertex is always reached
             // occurrence records of the first edge; those of edge l+1 are requested before edge l is pushed
             uint4 rec = lcb_load_rec(T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            // (compact variant, LCB_PUSH_AHEAD: a pipeline two edges deep - records of edge l+2, bounds / `used` words / home slot of edge l+1)
+            constexpr bool AHEAD = LCB_PUSH_AHEAD != 0 && ST::MODE == 0;
+            uint4 recA = uint4{0u, 0u, 0u, 0u};                      // AHEAD: records of edge l+1
+            LcbPushAhead pa, paN;
+            if (AHEAD) {
+                pa = lcb_push_ahead(S, bt, 0, rec);
+                if (nE > 1) { const uint32_t p0 = lcb_rl(bt.o0, 1), p1 = lcb_rl(bt.o1, 1); recA = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+            }
             for (uint32_t l = 0; l < nE; l++) {
                 const LcbEdge E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+                if (AHEAD) {
+                    if (l + 2 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 2), p1 = lcb_rl(bt.o1, l + 2); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+                    if (l + 1 < nE) paN = lcb_push_ahead(S, bt, l + 1, recA);
+                } else if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
                 LCB_MARK(S, 6, 3); LCB_MARK(S, 8, E.gIt);
                 const uint64_t tp0 = PROF ? wall_clock64() : 0;
-                success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec);
+                success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec, AHEAD ? &pa : nullptr);
                 const uint64_t tp1 = PROF ? wall_clock64() : 0;
                 if (PROF) S.pfTPush += tp1 - tp0;
                 LCB_MARK(S, 6, 4);
@@ -1356,7 +1442,7 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
                     }
                     if (PROF) S.pfTScore += wall_clock64() - tp1;
                 }
-                rec = recN;
+                if (AHEAD) { rec = recA; recA = recN; pa = paN; } else rec = recN;
             }
             if (nE < 64 || (positive ? lcb_rl(bt.idN, 63) : -lcb_rl(bt.idN, 63)) == next) break;
             g = (uint32_t)((int64_t)g + 64 * dir);
@@ -1405,12 +1491,22 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
             LcbEdgeBatch bt;
             lcb_batch_from_body(S, from, nE, bt);
             uint4 rec = lcb_load_rec(S.T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            constexpr bool AHEAD = LCB_PUSH_AHEAD != 0 && MODE == 0;     // (the pipeline of lcb_extend)
+            uint4 recA = uint4{0u, 0u, 0u, 0u};
+            LcbPushAhead pa, paN;
+            if (AHEAD) {
+                pa = lcb_push_ahead(S, bt, 0, rec);
+                if (nE > 1) { const uint32_t p0 = lcb_rl(bt.o0, 1), p1 = lcb_rl(bt.o1, 1); recA = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+            }
             for (uint32_t l = 0; l < nE && !S.status; l++) {
                 const LcbEdge E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
-                lcb_push<true, STATS, PROF>(S, E, false, rec);
-                rec = recN;
+                if (AHEAD) {
+                    if (l + 2 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 2), p1 = lcb_rl(bt.o1, l + 2); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+                    if (l + 1 < nE) paN = lcb_push_ahead(S, bt, l + 1, recA);
+                } else if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+                lcb_push<true, STATS, PROF>(S, E, false, rec, AHEAD ? &pa : nullptr);
+                if (AHEAD) { rec = recA; recA = recN; pa = paN; } else rec = recN;
             }
             from += nE;
         }
@@ -1549,7 +1645,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.abort = W.abort;
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
-    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
+    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0; S.lastIns = 0xFFFFFFFFu;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
     S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;

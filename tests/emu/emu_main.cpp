@@ -92,6 +92,7 @@ struct Emu {
             LcbWork& W = c.W;
             // capacities as the product's device.hip chooses them per kernel variant (compact / wide / big / huge)
             W.pathCap = 65536; W.bodyCap = 32768;
+            if (getenv("EMU_PATH_CAP")) { W.pathCap = (uint32_t)atoi(getenv("EMU_PATH_CAP")); W.bodyCap = W.pathCap / 2; }   // tiny path sets: long probe chains, colliding home slots
             W.bestCap = mode == 0 ? LcbCfg<0>::IC : (mode == 1 ? LcbCfg<1>::IC : (mode == 2 ? LcbCfg<2>::IC : 8192));
             W.instCap = mode == 2 ? LcbCfg<2>::IC : (mode == 3 ? 8192 : 0); W.voteCap = mode == 3 ? 65536 : 0;
             W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr;

@@ -131,6 +131,7 @@ def test_cli_usage_errors(built, case, tmp_path):
 EMU = os.path.join(ROOT, "tests", "emu", "build", "emu_check")
 EMU_SHARE = os.path.join(ROOT, "tests", "emu", "build", "emu_check_share8")   # tiny LCB_VOTE_SHARE_MIN: all-waves reduce/clear path
 EMU_SIG = os.path.join(ROOT, "tests", "emu", "build", "emu_check_sig")        # -DLCB_PATH_SIG=1: path signatures for the engine's relaxViews rule
+EMU_AHEAD = os.path.join(ROOT, "tests", "emu", "build", "emu_check_ahead")    # -DLCB_PUSH_AHEAD=1: the compact variant's pushes as a software pipeline
 
 
 @pytest.fixture(scope="session")
@@ -183,6 +184,11 @@ def emu_built():
                                             ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
                                             ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
+                                            # round-3 candidate (-DLCB_PUSH_AHEAD=1): the compact variant requests what the next two pushes need ahead of them;
+                                            # counters, footprints, a small path set (colliding home slots: the stale-key guard), the engine
+                                            ("collinear6", "seeds-init", {"EMU_LIMIT": "600", "EMU_AHEAD": "1"}), ("nruns_abund", "seeds-final", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1000", "EMU_FP_CHECK": "1", "EMU_AHEAD": "1"}),
+                                            ("collinear6", "seeds-init", {"EMU_NOSTATS": "1", "EMU_LIMIT": "800", "EMU_PATH_CAP": "4096", "EMU_AHEAD": "1"}),
+                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_AHEAD": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
@@ -192,6 +198,9 @@ def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode
     from tests.conftest import Case
     c = Case(name, case_dir)
     exe = EMU_SHARE if env.get("EMU_SHARE") else (EMU_SIG if env.get("EMU_SIG") else emu_built)
+    if env.get("EMU_AHEAD"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/emu_check_ahead"])
+        exe = EMU_AHEAD
     r = subprocess.run([exe, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
                        env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
