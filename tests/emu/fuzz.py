@@ -14,7 +14,7 @@ cases inside the CPU suite; the open-ended campaign is this script.
 import os, random, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BIN = ROOT + "/sibeliaz_amd/bin"
-EMU = ROOT + "/tests/emu/build/emu_check"
+EMU = os.environ.get("LCB_FUZZ_EMU") or ROOT + "/tests/emu/build/emu_check"      # (another build of the harness, e.g. build/emu_check_ahead)
 
 
 def case_params(i, small=False):
