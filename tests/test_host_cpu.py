@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol(built):
     assert set(sibeliaz_amd.api.EXPORTS) <= declared
 
 
+def test_ctypes_structs_have_the_layout_of_the_header(built, tmp_path):
+    """The binding's ctypes mirrors of the C-ABI structs (sibeliaz_amd/api.py) against include/lcb.h compiled by gcc: sizes of all of them,
+    offsets of the last fields of the ones that keep growing."""
+    import ctypes as C
+    from sibeliaz_amd import api
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lcb.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lcb_stats), sizeof(lcb_hooks), '
+                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, early_critical), offsetof(lcb_hooks, early_critical), '
+                   'offsetof(lcb_device_opts, stream_priority)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    want = [C.sizeof(api.Stats), C.sizeof(api.Hooks), C.sizeof(api.DeviceOpts), sibeliaz_amd.SEED_DTYPE.itemsize, sibeliaz_amd.BLOCK_DTYPE.itemsize,
+            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.early_critical.offset, api.Hooks.early_critical.offset, api.DeviceOpts.stream_priority.offset]
+    assert got == want
+
+
 def test_device_fails_loudly_without_gpu(built, case):
     st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
     try:
