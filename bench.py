@@ -421,6 +421,8 @@ def main():
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
                        "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]), "early_rounds": int(st["early_rounds"]),
                        "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
+                       "opt_in": {"early_critical_launches": int(st.get("early_critical", 0)), "device_commits": int(st.get("device_commits", 0)),
+                                  "device_rounds": int(st.get("device_rounds", 0))},      # (0 unless asked for with --engine-opt)
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())) if gpus is None else None,
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
