@@ -50,4 +50,25 @@ for wl in ("primates8_test", "mice16_test"):
     same = isinstance(r, tuple) and bench.md5(r[2]) == bench.md5(os.path.join(w["dir"], "cli", "blocks_coords.gff"))
     print("%s: reference -t 32 whole process %s s (analyze %s s) | sibeliaz-lcb on the MI355X whole process %.1f s rc %d | gff equal %s" % (wl, "%.1f" % r[1] if isinstance(r, tuple) else r, "%.1f" % r[0] if isinstance(r, tuple) else "-", ours, p.returncode, same))
 PY
-timeout 2000 python bench.py --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-1500 $O/bench_n1.json
+# section timers of the heavy seeds on the current build (instrumented variant): repeated votes, voters and chunks per vote
+LCB_VERBOSE=1 LCB_TRACE_SEEDS=1 LCB_TRACE_LAUNCHES=$O/trace.tsv timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline > $O/prof.json 2> $O/prof.err
+python - <<'PY'
+rows = []
+mode = {}
+for line in open("gpurun_out/r4a/trace.tsv"):
+    f = line.rstrip("\n").split("\t")
+    if f[0] != "#seed":
+        mode[int(f[0])] = f[3]; continue
+    d = dict(x.split("=") for x in f[4:]); d = {k: int(v) for k, v in d.items()}; d["launch"] = int(f[1]); rows.append(d)
+for md in ("compact", "wide", "big"):
+    for lo, hi in ((50, 500), (500, 10**9)):
+        sel = [d for d in rows if mode.get(d["launch"]) == md and lo <= d["vote"] < hi]
+        if not sel: continue
+        S = lambda k: sum(d[k] for d in sel)
+        nv = S("vote")
+        print("%s votes [%d,%d): %d seeds %.1f s | per vote: total %.2f us = walk %.2f + waitB %.2f + reduce %.2f | touch/vote %.1f, wave-0 voters/vote %.2f chunks/vote %.2f, repeated votes (probe) %.3f | per push %.2f us, score %.2f us, pushes/vote %.2f inst %.0f" % (
+            md, lo, hi, len(sel), S("ticks") / 1e8, S("tv") / 100.0 / nv, S("cwalk") / 100.0 / nv, S("cwaitb") / 100.0 / nv, S("creduce") / 100.0 / nv,
+            S("touch") / nv, S("voters") / nv, S("chunks") / nv, S("probe") / nv, S("tp") / 100.0 / S("push"), S("ts") / 100.0 / S("push"), S("push") / nv, S("inst") / len(sel)))
+PY
+python scripts/analyze_trace.py $O/trace.tsv > $O/trace_summary.txt 2>&1; head -30 $O/trace_summary.txt
+grep -v "^#seed" $O/trace.tsv > $O/launch_trace.tsv; rm -f $O/trace.tsv
