@@ -259,7 +259,6 @@ def main():
     ap.add_argument("--verify-counts", action="store_true", help="count the events again (a 3-minute stats-mode pass) when the committed counts were counted by a build of other sources; "
                     "they are a property of input and parameters, so the default run uses them as they are")
     ap.add_argument("--write-counts", action="store_true", help="store the counts of this run's counting pass in bench_event_counts.json (with the hash of the sources)")
-    ap.add_argument("--overlap", action="store_true", help="A/B: begin the next round's launch while this round is committed (measured slower)")
     ap.add_argument("--no-cli", action="store_true", help="skip the whole-process wall-clock run of sibeliaz-lcb")
     ap.add_argument("--device-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: a field of lcb_device_opts (e.g. path_cap=8192)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: an engine field of lcb_hooks (e.g. max_jobs=256)")
@@ -301,8 +300,6 @@ def main():
     t = time.time()
     dev_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.device_opt}
     engine_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.engine_opt}
-    if args.overlap:
-        engine_opts["overlap"] = 1
     gpus = None
     if in_process:
         gpus = sibeliaz_amd.GpuSet(storage, params, list(range(args.gpus)), **dev_opts)      # tables resident in the HBM of every GPU, RCCL initialised
@@ -419,10 +416,10 @@ def main():
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
-                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]), "early_rounds": int(st["early_rounds"]),
+                       "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]),
                        "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
-                       "opt_in": {"early_critical_launches": int(st.get("early_critical", 0)), "device_commits": int(st.get("device_commits", 0)),
-                                  "device_rounds": int(st.get("device_rounds", 0))},      # (0 unless asked for with --engine-opt)
+                       "early_critical_launches": int(st.get("early_critical", 0)),
+                       "device_resident_commit": {"results": int(st.get("device_commits", 0)), "whole_rounds": int(st.get("device_rounds", 0))},
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())) if gpus is None else None,
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},

@@ -78,7 +78,7 @@ typedef struct {
     int64_t failures;       /* failure_ : ordered-commit conflicts that were re-processed (blocksfinder.h:406) */
     int64_t launches;       /* kernel launches */
     int64_t big_retries;    /* seeds re-run with global-memory workspaces after an LDS capacity overflow */
-    double kernel_ms;       /* sum of hipEvent-timed kernel durations on the device's stream */
+    double kernel_ms;       /* sum of the hipEvent-timed kernel durations over the device's streams (see kernel_busy_ms) */
     double wall_ms;         /* wall time of the phase loop */
     int64_t rounds;             /* speculative multi-phase launches */
     int64_t recompute_launches; /* job launches: after a stop of the ordered commit, every seed the dry run expects to need a new result */
@@ -93,7 +93,6 @@ typedef struct {
     double plan_ms;             /* wall time of the dry runs */
     lcb_counters events;        /* lcb_hooks.count_events: the reference-semantics event counts of the whole FindBlocks (phase-start
                                    Process() of every seed + the re-Process() of every commit conflict), else zero */
-    int64_t early_rounds;       /* rounds whose speculative launch ran on the GPU while the host was committing the previous round */
     int64_t side_batches;       /* asynchronous job batches (side lanes): a stop waits only for the results it cannot go on without */
     int64_t side_jobs;          /* ... their jobs (also counted in recomputed_seeds) */
     int64_t side_taken;         /* ... results taken when the commit reached their seed */
@@ -101,13 +100,20 @@ typedef struct {
     int64_t side_failed;        /* ... jobs that ended without a result (stopped, or needed another kernel variant) */
     int64_t device_commits;     /* results validated, conflict-checked and marked used by the device-side commit kernel (the host mirrors them) */
     int64_t device_rounds;      /* ... rounds it committed from the first to the last seed */
-    int64_t early_critical;     /* stops whose own jobs were computed while the host planned the rest (lcb_hooks.early_critical) */
+    int64_t early_critical;     /* stops whose own jobs were computed while the host planned the rest */
+    double kernel_busy_ms;      /* UNION of the hipEvent-timed kernel intervals of all streams: the time the GPU was busy with process kernels
+                                   (kernel_ms is their SUM; the side lanes' kernels run beside the synchronous ones, so the sum can exceed the pass) */
+    double kernel_side_ms;      /* the part of kernel_ms that ran on the side lanes' streams */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
 const char* lcb_last_error(void);
 /* Library version string. */
 const char* lcb_version(void);
+/* Layout version of the structs of this header (lcb_stats, lcb_hooks, lcb_device_opts): they are allocated by the caller, so a caller
+ * built against another LCB_ABI_VERSION must not call in. lcb_abi_version() returns the library's. */
+#define LCB_ABI_VERSION 4
+int lcb_abi_version(void);
 
 /* ---- graph: JunctionStorage::Init (junctionstorage.h:572-650), junctionapi.h:80-98, streamfastaparser.cpp:28-92 */
 lcb_graph* lcb_graph_load(const char* junction_file, const char* const* fasta_files, int n_fasta,
@@ -149,9 +155,8 @@ typedef struct {
                                 default 1 << 22; enlarged x4 when a launch fills it (its unlucky seeds run again) */
     uint32_t side_lanes;     /* asynchronous job batches that can be in flight beside the synchronous launches (own streams, buffers,
                                 workspace slots and predicted views each); default 4; 0xFFFFFFFF = none */
-    uint32_t stream_priority;/* 1: the stream of the synchronous launches (the results the commit waits for) gets the highest HIP stream
-                                priority and the side lanes' streams the lowest, so that speculation that fills the machine does not delay a
-                                needed result; default 0 = all streams alike (not measured yet) */
+                             /* (the stream of the synchronous launches - the results the commit waits for - has the highest HIP stream priority,
+                                the side lanes' streams the lowest: speculation that fills the machine does not delay a needed result) */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows
@@ -235,20 +240,12 @@ typedef struct {
                                    2 the still-free instances of its phase-start result, 3 (default) a stale re-processed result if any, else as 2 */
     int32_t exchange_always;    /* 1: a single rank still packs / all-gathers / unpacks every launch (tests of the exchange path) */
     int32_t count_events;       /* 1: fill lcb_stats.events (the device must be in stats mode; one rank) */
-    int32_t overlap;            /* 1: run the next round's speculative launch while this round is being committed (measured slower
-                                   on configs 2 and 3, so off by default) */
-    int32_t relax_views;        /* 1 (experimental, needs a library built with -DLCB_PATH_SIG=1; an error otherwise): a predicted mark
-                                   that did not come true voids a job's result only if the job can have read it */
-    int32_t device_commit;      /* 1: the clean prefix of every round - phase-start results that are still exact, results that pass the weak
-                                   conflict check - is validated, committed and marked used by a kernel on the device (lcb_commit_kernel); the
-                                   host mirrors those commits and takes over at the first seed that needs a new computation.
-                                   Off by default: exact under the CPU wavefront emulator, not yet run on the MI355X (round 3 ran out of GPU time) */
     int32_t sync_jobs;          /* 1: do not use the device's side lanes - every job of a stop's plan runs in one synchronous launch
-                                   (the round-2 engine; for A/B runs and tests) */
-    int32_t early_critical;     /* 1 (with side lanes): the results a stop cannot go on without - the re-processing of the stopping seed, or
-                                   the missing phase-start results of the phase about to start - are launched BEFORE the dry run that plans
-                                   the rest of the stop's jobs, which then runs in the shadow of that kernel instead of in front of it.
-                                   Off by default: written after round 3 had used up its GPU time; exact under the CPU wavefront emulator */
+                                   (the round-2 engine; for A/B runs and tests). With side lanes the results a stop cannot go on without
+                                   are launched BEFORE the dry run that plans the rest of the stop's jobs (measured: profiles/r04/ab_first.txt) */
+    int32_t host_commit;        /* 1: the ordered commit of a round runs on the host only (for A/B runs and tests). Default: the clean prefix of
+                                   every round is validated, conflict-checked and marked used by lcb_commit_kernel on the device, chained behind
+                                   the round's kernels; the host mirrors those commits and takes over at the first seed that needs a new result */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

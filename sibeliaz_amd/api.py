@@ -36,8 +36,9 @@ class Stats(C.Structure):
                 ("big_retries", C.c_int64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double), ("rounds", C.c_int64),
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
-                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [("early_rounds", C.c_int64)] + [
-                    (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "device_commits", "device_rounds", "early_critical")]
+                ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [
+                    (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "device_commits", "device_rounds", "early_critical")] + [
+                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -52,16 +53,16 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("overlap", C.c_int32), ("relax_views", C.c_int32), ("device_commit", C.c_int32), ("sync_jobs", C.c_int32), ("early_critical", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("host_commit", C.c_int32)]
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "overlap", "relax_views", "device_commit", "sync_jobs", "early_critical")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "host_commit")
 
 
 class DeviceOpts(C.Structure):
     """lcb_device_opts: tuning knobs of a device, 0 = default."""
     _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
-                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes", "stream_priority")]
+                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")]
 
 
 class Counters(C.Structure):
@@ -71,12 +72,14 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
 
+ABI_VERSION = 4        # LCB_ABI_VERSION of include/lcb.h: layout of Stats, Hooks, DeviceOpts
+
 REPROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
 
 _lib = None
 
 EXPORTS = [
-    "lcb_last_error", "lcb_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
+    "lcb_last_error", "lcb_version", "lcb_abi_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
     "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
     "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
     "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_process_seeds_fp", "lcb_device_kernel_time", "lcb_committer_create",
@@ -97,6 +100,8 @@ def load_library():
     vp, i64, u64p = C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)
     L.lcb_last_error.restype = C.c_char_p
     L.lcb_version.restype = C.c_char_p
+    if not hasattr(L, "lcb_abi_version") or L.lcb_abi_version() != ABI_VERSION:
+        raise LcbError("%s has another struct layout version than this binding (LCB_ABI_VERSION %d): rebuild it" % (path, ABI_VERSION))
     L.lcb_graph_load.restype = vp
     L.lcb_graph_load.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcb_graph_free.argtypes = [vp]

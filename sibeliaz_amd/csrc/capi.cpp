@@ -27,7 +27,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.deviceCommit = hooks->device_commit != 0; cfg.earlyCritical = hooks->early_critical != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0;
     }
     return cfg;
 }
@@ -46,7 +46,8 @@ int giveBlocks(std::vector<lcb_block>& v, lcb_block** blocks, int64_t* n_blocks)
 extern "C" {
 
 const char* lcb_last_error(void) { return g_error.c_str(); }
-const char* lcb_version(void) { return "sibeliaz_amd 0.1 (gfx950)"; }
+const char* lcb_version(void) { return "sibeliaz_amd 0.4 (gfx950)"; }
+int lcb_abi_version(void) { return LCB_ABI_VERSION; }
 void lcb_free(void* p) { free(p); }
 
 lcb_graph* lcb_graph_load(const char* junction_file, const char* const* fasta_files, int n_fasta, int k, int abundance, int threads)
@@ -225,7 +226,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.overlap = hooks->overlap != 0; cfg.relaxViews = hooks->relax_views != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.deviceCommit = hooks->device_commit != 0; cfg.earlyCritical = hooks->early_critical != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -240,7 +241,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
             stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-            stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
+            stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
             stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
             stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
         }

@@ -17,10 +17,11 @@
 // public C ABI that this file binds with dlsym.
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+typedef enum : int { ncclSuccess = 0 } ncclResult_t;        // (fixed underlying type: RCCL returns other codes than the one named here)
+typedef enum : int { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
 #endif
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -81,6 +82,7 @@ Rccl& rccl()
 
 struct lcb_comm {
     ncclComm_t comm = nullptr;
+    std::atomic<bool> aborted{false};    // set (never cleared) when another rank thread of the set failed: no further collective is issued
     int rank = 0, world = 1, ordinal = 0;
     hipStream_t stream = nullptr;
     void* dSend = nullptr; void* dRecv = nullptr;
@@ -100,6 +102,7 @@ struct lcb_comm {
     // travels GPU to GPU over xGMI.
     void allgather(const void* send, uint64_t n, void* recv)
     {
+        if (aborted.load(std::memory_order_acquire)) throw LcbError("the communicator was aborted (another rank failed)");
         use();
         reserve((size_t)n);
         HIP_CHECK(hipMemcpyAsync(dSend, send, (size_t)n, hipMemcpyHostToDevice, stream));
@@ -151,7 +154,7 @@ void lcb_comm_destroy_impl(lcb_comm* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->dSend) (void)hipFree(c->dSend);
     if (c->dRecv) (void)hipFree(c->dRecv);
-    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->comm && !c->aborted.load()) (void)rccl().CommDestroy(c->comm);      // (an aborted communicator has been freed by ncclCommAbort)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -218,11 +221,14 @@ void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t 
             } catch (std::exception& e) {
                 err[(size_t)r] = e.what();
                 // A rank that fails outside the engine's own error exchange (a HIP error, a view pool that cannot grow ...) would leave
-                // the others blocked in their next all-gather and this call in join(): the communicators are aborted, once.
+                // the others blocked in their next all-gather and this call in join(): the communicators are aborted, once. The handles
+                // stay where they are (other rank threads may be reading them at this moment): a flag keeps those threads from issuing
+                // another collective, the handles are dropped with the set.
                 std::lock_guard<std::mutex> lock(abortMutex);
                 if (!m->broken && n > 1) {
                     m->broken = true;
-                    for (auto c : m->comm) if (c && c->comm) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; }
+                    for (auto c : m->comm) if (c) c->aborted.store(true, std::memory_order_release);
+                    for (auto c : m->comm) if (c && c->comm) (void)rccl().CommAbort(c->comm);
                 }
             }
         });
@@ -234,7 +240,10 @@ void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t 
     blocks.swap(out[0]);
     if (stats) {
         *stats = st[0];
-        for (int r = 1; r < n; r++) { stats->kernel_ms = std::max(stats->kernel_ms, st[(size_t)r].kernel_ms); stats->launches = std::max(stats->launches, st[(size_t)r].launches); }
+        for (int r = 1; r < n; r++) {
+            stats->kernel_ms = std::max(stats->kernel_ms, st[(size_t)r].kernel_ms); stats->kernel_busy_ms = std::max(stats->kernel_busy_ms, st[(size_t)r].kernel_busy_ms);
+            stats->launches = std::max(stats->launches, st[(size_t)r].launches);
+        }
     }
 }
 

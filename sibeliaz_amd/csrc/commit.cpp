@@ -23,18 +23,26 @@ lcb_committer::lcb_committer(const lcb_graph* graph, const lcb_params& prm) : g(
 
 bool lcb_committer::anyUsed(uint64_t lo, uint64_t hi) const
 {
-    for (uint64_t i = lo; i < hi;) {
-        if ((i & 31) == 0 && i + 32 <= hi) { if (used[i >> 5]) return true; i += 32; }
-        else { if ((used[i >> 5] >> (i & 31)) & 1u) return true; i++; }
+    if (hi <= lo) return false;
+    const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+    for (uint64_t w = w0; w <= w1; w++) {
+        uint32_t mask = 0xFFFFFFFFu;
+        if (w == w0) mask &= 0xFFFFFFFFu << (lo & 31);
+        if (w == w1) mask &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+        if (used[w] & mask) return true;
     }
     return false;
 }
 
 bool lcb_committer::allUsed(uint64_t lo, uint64_t hi) const
 {
-    for (uint64_t i = lo; i < hi;) {
-        if ((i & 31) == 0 && i + 32 <= hi) { if (used[i >> 5] != 0xFFFFFFFFu) return false; i += 32; }
-        else { if (!((used[i >> 5] >> (i & 31)) & 1u)) return false; i++; }
+    if (hi <= lo) return true;
+    const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+    for (uint64_t w = w0; w <= w1; w++) {
+        uint32_t mask = 0xFFFFFFFFu;
+        if (w == w0) mask &= 0xFFFFFFFFu << (lo & 31);
+        if (w == w1) mask &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+        if ((used[w] & mask) != mask) return false;
     }
     return true;
 }
@@ -55,7 +63,13 @@ void lcb_committer::finalize(const lcb_instance* inst, uint64_t n)              
         const uint64_t lo = base + (in.front_idx < in.back_idx ? in.front_idx : in.back_idx);
         const uint64_t hi = base + (in.front_idx < in.back_idx ? in.back_idx : in.front_idx);
         if (hi > lo) {
-            for (uint64_t q = lo; q < hi; q++) used[q >> 5] |= 1u << (q & 31);
+            const uint64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;                // word-wise: blocks are thousands of positions long
+            for (uint64_t w = w0; w <= w1; w++) {
+                uint32_t mask = 0xFFFFFFFFu;
+                if (w == w0) mask &= 0xFFFFFFFFu << (lo & 31);
+                if (w == w1) mask &= 0xFFFFFFFFu >> (31 - ((hi - 1) & 31));
+                used[w] |= mask;
+            }
             marks.push_back(lo); marks.push_back(hi);
         }
     }

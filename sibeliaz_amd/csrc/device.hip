@@ -59,9 +59,10 @@ __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKP
     lcb_process_body<MODE, STATS, NW, PROF>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
-__global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
+__global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive,
+                                                         const uint32_t* roundIdx, uint32_t* roundState)
 {
-    lcb_screen_body(T, seeds, nSeeds, out, live, nLive);
+    lcb_screen_body(T, seeds, nSeeds, out, live, nLive, roundIdx, roundState);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -133,9 +134,21 @@ __global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* liv
     }
 }
 
-// The device-side ordered commit of a round's clean prefix (lcb_commit_body, lcb_kernel.h): one workgroup.
-#define LCB_NW_COMMIT 8
+// The device-resident ordered commit of a round's clean prefix (lcb_commit_body, lcb_kernel.h): one workgroup, chained behind every
+// launch of a round; lcb_commit_unmark_kernel clears the previous round's marks out of the delta bitmap.
+#define LCB_NW_COMMIT 16
 __global__ __launch_bounds__(64 * LCB_NW_COMMIT) void lcb_commit_kernel(LcbCommitArgs A) { lcb_commit_body<LCB_NW_COMMIT>(A); }
+// Before the next round the bits of `delta` that the round's commit set are cleared again through the list of its ranges (a bitmap-sized
+// memset per round would cost more than the commit itself: rounds of one phase come by the thousand).
+__global__ __launch_bounds__(256) void lcb_commit_unmark_kernel(uint32_t* delta, const uint2* list, uint32_t n)
+{
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint32_t lo = list[r].x, hi = list[r].y;
+        if (hi <= lo) continue;
+        const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+        for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 256) delta[w] = 0;      // whole words: every set bit of delta lies in a listed range
+    }
+}
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
 __global__ __launch_bounds__(256) void lcb_triad_kernel(float4* a, const float4* b, const float4* c, float s, size_t n)
@@ -211,11 +224,21 @@ struct lcb_device_impl {
     std::vector<SideLane> lanes;                 // asynchronous job batches
     hipStream_t ctlStream = nullptr;             // stop flags of the lanes are written from here
     uint32_t lanePoolPages = 0;                  // private pages per lane (fixed: the live bitmap cannot move while a lane is running)
-    int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0;
-    // device-side commit (commitRound): marks of the current round, per-chromosome phase stamps, the round's results of the live seeds
-    uint32_t* dDelta = nullptr; uint32_t* dChrStamp = nullptr; uint32_t* dCommitBuf = nullptr; size_t commitBufWords = 0;
-    uint32_t* hCommitOut = nullptr; size_t commitOutCap = 0;
-    int64_t commitCalls = 0;
+    int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0, sideNoFit = 0;
+    // device-resident commit of a round (processRound): headers of the round's final results and their state per seed of the round,
+    // marks of the current round (bitmap + the list of its ranges), per-chromosome phase stamps, the commit kernel's state
+    struct RoundCtx {
+        bool active = false;                     // the current process() call is a round whose commit runs behind its launches
+        uint32_t n = 0, phase = 0;
+        LcbSeedOut* dOut = nullptr; uint32_t* dState = nullptr; size_t cap = 0;      // [cap] seeds of a round
+        uint32_t* dDelta = nullptr; uint32_t* dChrStamp = nullptr;
+        uint2* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 20;
+        uint32_t* hIdx = nullptr;                // pinned: launch-local seed index -> index in the round
+        uint32_t* hState = nullptr;              // pinned: LCB_CS_* words, then the count of the delta list as of the last read
+        uint32_t* hCommitted = nullptr; size_t committedCap = 0;                   // pinned
+        bool arenaFresh = true;                  // the next launch of the round is its first: the arena allocators start at 0
+        int64_t rounds = 0, kernels = 0, abandoned = 0;
+    } rc;
     struct lcb_async_call* async = nullptr;      // the call begun with processBegin and not yet ended
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
@@ -225,11 +248,6 @@ struct lcb_device_impl {
     LcbKSeed* hSeeds = nullptr;
     LcbSeedOut* hOut = nullptr;
     LcbSeedCtr* hCtr = nullptr;                  // stats / instrumented variants only
-#if LCB_PATH_SIG
-    int32_t* hSig = nullptr;                     // path vertices of the seeds of a launch (pinned, device-mapped)
-    unsigned long long sigCap = 0;
-    bool wantSig = false;
-#endif
     uint4* hArena = nullptr;
     uint2* hFp = nullptr;                        // footprint arena (pinned)
     unsigned long long fpCap = 0;
@@ -258,7 +276,31 @@ struct lcb_device_impl {
     // recomputation does not repeat the doomed attempt
     std::unordered_map<uint64_t, uint8_t> modeHint;
     std::vector<uint64_t> hintBits = std::vector<uint64_t>(1024, 0);   // 65 536-bit prefilter in front of modeHint (most seeds have no hint)
-    double kernelMs = 0;
+    double kernelMs = 0;                         // sum of the hipEvent-timed durations of the process kernels of every stream ...
+    // ... and the intervals themselves, relative to evBase (recorded when the counters are read and reset): the kernels of the side
+    // lanes run beside the synchronous ones, so the GPU-busy time of a pass is the UNION of the intervals, not their sum
+    hipEvent_t evBase = nullptr;
+    double sideKernelMs = 0;                     // ... the part of kernelMs that ran on the side lanes' streams
+    std::vector<std::pair<float, float>> kernelSpans;
+    void noteSpan(hipEvent_t a, hipEvent_t b)
+    {
+        float ta = 0, tb = 0;
+        if (evBase && hipEventElapsedTime(&ta, evBase, a) == hipSuccess && hipEventElapsedTime(&tb, evBase, b) == hipSuccess) kernelSpans.emplace_back(ta, tb);
+    }
+    void resetSpans()
+    {
+        kernelSpans.clear();
+        if (!evBase) HIP_CHECK(hipEventCreate(&evBase));
+        HIP_CHECK(hipEventRecord(evBase, stream));
+        HIP_CHECK(hipEventSynchronize(evBase));
+    }
+    double busyMs()                              // union of the recorded intervals
+    {
+        std::sort(kernelSpans.begin(), kernelSpans.end());
+        double busy = 0; float hi = -1e30f;
+        for (auto& q : kernelSpans) { if (q.second <= hi) continue; busy += q.second - std::max(q.first, hi); hi = q.second; }
+        return busy;
+    }
     int64_t launches = 0, bigRetries = 0;
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
     int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
@@ -314,21 +356,23 @@ struct lcb_device_impl {
         W.live = screen ? dLive : nullptr; W.nLive = screen ? dCursor + 1 : nullptr;
         W.arenaCursor = (unsigned long long*)(dCursor + 2); W.arenaBase = 0;
         W.fpCursor = (unsigned long long*)(dCursor + 4); W.fpBase = 0;
-#if LCB_PATH_SIG
-        W.sigArena = wantSig ? hSig : nullptr; W.sigCursor = (unsigned long long*)(dCursor + 6); W.sigBase = 0; W.sigCap = sigCap;
-#endif
         const bool prof = (hDbg != nullptr) || seedTrace || forceProf;
         W.ctr = (stats || prof) ? hCtr : nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         W.abort = nullptr;
+        // a launch of a round: final results are also kept on the device, for the commit kernel chained behind the launch
+        const bool round = rc.active && wait;
+        W.roundIdx = round ? rc.hIdx : nullptr; W.roundOut = round ? rc.dOut : nullptr; W.roundState = round ? rc.dState : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
         if (watchdogS > 0 || screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // unfinished seeds can be named (and a header nobody wrote is noticed)
-        HIP_CHECK(hipMemsetAsync(dCursor, 0, 32, stream));
+        // (the launches of a round share the result arenas: the commit kernel reads the results of all of them in place)
+        HIP_CHECK(hipMemsetAsync(dCursor, 0, round && !rc.arenaFresh ? 8 : 32, stream));
+        if (round) rc.arenaFresh = false;
         HIP_CHECK(hipEventRecord(evA, stream));
         if (screen) {
-            hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
+            hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1, W.roundIdx, W.roundState);
             HIP_CHECK(hipGetLastError());
         }
 #define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))
@@ -342,6 +386,17 @@ struct lcb_device_impl {
 #undef LCB_LAUNCH_MODE
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
+        if (round) {
+            // the ordered commit of the round goes on as far as the results reach, behind the kernels that produced them
+            LcbCommitArgs A;
+            A.chrStart = T.chrStart; A.used = dUsed; A.delta = rc.dDelta; A.chrStamp = rc.dChrStamp;
+            A.roundState = rc.dState; A.roundOut = rc.dOut; A.arena = hArena; A.fpArena = hFp;
+            A.n = rc.n; A.phase = rc.phase; A.nPos = T.nPos;
+            A.state = rc.hState; A.committed = rc.hCommitted; A.deltaList = rc.dDeltaList; A.deltaCount = rc.dDeltaCount; A.deltaCap = rc.deltaCap;
+            hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, stream, A);
+            HIP_CHECK(hipGetLastError());
+            rc.kernels++;
+        }
         HIP_CHECK(hipEventRecord(evB, stream));
         if (screen) {      // the host only looks at the seeds that survived the screening
             HIP_CHECK(hipMemcpyAsync(hLive + batchCap, dCursor + 1, 4, hipMemcpyDeviceToHost, stream));
@@ -392,6 +447,7 @@ struct lcb_device_impl {
         HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
         kernelMs += ms;
         launches++;
+        noteSpan(evA, evB);
         modeSeeds[w.mode] += m;
         if (traceFile) {
             fprintf(traceFile, "%lld\t%u\t%u\t%s\t%.4f\n", (long long)launches, m, grid, modeName(w.mode), ms);
@@ -438,11 +494,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         if (!o.wide_threshold) o.wide_threshold = 2 * o.wide_slots;
         if (!o.screen_min) o.screen_min = 2048;
         if (o.path_cap & (o.path_cap - 1)) throw LcbError("lcb_device_opts.path_cap must be a power of two");
-        // lcb_device_opts.stream_priority: needed results ahead of speculation (numerically lower = higher priority)
+        // needed results ahead of speculation: the stream of the synchronous launches gets the highest HIP stream priority, the side
+        // lanes' streams the lowest (numerically lower = higher priority; -4 % per pass together with the early critical launch,
+        // profiles/r04/ab_first.txt)
         int prioLow = 0, prioHigh = 0;
-        if (o.stream_priority) HIP_CHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-        if (o.stream_priority) HIP_CHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prioHigh));
-        else HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+        HIP_CHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prioHigh));
         HIP_CHECK(hipEventCreate(&d->ev0));
         HIP_CHECK(hipEventCreate(&d->ev1));
         HIP_CHECK(hipEventCreate(&d->ev2));
@@ -512,10 +569,6 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hCtr, (size_t)d->batchCap * sizeof(LcbSeedCtr), hipHostMallocDefault));
         d->allocArena(o.arena);
-#if LCB_PATH_SIG
-        d->sigCap = 1ull << 22;
-        HIP_CHECK(hipHostMalloc((void**)&d->hSig, (size_t)d->sigCap * sizeof(int32_t), hipHostMallocDefault));
-#endif
         d->swapBufs();
         HIP_CHECK(hipHostMalloc((void**)&d->hSeeds, (size_t)d->batchCap * sizeof(LcbKSeed), hipHostMallocDefault));
         HIP_CHECK(hipHostMalloc((void**)&d->hOut, (size_t)d->batchCap * sizeof(LcbSeedOut), hipHostMallocDefault));
@@ -539,13 +592,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->lanes.resize(nLanes);
         for (uint32_t l = 0; l < nLanes; l++) {
             SideLane& L = d->lanes[l];
-            if (o.stream_priority) {
-                HIP_CHECK(hipStreamCreateWithPriority(&L.sw, hipStreamNonBlocking, prioLow));
-                HIP_CHECK(hipStreamCreateWithPriority(&L.sb, hipStreamNonBlocking, prioLow));
-            } else {
-                HIP_CHECK(hipStreamCreateWithFlags(&L.sw, hipStreamNonBlocking));
-                HIP_CHECK(hipStreamCreateWithFlags(&L.sb, hipStreamNonBlocking));
-            }
+            HIP_CHECK(hipStreamCreateWithPriority(&L.sw, hipStreamNonBlocking, prioLow));
+            HIP_CHECK(hipStreamCreateWithPriority(&L.sb, hipStreamNonBlocking, prioLow));
             for (hipEvent_t* e : {&L.w0, &L.w1, &L.b0, &L.b1}) HIP_CHECK(hipEventCreate(e));
             L.cap = 2048; L.arenaCap = 1ull << 20;
             // the host polls these while the kernels run: fine-grained (coherent) pinned memory
@@ -583,7 +631,7 @@ void lcb_device_destroy_impl(lcb_device* h)
         lcb_device_drop_async(d);
         lcb_device_drain_lanes(d);
         if (getenv("LCB_VERBOSE")) {
-            fprintf(stderr, "lcb device %d: side lanes %zu: %lld batches, %lld jobs (%lld plans found no free lane)\n", d->ordinal, d->lanes.size(), (long long)d->sideBatches, (long long)d->sideJobs, (long long)d->sideNoLane);
+            fprintf(stderr, "lcb device %d: side lanes %zu: %lld batches, %lld jobs (%lld plans found no free lane, %lld did not fit a lane)\n", d->ordinal, d->lanes.size(), (long long)d->sideBatches, (long long)d->sideJobs, (long long)d->sideNoLane, (long long)d->sideNoFit);
             fprintf(stderr, "lcb device %d: seeds per variant compact %lld wide %lld big %lld huge %lld | screened %lld (dead %lld)\n", d->ordinal, (long long)d->modeSeeds[0],
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->views.poolPages);
@@ -604,8 +652,8 @@ void lcb_device_destroy_impl(lcb_device* h)
             for (void* q : {(void*)L.hSeeds, (void*)L.hOut, (void*)L.hArena, (void*)L.hFp, (void*)L.hList, (void*)L.hCtl}) if (q) (void)hipHostFree(q);
             for (void* q : {(void*)L.dCtl, (void*)L.views.tab, (void*)L.views.dEntries, (void*)L.views.dVersions, (void*)L.views.dPieces, (void*)L.wide.base, (void*)L.big.base}) if (q) (void)hipFree(q);
         }
-        for (void* q : {(void*)d->dDelta, (void*)d->dChrStamp, (void*)d->dCommitBuf}) if (q) (void)hipFree(q);
-        if (d->hCommitOut) (void)hipHostFree(d->hCommitOut);
+        for (void* q : {(void*)d->rc.dOut, (void*)d->rc.dState, (void*)d->rc.dDelta, (void*)d->rc.dChrStamp, (void*)d->rc.dDeltaList, (void*)d->rc.dDeltaCount}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d->rc.hIdx, (void*)d->rc.hState, (void*)d->rc.hCommitted}) if (q) (void)hipHostFree(q);
         if (d->ctlStream) (void)hipStreamDestroy(d->ctlStream);
         if (d->views.tab) (void)hipFree(d->views.tab);
         if (d->views.dEntries) (void)hipFree(d->views.dEntries);
@@ -621,14 +669,12 @@ void lcb_device_destroy_impl(lcb_device* h)
         if (d->hSeeds) (void)hipHostFree(d->hSeeds);
         if (d->hOut) (void)hipHostFree(d->hOut);
         if (d->hCtr) (void)hipHostFree(d->hCtr);
-#if LCB_PATH_SIG
-        if (d->hSig) (void)hipHostFree(d->hSig);
-#endif
         if (d->hArena) (void)hipHostFree(d->hArena);
         if (d->hFp) (void)hipHostFree(d->hFp);
         if (d->hRanges) (void)hipHostFree(d->hRanges);
         if (d->hDbg) (void)hipHostFree(d->hDbg);
         if (d->traceFile) fclose(d->traceFile);
+        if (d->evBase) (void)hipEventDestroy(d->evBase);
         if (d->ev0) (void)hipEventDestroy(d->ev0);
         if (d->ev1) (void)hipEventDestroy(d->ev1);
         if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -783,11 +829,16 @@ int lcb_device_concurrency_impl(lcb_device* h) { return (int)h->impl->ws[0].nSlo
 
 void lcb_device_set_stats_impl(lcb_device* h, bool on) { h->impl->stats = on; }
 
-void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches)
+void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches, double* busyMs, double* sideMs)
 {
-    if (ms) *ms = h->impl->kernelMs;
-    if (launches) *launches = h->impl->launches;
-    h->impl->kernelMs = 0; h->impl->launches = 0;
+    lcb_device_impl* d = h->impl;
+    d->use();
+    if (ms) *ms = d->kernelMs;
+    if (launches) *launches = d->launches;
+    if (busyMs) *busyMs = d->busyMs();
+    if (sideMs) *sideMs = d->sideKernelMs;
+    d->kernelMs = 0; d->sideKernelMs = 0; d->launches = 0;
+    d->resetSpans();
 }
 
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
@@ -814,7 +865,6 @@ struct ProcAcc {
     int64_t arenaOvf = 0;                               // seeds of the current variant's launches that found the result arena full
     std::vector<uint8_t> start;                         // first variant of every seed of the call
     bool allBig = false;                                // every seed of the call starts in the big variant (accInit)
-    std::vector<std::vector<int32_t>>* sig = nullptr;   // LCB_PATH_SIG: where the path vertices of every seed go
     int64_t neededBig = 0;                              // seeds that finished in the big / huge variant and could not have run in a smaller one
 };
 
@@ -869,6 +919,7 @@ void fillSeeds(lcb_device_impl* d, const ProcAcc& A, const std::vector<int64_t>&
         const int64_t s = list[at + i];
         d->hSeeds[i].vid = A.seeds[s].vid; d->hSeeds[i].ch = A.seeds[s].ch; d->hSeeds[i].view = A.view ? A.view[s] : 0u; d->hSeeds[i].pad = 0;
     }
+    if (d->rc.active) for (uint32_t i = 0; i < m; i++) d->rc.hIdx[i] = (uint32_t)list[at + i];
 }
 
 // Takes the results of one finished launch out of the host buffers; seeds that overflowed go to the next variant's list.
@@ -893,18 +944,6 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
                 for (uint32_t e = 0; e < o.nInst; e++) A.flat[f0 + e] = lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w};
             }
             if (A.bestScore) A.bestScore[s] = o.bestScore;
-#if LCB_PATH_SIG
-            if (A.sig) {
-                std::vector<int32_t>& sg = (*A.sig)[(size_t)s];
-                sg.clear();
-                if (o.nSig == 0xFFFFFFFFu) sg.push_back(INT32_MIN);          // the list did not fit: every predicted mark counts as read
-                else {
-                    for (uint32_t e = 0; e < o.nSig; e++) { const int32_t v = d->hSig[o.sigOff + e]; sg.push_back(v < 0 ? -v : v); }
-                    std::sort(sg.begin(), sg.end());
-                    sg.erase(std::unique(sg.begin(), sg.end()), sg.end());
-                }
-            }
-#endif
             if (A.wantFp) {
                 A.fpAt[(size_t)s] = A.fpFlat.size(); A.fpCnt[(size_t)s] = o.nFp;
                 const uint2* src = d->hFp + o.fpOff;
@@ -977,6 +1016,9 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
         }
+        // (a round whose launches fill the shared result arenas: the arenas are emptied between launches again, so the commit kernel
+        // can no longer find earlier results in place - what it has committed so far stands, the host commits the rest)
+        if (d->rc.active && (A.arenaOvf || hugeOverflow)) { d->rc.active = false; d->rc.abandoned++; }
         if (A.growCompactPath) {
             // The compact path set starts small on purpose (the sets of all slots together stay cache-resident: 1280 x 128 KB)
             // and grows only for workloads whose paths need it (k = 25, long blocks of few genomes)
@@ -991,7 +1033,7 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->allocArena(d->arenaCap * 4);
             d->arenaGrown++;
         } else
-        if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
+        if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) { if (d->rc.active) { d->rc.active = false; d->rc.abandoned++; } d->allocArena(d->arenaCap * 4); }   // not even one batch fitted
         A.arenaOvf = 0;
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
@@ -1030,8 +1072,7 @@ void accLayout(ProcAcc& A, std::vector<uint64_t>& offsets, std::vector<lcb_insta
 
 void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, std::vector<uint64_t>& offsets,
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
-                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr,
-                             std::vector<std::vector<int32_t>>* pathSink)
+                             std::vector<uint64_t>* fpOffsets, std::vector<lcb_fp>* fpOut, const uint32_t* view, std::vector<lcb_counters>* perSeedCtr)
 {
     lcb_device_impl* d = h->impl;
     d->use();
@@ -1039,29 +1080,18 @@ void lcb_device_process_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, st
     d->wantFp = fpOffsets != nullptr && fpOut != nullptr;
     ProcAcc A;
     accInit(d, A, seeds, n, view, bestScore, ctr, perSeedCtr, d->wantFp);
-#if LCB_PATH_SIG
-    if (pathSink) { pathSink->assign((size_t)n, std::vector<int32_t>()); A.sig = pathSink; d->wantSig = true; }
-#else
-    if (pathSink) throw LcbError("this build does not report path vertices (-DLCB_PATH_SIG=1)");
-#endif
     try { runToCompletion(d, A); } catch (...) {
-#if LCB_PATH_SIG
-        d->wantSig = false;
-#endif
         d->wantFp = false; throw; }
-#if LCB_PATH_SIG
-    d->wantSig = false;
-#endif
     accLayout(A, offsets, inst, fpOffsets, fpOut);
     d->wantFp = false;
 }
 
 // ---- a call whose first launch runs while the host is still busy with something else --------------------------------------
-// begin: the seeds that start in the compact variant are enqueued (second set of host buffers, nothing is waited for) against
-// the live `used` state of this moment — later marks and launches are ordered behind it on the stream; end: waits for that
-// launch, takes its results, then runs whatever is left (seeds with a hint for another variant, overflows) like a normal call.
-// anySize (the engine's early critical launch: the results a stop cannot go on without are computed while the host plans the
-// rest): calls of few seeds too; the first launch is then the one a synchronous call would start with (wide, or big).
+// (the engine's early critical launch: the results a stop cannot go on without are computed while the host plans the rest of the
+// stop's jobs). begin: the first launch a synchronous call would make (compact, wide or big by the size of the call and what is
+// known about its seeds) is enqueued on the second set of host buffers, nothing is waited for, against the live `used` state of
+// this moment — later marks and launches are ordered behind it on the stream; end: waits for that launch, takes its results, then
+// runs whatever is left (seeds with a hint for another variant, overflows) like a normal call.
 struct lcb_async_call { ProcAcc A; std::vector<int64_t> list; uint32_t m = 0; int mode = 0; bool screen = false, launched = false; };
 
 static void lcb_device_drop_async(lcb_device_impl* d)
@@ -1071,17 +1101,16 @@ static void lcb_device_drop_async(lcb_device_impl* d)
     d->async = nullptr;
 }
 
-bool lcb_device_process_begin_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, bool anySize)
+bool lcb_device_process_begin_impl(lcb_device* h, const lcb_seed* seeds, int64_t n)
 {
     lcb_device_impl* d = h->impl;
     if (d->stats || d->async || n <= 0 || n > (int64_t)d->batchCap) return false;
-    if (!anySize && (n <= (int64_t)d->o.wide_threshold || d->o.start_mode > 1)) return false;
     if (d->hDbg || d->seedTrace || d->forceProf) return false;     // (the instrumented variants share one profile buffer)
     d->use();
     std::unique_ptr<lcb_async_call> c(new lcb_async_call());
     c->A.ownSeeds.assign(seeds, seeds + n);
     accInit(d, c->A, c->A.ownSeeds.data(), n, nullptr, nullptr, nullptr, nullptr, true);
-    if (anySize) for (int m = 3; m >= 0; m--) if (!c->A.todo[m].empty()) c->mode = m;       // the variant a synchronous call would launch first
+    for (int m = 3; m >= 0; m--) if (!c->A.todo[m].empty()) c->mode = m;       // the variant a synchronous call would launch first
     c->list.swap(c->A.todo[c->mode]);
     c->m = (uint32_t)c->list.size();
     if (c->m) {
@@ -1124,59 +1153,66 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
     d->wantFp = false;
 }
 
-// ---- device-side ordered commit (LcbProcessor::commitRound) ----------------------------------------------------------------
-// The round's results of the live seeds are handed back to the device in one buffer (they were gathered from several launches and
-// kernel variants), the commit kernel walks them against the live bitmap and reports what it committed and where it stopped.
-bool lcb_device_commit_round_impl(lcb_device* h, const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
-                                  const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
-                                  std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
+// ---- device-resident ordered commit of a round (LcbProcessor::processRound) ---------------------------------------------------
+// process() of the n seeds of a round against the live state, with lcb_commit_kernel chained behind every launch of the call: the
+// kernels keep the header of every final result on the device under the seed's index in the round, instances and footprints stay in
+// the launch arenas (not reset between the launches of a round), and the commit kernel goes on - phase by phase, in seed order - as
+// far as final results reach. The host reads its state words and the committed list after the last launch.
+bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst,
+                                   std::vector<uint64_t>& fpOffsets, std::vector<lcb_fp>& fpOut, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
 {
     lcb_device_impl* d = h->impl;
-    if (d->stats || live.empty() || phase <= 0) return false;
+    if (d->stats || n <= 0 || phase <= 0 || n > (int64_t)(1u << 30) || d->hDbg || d->seedTrace || d->forceProf) return false;
     d->use();
-    const size_t nLive = live.size();
+    auto& R = d->rc;
     static_assert(sizeof(lcb_instance) == 16 && sizeof(lcb_fp) == 8, "layouts the commit kernel reads");
-    // one device buffer: seedIdx | off | fpOff | committed | result(4) | inst (16-B aligned) | fp
-    auto al4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
-    const size_t wSeed = 0, wOff = al4(wSeed + nLive), wFpOff = al4(wOff + nLive + 1), wCom = al4(wFpOff + nLive + 1), wRes = al4(wCom + nLive),
-                 wInst = al4(wRes + 4), wFp = al4(wInst + 4 * inst.size()), wEnd = al4(wFp + 2 * fp.size());
-    if (wEnd > d->commitBufWords) {
-        if (d->dCommitBuf) HIP_CHECK(hipFree(d->dCommitBuf));
-        d->commitBufWords = wEnd + wEnd / 2;
-        HIP_CHECK(hipMalloc((void**)&d->dCommitBuf, d->commitBufWords * 4));
+    if ((size_t)n > R.cap) {
+        for (void* q : {(void*)R.dOut, (void*)R.dState}) if (q) HIP_CHECK(hipFree(q));
+        R.cap = std::max<size_t>((size_t)n, d->batchCap);
+        HIP_CHECK(hipMalloc((void**)&R.dOut, R.cap * sizeof(LcbSeedOut)));
+        HIP_CHECK(hipMalloc((void**)&R.dState, R.cap * 4));
     }
-    if (!d->dDelta) {
-        HIP_CHECK(hipMalloc((void**)&d->dDelta, d->usedWords * 4));
-        HIP_CHECK(hipMalloc((void**)&d->dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
+    if ((size_t)n > R.committedCap) {
+        if (R.hCommitted) HIP_CHECK(hipHostFree(R.hCommitted));
+        R.committedCap = std::max<size_t>((size_t)n, d->batchCap);
+        HIP_CHECK(hipHostMalloc((void**)&R.hCommitted, R.committedCap * 4, hipHostMallocDefault));
     }
-    if (nLive + 4 > d->commitOutCap) {
-        if (d->hCommitOut) HIP_CHECK(hipHostFree(d->hCommitOut));
-        d->commitOutCap = (nLive + 4) * 2;
-        HIP_CHECK(hipHostMalloc((void**)&d->hCommitOut, d->commitOutCap * 4, hipHostMallocDefault));
+    if (!R.dDelta) {
+        HIP_CHECK(hipMalloc((void**)&R.dDelta, d->usedWords * 4));
+        HIP_CHECK(hipMemsetAsync(R.dDelta, 0, d->usedWords * 4, d->stream));
+        HIP_CHECK(hipMalloc((void**)&R.dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
+        HIP_CHECK(hipMalloc((void**)&R.dDeltaList, (size_t)R.deltaCap * sizeof(uint2)));
+        HIP_CHECK(hipMalloc((void**)&R.dDeltaCount, 4));
+        HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
+        HIP_CHECK(hipHostMalloc((void**)&R.hIdx, (size_t)d->batchCap * 4, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&R.hState, 64, hipHostMallocDefault));
+        memset(R.hState, 0, 64);
     }
-    HIP_CHECK(hipMemsetAsync(d->dDelta, 0, d->usedWords * 4, d->stream));
-    HIP_CHECK(hipMemsetAsync(d->dChrStamp, 0, ((size_t)d->g->nChr() + 1) * 4, d->stream));
-    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wSeed, live.data(), nLive * 4, hipMemcpyHostToDevice, d->stream));
-    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wOff, off.data(), (nLive + 1) * 4, hipMemcpyHostToDevice, d->stream));
-    HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wFpOff, fpOff.data(), (nLive + 1) * 4, hipMemcpyHostToDevice, d->stream));
-    if (!inst.empty()) HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wInst, inst.data(), inst.size() * 16, hipMemcpyHostToDevice, d->stream));
-    if (!fp.empty()) HIP_CHECK(hipMemcpyAsync(d->dCommitBuf + wFp, fp.data(), fp.size() * 8, hipMemcpyHostToDevice, d->stream));
-    LcbCommitArgs A;
-    A.chrStart = d->T.chrStart; A.used = d->dUsed; A.delta = d->dDelta; A.chrStamp = d->dChrStamp;
-    A.seedIdx = d->dCommitBuf + wSeed; A.off = d->dCommitBuf + wOff; A.inst = (const uint4*)(d->dCommitBuf + wInst);
-    A.fpOff = d->dCommitBuf + wFpOff; A.fp = (const uint2*)(d->dCommitBuf + wFp);
-    A.nLive = (uint32_t)nLive; A.phase = (uint32_t)phase; A.nPos = d->T.nPos;
-    A.committed = d->dCommitBuf + wCom; A.result = d->dCommitBuf + wRes;
-    hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, d->stream, A);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(d->hCommitOut, d->dCommitBuf + wRes, 16, hipMemcpyDeviceToHost, d->stream));
+    // the marks of the previous round leave the delta bitmap through the list of its ranges (hState[8]: their number)
+    const uint32_t nPrev = R.hState[8];
+    if (nPrev > R.deltaCap) HIP_CHECK(hipMemsetAsync(R.dDelta, 0, d->usedWords * 4, d->stream));
+    else if (nPrev) { hipLaunchKernelGGL(lcb_commit_unmark_kernel, dim3(std::min<uint32_t>(nPrev, 1024u)), dim3(256), 0, d->stream, R.dDelta, R.dDeltaList, nPrev); HIP_CHECK(hipGetLastError()); }
+    if (nPrev) HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
+    HIP_CHECK(hipMemsetAsync(R.dState, 0, (size_t)n * 4, d->stream));
+    HIP_CHECK(hipMemsetAsync(R.dChrStamp, 0, ((size_t)d->g->nChr() + 1) * 4, d->stream));
+    memset(R.hState, 0, 64);                     // (the stream is idle: every earlier call has been waited for)
+    R.n = (uint32_t)n; R.phase = (uint32_t)phase; R.arenaFresh = true; R.active = true;
+    inst.clear();
+    d->wantFp = true;
+    ProcAcc A;
+    accInit(d, A, seeds, n, nullptr, nullptr, nullptr, nullptr, true);
+    try { runToCompletion(d, A); } catch (...) { d->wantFp = false; R.active = false; throw; }
+    accLayout(A, offsets, inst, &fpOffsets, &fpOut);
+    d->wantFp = false;
+    R.active = false;
+    HIP_CHECK(hipMemcpyAsync(R.hState + 8, R.dDeltaCount, 4, hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
-    const uint32_t nCom = d->hCommitOut[0];
-    stopAt = d->hCommitOut[1]; stopKind = (int)d->hCommitOut[2];
-    if (nCom > nLive || stopAt > nLive || stopKind < 0 || stopKind > 2) throw LcbError("device commit: inconsistent result");
-    committed.resize(nCom);
-    if (nCom) HIP_CHECK(hipMemcpy(committed.data(), d->dCommitBuf + wCom, (size_t)nCom * 4, hipMemcpyDeviceToHost));
-    d->commitCalls++;
+    const uint32_t next = R.hState[LCB_CS_NEXT], nCom = R.hState[LCB_CS_NCOMMITTED];
+    stopKind = (int)R.hState[LCB_CS_STOPKIND]; stopAt = R.hState[LCB_CS_STOPAT];
+    if (nCom > (uint32_t)n || next > (uint32_t)n || stopKind < 0 || stopKind > 2 || (stopKind && stopAt >= (uint32_t)n)) throw LcbError("device commit: inconsistent state");
+    committed.assign(R.hCommitted, R.hCommitted + nCom);
+    if (stopKind == 0 && next < (uint32_t)n) { stopKind = 3; stopAt = next; }     // the commit did not get further (the round's arenas had to be reset): the host goes on from this phase
+    R.rounds++;
     return true;
 }
 
@@ -1191,8 +1227,8 @@ bool lcb_device_commit_round_impl(lcb_device* h, const std::vector<int32_t>& liv
 static void lcb_lane_retire(lcb_device_impl* d, SideLane& L)
 {
     float ms = 0;
-    if (L.ranW) { HIP_CHECK(hipEventSynchronize(L.w1)); HIP_CHECK(hipEventElapsedTime(&ms, L.w0, L.w1)); d->kernelMs += ms; d->launches++; }
-    if (L.ranB) { HIP_CHECK(hipEventSynchronize(L.b1)); HIP_CHECK(hipEventElapsedTime(&ms, L.b0, L.b1)); d->kernelMs += ms; d->launches++; }
+    if (L.ranW) { HIP_CHECK(hipEventSynchronize(L.w1)); HIP_CHECK(hipEventElapsedTime(&ms, L.w0, L.w1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.w0, L.w1); }
+    if (L.ranB) { HIP_CHECK(hipEventSynchronize(L.b1)); HIP_CHECK(hipEventElapsedTime(&ms, L.b0, L.b1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.b0, L.b1); }
     L.busy = L.released = L.ranW = L.ranB = false;
 }
 
@@ -1231,9 +1267,10 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
             HIP_CHECK(hipStreamSynchronize(d->lanes[l].sw)); HIP_CHECK(hipStreamSynchronize(d->lanes[l].sb));
             lcb_lane_retire(d, d->lanes[l]); lane = (int)l;
         }
-    if (lane < 0 || n > (int64_t)d->lanes[(size_t)lane].cap) { d->sideNoLane++; return -1; }
+    if (lane < 0) { d->sideNoLane++; return -1; }
+    if (n > (int64_t)d->lanes[(size_t)lane].cap) { d->sideNoFit++; return -2; }      // (-2: no lane can take this batch, whatever gives way)
     SideLane& L = d->lanes[(size_t)lane];
-    if (!lcb_build_views_into(d, L.views, L.sw, false, nViews, marks, nMarks)) { d->sideNoLane++; return -1; }
+    if (!lcb_build_views_into(d, L.views, L.sw, false, nViews, marks, nMarks)) { d->sideNoFit++; return -2; }
     // jobs by variant: big for the seeds known to need it, wide for the rest (ticket order = plan order within a kernel)
     uint32_t nW = 0, nB = 0;
     uint32_t* listW = L.hList; uint32_t* listB = L.hList + L.cap;
@@ -1262,10 +1299,7 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
         W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap; W.instCap = w.instCap; W.voteCap = w.voteCap;
         W.cursor = L.dCtl + ticketWord; W.cursorBase = 0; W.live = list; W.nLive = L.dCtl + countWord;
         W.arenaCursor = (unsigned long long*)(L.dCtl + 2); W.arenaBase = 0; W.fpCursor = (unsigned long long*)(L.dCtl + 4); W.fpBase = 0;
-#if LCB_PATH_SIG
-        W.sigArena = nullptr; W.sigCursor = nullptr; W.sigBase = 0; W.sigCap = 0;
-#endif
-        W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8;
+        W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8; W.roundIdx = nullptr; W.roundOut = nullptr; W.roundState = nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         HIP_CHECK(hipEventRecord(e0, q));
         if (w.mode == 2) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
@@ -1336,13 +1370,12 @@ struct DeviceProcessor : LcbProcessor {
     void process(const lcb_seed* seeds, const uint32_t* view, int64_t n, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst,
                  std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
-        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view, ctrSink, view ? pathSink : nullptr);
-        if (pathSink && !view) pathSink->assign((size_t)n, std::vector<int32_t>());      // a launch against the live state has no predicted marks
+        lcb_device_process_impl(dev, seeds, n, off, inst, nullptr, nullptr, &fpOff, &fp, view, ctrSink);
     }
     int maxViews() const override { return lcb_device_max_views_impl(dev); }
     int concurrency() const override { return lcb_device_concurrency_impl(dev); }
     void buildViews(int nViews, const LcbViewMark* marks, int64_t nMarks) override { lcb_device_build_views_impl(dev, nViews, marks, nMarks); }
-    bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize) override { return lcb_device_process_begin_impl(dev, seeds, n, anySize); }
+    bool processBegin(const lcb_seed* seeds, int64_t n) override { return lcb_device_process_begin_impl(dev, seeds, n); }
     void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp) override
     {
         lcb_device_process_end_impl(dev, off, inst, fpOff, fp);
@@ -1356,10 +1389,10 @@ struct DeviceProcessor : LcbProcessor {
     }
     int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return lcb_device_side_poll_impl(dev, lane, k, wait, inst, fp); }
     void sideRelease(int lane) override { lcb_device_side_release_impl(dev, lane); }
-    bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst, const std::vector<uint32_t>& fpOff,
-                     const std::vector<lcb_fp>& fp, int64_t phase, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
+    bool processRound(const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
+                      std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
     {
-        return lcb_device_commit_round_impl(dev, live, off, inst, fpOff, fp, phase, committed, stopAt, stopKind);
+        return lcb_device_process_round_impl(dev, seeds, n, phase, off, inst, fpOff, fp, committed, stopAt, stopKind);
     }
 };
 
@@ -1374,16 +1407,23 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
     DeviceProcessor proc(dev);
     LcbEngineStats es;
     lcb_engine_run(g, p, seeds, nSeeds, proc, cfg, blocks, &es);
+    lcb_device_drain_lanes(dev->impl);      // (the last batches are released but not retired: their kernel time belongs to this pass)
+    if (getenv("LCB_VERBOSE"))
+        fprintf(stderr, "lcb engine: %.0f ms = processor %.0f + dry runs %.0f + rest %.0f (round setup %.0f, validation %.0f, commit %.0f, marks to the device %.0f, mirror of device commits %.0f) | "
+                        "device-resident commit: %lld rounds, %lld kernels, %lld given up\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs, es.sectionMs[LCB_SEC_SETUP],
+                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_MIRROR], (long long)dev->impl->rc.rounds, (long long)dev->impl->rc.kernels,
+                (long long)dev->impl->rc.abandoned);
     if (stats) {
-        double ms = 0; int64_t l = 0;
-        lcb_device_kernel_time_impl(dev, &ms, &l);
+        double ms = 0, busy = 0, side = 0; int64_t l = 0;
+        lcb_device_kernel_time_impl(dev, &ms, &l, &busy, &side);
+        stats->kernel_busy_ms = busy; stats->kernel_side_ms = side;
         stats->seeds = nSeeds; stats->blocks_found = es.blocksFound; stats->failures = es.failures;
         stats->launches = l; stats->kernel_ms = ms; stats->big_retries = lcb_device_big_retries_impl(dev) - retries0;
         stats->wall_ms = es.wallMs;
         stats->rounds = es.rounds; stats->recompute_launches = es.recomputeLaunches; stats->recomputed_seeds = es.recomputedSeeds;
         stats->conflict_launches = es.conflictLaunches; stats->conflict_seeds = es.conflictSeeds; stats->exchanges = es.exchanges;
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
-        stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events; stats->early_rounds = es.earlyRounds;
+        stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
         stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
     }

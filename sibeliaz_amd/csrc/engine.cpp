@@ -92,7 +92,6 @@ struct Results {                       // per-seed results of one process() call
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
     std::vector<lcb_counters> ctr;     // countEvents only
-    std::vector<std::vector<int32_t>> pathV;   // relaxViews only
 };
 
 inline void addCounters(lcb_counters& a, const lcb_counters& b)
@@ -110,7 +109,6 @@ struct Cand {
     std::vector<lcb_instance> inst;
     std::vector<lcb_fp> fp;
     lcb_counters ctr{};
-    std::vector<int32_t> pathV;        // relaxViews: sorted |id| of the path's vertices
 };
 
 void pack(const Results& r, int64_t n, std::vector<unsigned char>& buf)
@@ -159,31 +157,25 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     if (world > 1 && !cfg.allgather) throw LcbError("world > 1 needs an all-gather callback");
     if (rank < 0 || rank >= world) throw LcbError("bad rank");
     if (cfg.countEvents && world > 1) throw LcbError("event counting runs on one rank");
-    if (cfg.relaxViews && (world > 1 || (cfg.exchangeAlways && cfg.allgather))) throw LcbError("relaxViews: the path vertices are not part of the rank exchange yet (one rank only)");
 
     lcb_committer com(g, *p);
     proc.reset();
     LcbEngineStats st;
     st.seeds = nSeeds;
     std::vector<uint64_t> pending;                 // marks not yet applied to the processor's `used` state
+    bool inPlan = false;
     auto flush = [&]() {
         if (pending.empty()) return;
+        const auto tf = std::chrono::steady_clock::now();
         proc.mark(pending.data(), (int64_t)(pending.size() / 2));
         pending.clear();
+        if (!inPlan) st.sectionMs[LCB_SEC_FLUSH] += msSince(tf);       // (inside a dry run it is part of the dry run's time)
     };
     std::vector<RangeSet> epochMarks;              // epochMarks[e]: ranges marked after launch e of this round and before launch e+1
-    // Overlap of host and device (one rank): while the host validates and commits round r, the processor already runs the
-    // speculative launch of round r+1 — begun against the state at the START of round r (its W), so everything round r commits is
-    // "marked since" for its results (sinceBegin becomes epoch 0 of round r+1). Only in sparse stretches (the previous round
-    // re-launched < 5 % of its seeds): where commits are dense the results of the early launch would mostly be void.
-    bool begun = false;                            // a processBegin for the next round is in flight
-    int64_t begunN = 0;
-    RangeSet sinceBegin;
     double lastInvalid = 1.0;
     auto takeMarks = [&](bool alreadyInProcessor = false) {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
             epochMarks.back().add(com.marks[i], com.marks[i + 1]);
-            if (begun) sinceBegin.add(com.marks[i], com.marks[i + 1]);
             if (!alreadyInProcessor) { pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]); }
         }
         com.marks.clear();
@@ -207,15 +199,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<int32_t> liveIdx;
     auto liveFrom = [&](int64_t i) { return (size_t)(std::lower_bound(liveIdx.begin(), liveIdx.end(), (int32_t)i) - liveIdx.begin()); };
 
-    // ---- device-side commit (commitRound of the processor), one rank only
-    const bool useDevCommit = world == 1 && cfg.deviceCommit && !cfg.countEvents && !cfg.overlap && !(cfg.exchangeAlways && cfg.allgather);
-    std::vector<uint32_t> dcOff, dcFpOff, dcCommitted;
-    std::vector<lcb_instance> dcInst;
-    std::vector<lcb_fp> dcFp;
+    // ---- device-resident commit of a round's clean prefix (processRound of the processor), one rank only
+    const bool useDevCommit = world == 1 && !cfg.hostCommit && !cfg.countEvents && !(cfg.exchangeAlways && cfg.allgather);
+    std::vector<uint32_t> dcCommitted;
     // ---- asynchronous job batches (side lanes of the processor), one rank only
-    const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !cfg.relaxViews && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
+    const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
     // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs
-    const bool useEarly = useSide && cfg.earlyCritical && !cfg.overlap;
+    const bool useEarly = useSide;
     std::vector<lcb_seed> earlySeeds;
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
     std::vector<SideJob> sideJobs;                  // of this round
@@ -253,10 +243,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         if (world == 1 && !(cfg.exchangeAlways && cfg.allgather)) {
             const auto tp = std::chrono::steady_clock::now();
             proc.ctrSink = cfg.countEvents ? &out.ctr : nullptr;
-            proc.pathSink = cfg.relaxViews ? &out.pathV : nullptr;
             proc.process(sd, view, n, out.off, out.inst, out.fpOff, out.fp);
-            proc.ctrSink = nullptr; proc.pathSink = nullptr;
-            if (cfg.relaxViews && (int64_t)out.pathV.size() != n) throw LcbError("relaxViews needs a processor that reports the path vertices");
+            proc.ctrSink = nullptr;
             if (cfg.countEvents && (int64_t)out.ctr.size() != n) throw LcbError("the processor does not count events (stats mode off?)");
             st.processMs += msSince(tp);
             return;
@@ -316,32 +304,23 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     };
 
     for (int64_t pos = 0; pos < nSeeds;) {
-        const bool early = begun;                   // this round's launch was begun while the previous round was committed
-        const int64_t nRound = early ? begunN : std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
+        const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
         st.rounds++;
-        if (early) {
-            // its results were computed against the state at the start of the previous round: what that round marked is epoch 0
+        flush();                                    // processor state == live state at the start of phase `pos`
+        epochMarks.assign(1, RangeSet());
+        // ---- speculative launch of the whole round (dealt to the ranks; on one rank with the ordered commit of the round's clean
+        // prefix chained behind its kernels where the processor can do that)
+        bool devCommit = false;
+        uint32_t dcStopAt = 0; int dcStopKind = 0;
+        if (useDevCommit) {
             const auto tp = std::chrono::steady_clock::now();
-            proc.processEnd(round.off, round.inst, round.fpOff, round.fp);
+            dcCommitted.clear();
+            devCommit = proc.processRound(seeds + pos, nRound, phase, round.off, round.inst, round.fpOff, round.fp, dcCommitted, dcStopAt, dcStopKind);
             st.processMs += msSince(tp);
-            begun = false;
-            epochMarks.assign(1, sinceBegin);
-            sinceBegin.clear();
-            st.earlyRounds++;
-        } else {
-            flush();                                // processor state == live state at the start of phase `pos`
-            epochMarks.assign(1, RangeSet());
-            // ---- speculative launch of the whole round (dealt to the ranks) ---------------------------------------------
-            sub.assign(seeds + pos, seeds + pos + nRound);
-            processSharded(sub.data(), nullptr, nRound, round, (uint64_t)pos);
+            if (devCommit) launchOrdinal++;
         }
-        if (world == 1 && !cfg.countEvents && !cfg.exchangeAlways && !fixedRound && cfg.overlap && lastInvalid < 0.05 && pos + nRound < nSeeds) {
-            // the processor's state is still the one this round's launch saw (nothing has been committed since): begin the next round
-            flush();
-            begunN = std::min<int64_t>(nSeeds - (pos + nRound), (int64_t)roundPhases * phase);
-            begun = proc.processBegin(seeds + pos + nRound, begunN);
-            sinceBegin.clear();
-        }
+        if (!devCommit) processSharded(seeds + pos, nullptr, nRound, round, (uint64_t)pos);
+        const auto tSetup = std::chrono::steady_clock::now();
         cands.clear(); viewSets.clear();
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
@@ -349,6 +328,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
         if (useSide) { sideJobs.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
         const int64_t recomputedBefore = st.recomputedSeeds;
+        st.sectionMs[LCB_SEC_SETUP] += msSince(tSetup);
 
         // the newest E result of seed i: instances / footprint / provenance
         auto eInst = [&](int64_t i, const lcb_instance*& r, uint64_t& cnt) {
@@ -357,22 +337,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         };
         // Conditions (1) and (2) of the header for a result computed at launch `epoch` against view `view`, judged against
         // the live state now. `checkedTo` caches the closed epochs already examined; `viewOk` caches (1), which is monotone.
-        // relaxViews: can a computation with footprint f and path vertices pv have read a bit of the predicted mark q?
-        auto relevant = [&](const std::pair<uint64_t, uint64_t>& q, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv) -> bool {
-            if (!cfg.relaxViews || !pv) return true;
-            if (!pv->empty() && pv->front() == INT32_MIN) return true;      // the processor could not report the whole path
-            const uint64_t M = (uint64_t)std::max(p->max_branch, p->looking_depth) + 2;    // gap walks of Compatible, look-ahead windows of the vote
-            for (size_t k = 0; k < nf; k++) if (q.first <= (uint64_t)f[k].hi + M && q.second + M > (uint64_t)f[k].lo) return true;
-            for (uint64_t x = q.first; x < q.second; x++) {
-                const int32_t id = g->posId[(size_t)x];
-                if (std::binary_search(pv->begin(), pv->end(), id < 0 ? -id : id)) return true;
-            }
-            return false;
-        };
-        auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv = nullptr) -> bool {
+        auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf) -> bool {
             const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
             if (P && !(viewOk && *viewOk)) {
-                for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && relevant(q, f, nf, pv)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
+                for (auto& q : P->r) if (!com.allUsed(q.first, q.second)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
                 if (viewOk) *viewOk = true;
             }
             const uint32_t last = (uint32_t)epochMarks.size() - 1;
@@ -384,7 +352,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             return true;
         };
         auto eValidNow = [&](int64_t i) -> bool {
-            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV); }
+            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
             return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
         };
 
@@ -413,7 +381,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (slot < 0) { slot = (int32_t)cands.size(); cands.emplace_back(); }
             Cand& c = cands[(size_t)slot];
             c.epoch = sj.epoch; c.view = sj.set; c.checkedTo = (uint32_t)sj.epoch; c.viewOk = viewChecked || sj.set < 0;
-            c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{}; c.pathV.clear();
+            c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{};
             return true;
         };
         auto takeSide = [&](int64_t i, bool isF) -> bool {
@@ -447,7 +415,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         auto planAndLaunch = [&](int64_t ph0, int64_t stopAt, bool midPhase) {
             if (useSide) harvestSide();
             const auto tPlan = std::chrono::steady_clock::now();
+            inPlan = true;
             flush();                                // processor state == live state
+            inPlan = false;
             RangeSet simP;                          // predicted marks on top of the live state
             std::vector<uint8_t> simChr(com.invalidChr.begin(), com.invalidChr.end());
             std::vector<uint32_t> simChrList(com.invalidList.begin(), com.invalidList.end());
@@ -483,9 +453,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 return false;
             };
             // would this result still be exact if the predicted marks came true? (conditions (1) and (2) against live + simP)
-            auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf, const std::vector<int32_t>* pv = nullptr) -> bool {
+            auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf) -> bool {
                 const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
-                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second) && relevant(q, f, nf, pv)) {
+                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second)) {
                     // a predicted mark that is neither true yet nor predicted now (partly true + partly predicted is rare: treat as invalid)
                     return false;
                 }
@@ -511,10 +481,12 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             // start - run against the live state and are known before anything is simulated; their computation begins here and the
             // dry run below runs in its shadow.
             size_t nEarly = 0;                       // the first nEarly jobs of the plan were begun ahead of it
+            double earlyMs = 0;                      // (time inside processBegin: processor time, not planning time)
             auto beginEarly = [&]() {
                 const auto tp = std::chrono::steady_clock::now();
-                if (proc.processBegin(earlySeeds.data(), (int64_t)earlySeeds.size(), true)) nEarly = earlySeeds.size();
-                st.processMs += msSince(tp);
+                if (proc.processBegin(earlySeeds.data(), (int64_t)earlySeeds.size())) nEarly = earlySeeds.size();
+                earlyMs = msSince(tp);
+                st.processMs += earlyMs;
             };
             if (useEarly && midPhase) { earlySeeds.assign(1, seeds[pos + stopAt]); beginEarly(); }
             const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
@@ -533,7 +505,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     for (size_t q = lv; q < lvEnd; q++) {
                         const int64_t j = liveIdx[q];
                         bool ok;
-                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size(), &c.pathV); }
+                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
                         else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
                         if (!ok && !onItsWay(j, false)) {
                             if (!any) { currentView(); any = true; }
@@ -558,7 +530,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     bool have = false;
                     if (fIdx[(size_t)j] >= 0) {
                         Cand& c = cands[(size_t)fIdx[(size_t)j]];
-                        have = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size(), &c.pathV);
+                        have = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size());
                         if (have && c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
                     }
                     if (!have) {
@@ -598,7 +570,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     if (fIdx[(size_t)jobs[k].seed] >= 0) for (auto& in : cands[(size_t)fIdx[(size_t)jobs[k].seed]].inst) { uint64_t lo, hi; instRange(g, in, lo, hi); fl = std::max(fl, hi - lo); }
                     std::cerr << "   job " << k << " seed " << (pos + jobs[k].seed) << (jobs[k].isF ? " F" : " E") << " eLongest " << longest << " eCnt " << cnt << " staleF " << (fIdx[(size_t)jobs[k].seed] >= 0 ? (int64_t)fl : -1) << " view " << jobs[k].devView << "\n";
                 }
-            st.planMs += msSince(tPlan);
+            st.planMs += msSince(tPlan) - earlyMs;
             // The results the commit cannot go on without: the F of the stopping seed, or every missing E of the phase that is about to
             // start. They are the first jobs of the plan and run against the live state.
             size_t nCrit = 1;
@@ -609,7 +581,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (useSide && jobs.size() > nCrit) {
                 const auto tp = std::chrono::steady_clock::now();
                 lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
-                if (lane < 0 && !laneOrder.empty()) {
+                if (lane == -1 && !laneOrder.empty()) {      // (-2: the batch fits no lane - nothing would be gained by stopping another one)
                     // every lane holds a batch with jobs still running: the oldest one gives way (what it has finished is kept)
                     const int old = laneOrder.front();
                     for (size_t q = sideScan; q < sideJobs.size(); q++) if (sideJobs[q].lane == old && sideJobs[q].state == 0) dropSide((int32_t)q);
@@ -667,45 +639,31 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 c.inst.assign(tmp.inst.begin() + tmp.off[k], tmp.inst.begin() + tmp.off[k + 1]);
                 c.fp.assign(tmp.fp.begin() + tmp.fpOff[k], tmp.fp.begin() + tmp.fpOff[k + 1]);
                 if (cfg.countEvents) c.ctr = tmp.ctr[k];
-                if (cfg.relaxViews) c.pathV = tmp.pathV[(size_t)k];
             }
         };
 
-        // ---- device-side commit of the round's clean prefix ---------------------------------------------
-        // The processor validates and commits in its own `used` state as far as no new computation is needed; the host mirrors
-        // those commits (block ids, BlockInstances, its copy of the bitmap) and takes over at the stop.
+        // ---- what the processor committed itself: block ids, BlockInstances and the host's copy of the bitmap follow
         int64_t donePh = 0;                     // phases [0, donePh) of the round are committed
         int64_t resumeAt = -1;                  // >= 0: the phase at donePh is validated and committed up to (not including) this seed, which conflicts
-        if (useDevCommit && !early && !liveIdx.empty()) {
-            const auto tp = std::chrono::steady_clock::now();
-            dcOff.assign(1, 0u); dcFpOff.assign(1, 0u); dcInst.clear(); dcFp.clear();
-            for (int32_t i : liveIdx) {
-                dcInst.insert(dcInst.end(), round.inst.begin() + round.off[i], round.inst.begin() + round.off[i + 1]);
-                dcFp.insert(dcFp.end(), round.fp.begin() + round.fpOff[i], round.fp.begin() + round.fpOff[i + 1]);
-                dcOff.push_back((uint32_t)dcInst.size()); dcFpOff.push_back((uint32_t)dcFp.size());
+        if (devCommit) {
+            const auto tMirror = std::chrono::steady_clock::now();
+            int64_t curPh = -1;
+            for (uint32_t i : dcCommitted) {
+                if ((int64_t)i >= nRound || round.off[i + 1] - round.off[i] <= 1) throw LcbError("engine: the processor committed a seed that has no block");
+                const int64_t ph = (int64_t)i / phase;
+                if (ph != curPh) { if (curPh >= 0) com.endPhase(); curPh = ph; }
+                com.finalize(round.inst.data() + round.off[i], round.off[i + 1] - round.off[i]);
+                takeMarks(true);
+                st.deviceCommits++;
             }
-            uint32_t stopAt = 0; int stopKind = 0;
-            dcCommitted.clear();
-            flush();                            // (nothing is pending at a round start; the processor's state is the round's)
-            if (proc.commitRound(liveIdx, dcOff, dcInst, dcFpOff, dcFp, phase, dcCommitted, stopAt, stopKind)) {
-                int64_t curPh = -1;
-                for (uint32_t q : dcCommitted) {
-                    const int64_t i = liveIdx[q], ph = i / phase;
-                    if (ph != curPh) { if (curPh >= 0) com.endPhase(); curPh = ph; }
-                    com.finalize(round.inst.data() + round.off[i], round.off[i + 1] - round.off[i]);
-                    takeMarks(true);
-                    st.deviceCommits++;
-                }
-                if (stopKind == 0) { donePh = nRound; if (curPh >= 0) com.endPhase(); st.deviceRounds++; }
-                else {
-                    const int64_t stopSeed = liveIdx[stopAt];
-                    donePh = (stopSeed / phase) * phase;
-                    if (curPh >= 0 && (curPh * phase < donePh || stopKind == 1)) com.endPhase();      // (a stop at a phase start: the previous phase is closed)
-                    if (stopKind == 2) resumeAt = stopSeed;                                                // ... inside a phase: its invalidChr_ stays
-                }
-                if (cfg.progress) for (int64_t i = ((pos + portion - 1) / portion) * portion; i < pos + donePh; i += portion) std::cout << '.' << std::flush;
+            if (dcStopKind == 0) { donePh = nRound; if (curPh >= 0) com.endPhase(); st.deviceRounds++; }
+            else {
+                donePh = ((int64_t)dcStopAt / phase) * phase;
+                if (curPh >= 0 && curPh * phase < donePh) com.endPhase();                 // (a stop at a phase start: the previous phase is closed)
+                if (dcStopKind == 2) resumeAt = (int64_t)dcStopAt;                          // ... inside a phase: its invalidChr_ stays
             }
-            st.processMs += msSince(tp);
+            if (cfg.progress) for (int64_t i = ((pos + portion - 1) / portion) * portion; i < pos + donePh; i += portion) std::cout << '.' << std::flush;
+            st.sectionMs[LCB_SEC_MIRROR] += msSince(tMirror);
         }
         frozenTo = donePh;
 
@@ -715,6 +673,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             const bool resumed = resumeAt >= 0 && ph == donePh;       // the device validated this phase and committed its seeds before resumeAt
             // (a) exact phase-start results for every seed of the phase
             const size_t lv0 = liveFrom(resumed ? resumeAt : ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
+            double inStop = st.processMs + st.planMs;       // (what the stops inside a section cost is accounted there)
+            auto tSec = std::chrono::steady_clock::now();
             for (; !resumed;) {
                 bool all = true;
                 for (size_t q = lv0; q < lv1 && all; q++) {
@@ -736,6 +696,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 planAndLaunch(ph, ph, false);
             }
             frozenTo = ph + n;
+            st.sectionMs[LCB_SEC_VALIDATE] += msSince(tSec) - (st.processMs + st.planMs - inStop);
+            inStop = st.processMs + st.planMs; tSec = std::chrono::steady_clock::now();
             // (b) ordered commit (blocksfinder.h:372-414)
             if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;   // (a resumed phase prints its dots here)
             // the phase-start result of every seed is exact now: its events are the ones the reference's Process() call has
@@ -758,7 +720,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 for (;;) {
                     if (fIdx[(size_t)i] >= 0) {
                         Cand& c = cands[(size_t)fIdx[(size_t)i]];
-                        if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size(), &c.pathV)) break;
+                        if (validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size())) break;
                     }
                     if (useSide && takeSide(i, true)) continue;      // a background result for it has arrived: validate that
                     planAndLaunch(ph, i, true);
@@ -776,6 +738,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 if (c.inst.size() > 1) { com.finalize(c.inst.data(), c.inst.size()); takeMarks(); }   // blocksfinder.h:408-411
             }
             com.endPhase();
+            st.sectionMs[LCB_SEC_COMMIT] += msSince(tSec) - (st.processMs + st.planMs - inStop);
         }
         if (useSide) for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].state == 0) dropSide((int32_t)q);   // speculation beyond the round is void
         pos += nRound;

@@ -25,11 +25,10 @@ void lcb_device_process_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, st
                              std::vector<lcb_instance>& inst, int64_t* bestScore, lcb_counters* ctr,
                              std::vector<uint64_t>* fpOffsets = nullptr, std::vector<lcb_fp>* fp = nullptr,
                              const uint32_t* view = nullptr,    // view[i]: `used` view of seed i (null = the live state)
-                             std::vector<lcb_counters>* perSeedCtr = nullptr,
-                             std::vector<std::vector<int32_t>>* pathSink = nullptr);   // -DLCB_PATH_SIG=1 builds: sorted |id| of every seed's path vertices   // stats mode: the counters of every seed
+                             std::vector<lcb_counters>* perSeedCtr = nullptr);   // stats mode: the counters of every seed
 // The same for a call whose first launch overlaps with host work: begin enqueues it against the live state of this moment (false:
 // not applicable, use the synchronous call), end waits and completes it.
-bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, bool anySize = false);
+bool lcb_device_process_begin_impl(lcb_device* d, const lcb_seed* seeds, int64_t n);
 void lcb_device_process_end_impl(lcb_device* d, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOffsets,
                                  std::vector<lcb_fp>& fp);
 // Predicted `used` views 1..nViews = live state + the marks with firstView <= v (engine.cpp).
@@ -40,14 +39,15 @@ int lcb_device_side_lanes_impl(lcb_device* d);
 int lcb_device_side_begin_impl(lcb_device* d, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_side_poll_impl(lcb_device* d, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp);
 void lcb_device_side_release_impl(lcb_device* d, int lane);
-// device-side ordered commit of a round's clean prefix (LcbProcessor::commitRound)
-bool lcb_device_commit_round_impl(lcb_device* d, const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
-                                  const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
-                                  std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind);
+// a round with the device-resident ordered commit of its clean prefix chained behind its launches (LcbProcessor::processRound)
+bool lcb_device_process_round_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst,
+                                   std::vector<uint64_t>& fpOffsets, std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind);
 double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);
-void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches);
+// since the last call: sum of the hipEvent-timed kernel durations over all streams, launches, union of the kernels' intervals (the time
+// the GPU was busy with them: side-lane kernels overlap the synchronous ones), and the part of the sum that ran on the side lanes
+void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches, double* busyMs = nullptr, double* sideMs = nullptr);
 int64_t lcb_device_big_retries_impl(lcb_device* d);
 void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t nSeeds,
                           const LcbEngineConfig& cfg, std::vector<lcb_block>& blocks, lcb_stats* stats);

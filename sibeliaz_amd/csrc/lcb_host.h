@@ -84,15 +84,11 @@ struct LcbProcessor {
     // when set, process() also stores the reference-semantics event counters of every seed here (a processor that can
     // count them: the device in stats mode; others leave it empty)
     std::vector<lcb_counters>* ctrSink = nullptr;
-    // when set, process() also stores the sorted |vertex id| list of every seed's path (every vertex that was part of the path at
-    // any time of the computation); only the oracle-backed model processor of tests/emu provides it today (relaxViews below)
-    std::vector<std::vector<int32_t>>* pathSink = nullptr;
     // predicted views: maxViews() == 0 means the processor has none (everything runs against the live state)
     // Optional: start process(seeds, view 0) now, against the state of this moment (marks applied later must not reach it),
-    // and collect it with processEnd — the engine commits the previous round in between (anySize = false: only calls large
-    // enough to be worth it), or plans the rest of a stop's jobs while the results the stop needs are computed (anySize = true).
-    // false = not supported / not applicable.
-    virtual bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize = false) { (void)seeds; (void)n; (void)anySize; return false; }
+    // and collect it with processEnd — the engine plans the rest of a stop's jobs while the results the stop cannot go on without
+    // are computed. false = not supported / not applicable.
+    virtual bool processBegin(const lcb_seed* seeds, int64_t n) { (void)seeds; (void)n; return false; }
     virtual void processEnd(std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff, std::vector<lcb_fp>& fp)
     {
         (void)off; (void)inst; (void)fpOff; (void)fp; throw LcbError("processEnd without processBegin");
@@ -111,7 +107,7 @@ struct LcbProcessor {
     // is in the true state at the job's turn; a bit read as 0 that has been marked since is inside the footprint).
     virtual int sideLanes() const { return 0; }          // batches that can be in flight at once (0: no side lanes)
     // Starts seed i against view[i] (0 = live state, v >= 1 = view v of the nViews predicted views given by marks; the views are
-    // private to the batch). Returns the lane (>= 0), or -1: no lane is free (or the batch does not fit one).
+    // private to the batch). Returns the lane (>= 0), -1: no lane is free, or -2: the batch fits no lane (too many jobs, too many private pages).
     virtual int sideBegin(const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
     {
         (void)seeds; (void)view; (void)n; (void)nViews; (void)marks; (void)nMarks; return -1;
@@ -125,18 +121,19 @@ struct LcbProcessor {
     // Nobody will ask for the batch's results any more: its jobs stop at their next step, the lane is free once they have.
     virtual void sideRelease(int lane) { (void)lane; }
 
-    // ---- device-side ordered commit, optional. The clean prefix of a round - phase-start results that are still
-    // exact, results that pass the weak conflict check - is committed where the `used` state lives: the processor walks the round's
-    // live seeds in order (live[q]: index in the round, ascending; the instances inst[off[q] .. off[q+1]) and the footprint
-    // fp[fpOff[q] .. fpOff[q+1]) of each), marks what it commits in ITS state and stops at the first seed that needs a new
-    // computation. committed: the q's it committed, in order; stopAt / stopKind: where and why it stopped (stopKind 0: the whole
-    // round is committed, 1: a phase-start result of the phase that begins at live index stopAt is void, 2: seed stopAt conflicts).
-    // The state must be the one the round was launched against. false: not supported (the engine commits on the host).
-    virtual bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst,
-                             const std::vector<uint32_t>& fpOff, const std::vector<lcb_fp>& fp, int64_t phase,
-                             std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
+    // ---- device-resident ordered commit, optional. processRound = process() of ALL the seeds of a round against
+    // the live state (seed i of the call is seed i of the round; phases of `phase` seeds) with the thread-0 section of the reference
+    // (blocksfinder.h:372-414) for the round's clean prefix done where the results are: phase by phase, phase-start results that are
+    // still exact (no mark of this round inside their footprint) and pass the weak conflict check are committed - marked used in the
+    // processor's OWN state - until the first seed that needs a new computation. committed: the indices it committed, in order;
+    // stopKind 0: the whole round is committed; 1: a phase-start result of the phase that begins at seed stopAt is void; 2: seed
+    // stopAt conflicts (its phase is committed up to it); 3: the processor got no further than the phase that begins at stopAt
+    // (nothing is wrong with it). The engine assigns block ids, mirrors the marks and goes on from the stop.
+    // false: not supported (nothing was done; the engine calls process() and commits on the host).
+    virtual bool processRound(const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
+                              std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
     {
-        (void)live; (void)off; (void)inst; (void)fpOff; (void)fp; (void)phase; (void)committed; (void)stopAt; (void)stopKind; return false;
+        (void)seeds; (void)n; (void)phase; (void)off; (void)inst; (void)fpOff; (void)fp; (void)committed; (void)stopAt; (void)stopKind; return false;
     }
 };
 
@@ -164,7 +161,7 @@ struct LcbEagerSideLanes {
     }
     int begin(LcbProcessor& p, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks)
     {
-        if (cap > 0 && n > cap) return -1;
+        if (cap > 0 && n > cap) return -2;
         for (size_t l = 0; l < lanes.size(); l++) {
             if (lanes[l].busy) continue;
             Lane& L = lanes[l];
@@ -203,19 +200,16 @@ struct LcbEngineConfig {
     int maxJobs = 0;          // a dry run stops planning beyond this many jobs (0 = the processor's concurrency)
     int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
     bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
-    bool overlap = false;     // begin the next round's launch while this round is committed (sparse stretches, one rank). Off by
-                              // default: measured slower on configs 2 and 3 (the early results are computed against an older state, more of
-                              // them are void, and a stop has to wait for the early launch): 437 k vs 457 k and 1.87 M vs 1.93 M seeds/s
-    bool relaxViews = false;  // EXPERIMENT (needs a processor with pathSink): a predicted mark of a job's view that did not come true voids
-                              // the job's result only if the job can have read it - it lies within max_branch + 2 positions of the result's
-                              // footprint or holds an occurrence of one of the path's vertices. Every `used` read of Process() is of one of
-                              // these kinds, so the rule is exact; today any such mark voids every later job of the launch.
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
-    bool deviceCommit = false; // use the processor's commitRound for the clean prefix of every round. Off by default: built and
-                              // exact under the wavefront emulator, but the GPU budget of round 3 was spent before it ran on the MI355X
-    bool earlyCritical = false; // begin the stop's own jobs before the dry run that plans the rest (processBegin(anySize) / processEnd); needs side lanes
+    bool hostCommit = false;  // never use the processor's commitRound: the ordered commit of a round runs on the host only (A/B runs, tests)
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
+
+enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch (lists of the seeds that read or commit anything)
+       LCB_SEC_VALIDATE,       // phase-start validation of footprints against the marks since a result's launch
+       LCB_SEC_COMMIT,         // weak conflict check, Finalize, marks into the epochs
+       LCB_SEC_FLUSH,          // marks handed to the processor (LcbProcessor::mark)
+       LCB_SEC_MIRROR };       // block ids / BlockInstances / host bitmap of what the processor committed itself
 
 struct LcbEngineStats {
     int64_t seeds = 0, blocksFound = 0, failures = 0, rounds = 0, recomputeLaunches = 0, recomputedSeeds = 0, conflictLaunches = 0,
@@ -224,7 +218,6 @@ struct LcbEngineStats {
     int64_t jobsUsed = 0;         // ... results that were committed from (exactly validated)
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
-    int64_t earlyRounds = 0;      // rounds whose launch ran while the previous round was being committed
     int64_t deviceCommits = 0;    // results committed by the processor itself (commitRound), and ...
     int64_t deviceRounds = 0;     // ... rounds it committed completely
     int64_t earlyCritical = 0;    // stops whose own jobs ran while the rest was planned
@@ -234,6 +227,7 @@ struct LcbEngineStats {
     int64_t sideFailed = 0;       // ... jobs that ended without a result (stopped, or needed another kernel variant)
     double wallMs = 0;
     double processMs = 0, planMs = 0;   // wall time inside the processor (launches + result gathering) / inside the dry runs
+    double sectionMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // LCB_SEC_*: where the rest of the host's time goes (diagnostics: LCB_VERBOSE)
     lcb_counters events{};              // countEvents: totals over the phase-start result of every seed + the re-processed result of every conflict
 };
 

@@ -41,12 +41,6 @@
 #include <stdint.h>
 
 #define LCB_EMPTY_KEY INT32_MIN
-// Experiment (round 3, not measured yet, off): the pushes of an edge batch in the compact variant run as a software pipeline - the
-// occurrence records of edge l+2, the chromosome bounds and `used` words of edge l+1 and the home slot of vertex l+1 in the path set are
-// requested before edge l is pushed, so that a push waits for no global load of its own (see lcb_extend).
-#ifndef LCB_PUSH_AHEAD
-#define LCB_PUSH_AHEAD 0
-#endif
 // A pointer the compiler cannot prove to be a global one (it was merged with a null) is dereferenced with FLAT loads, which wait on
 // two counters and are slower; this says what it is. (Device compiler only: the CPU emulator of the tests sees a plain pointer.)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -114,12 +108,6 @@ struct LcbUsed { const uint32_t* live; const uint32_t* tab; };
 struct LcbKParams { int32_t k, minBlock, maxBranch, maxFlank, depth; };
 struct LcbKSeed { int32_t vid; int32_t ch; uint32_t view; uint32_t pad; };   // view: which `used` view this seed reads
 
-// Round-3 candidate, NOT in the shipped build (-DLCB_PATH_SIG=1): a seed that runs against a predicted view (a job) also reports
-// every vertex that was part of its path at any time - what LcbEngineConfig::relaxViews needs to tell which predicted marks the
-// computation can have read (profiles/r02/engine_model_findings.md).
-#ifndef LCB_PATH_SIG
-#define LCB_PATH_SIG 0
-#endif
 struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint32_t nInst;
     uint32_t status;
@@ -128,11 +116,6 @@ struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint64_t fpOff;            // first footprint interval of this seed in the footprint arena
     uint32_t nFp;              // number of footprint intervals (= instances ever created)
     uint32_t poolInst;         // instances in the pool when the seed ended (on an overflow: what the next variant has to hold at least)
-#if LCB_PATH_SIG
-    uint64_t sigOff;           // first path vertex of this seed in the signature arena
-    uint32_t nSig;             // number of them (with repeats); UINT32_MAX: the list did not fit - every mark counts as read
-    uint32_t pad2;
-#endif
 };
 struct LcbSeedCtr { uint64_t c[16]; };  // [0..8): lcb_counters order in stats mode, a cheap profile in the instrumented variant; [8..16): vote sections (instrumented)
 
@@ -155,17 +138,17 @@ struct LcbWork {               // per-workgroup global-memory workspace slots + 
     LcbSeedCtr* ctr;           // per-seed counters (stats / instrumented variants), or null
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
     const uint32_t* abort;     // asynchronous job batches (device.hip, side lanes): when the word becomes non-zero the seeds give up at their next vote
-#if LCB_PATH_SIG
-    int32_t* sigArena;         // path vertices of the seeds with a view (null: not wanted)
-    unsigned long long* sigCursor;
-    unsigned long long sigBase, sigCap;
-#endif
+    // Launches of a ROUND (device.hip, lcb_commit_body below): the header of a seed that ended with a final result is also kept on the
+    // device under the seed's index in the round - where the commit kernel that is chained behind the launch reads it.
+    const uint32_t* roundIdx;  // launch-local seed index -> index in the round, or null: not a round launch
+    LcbSeedOut* roundOut;      // [seeds of the round] headers of final results (arenaOff / fpOff index the launch's arenas, which a round never resets)
+    uint32_t* roundState;      // [seeds of the round] LCB_RS_*
 };
+enum { LCB_RS_NONE = 0, LCB_RS_DEAD = 1, LCB_RS_DONE = 2 };   // no final result yet / Path::Init finds nothing: empty result, no read / result in roundOut
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
     uint64_t pKeys, pSlots, body, best, ck;                   // always (ck: forward-extension checkpoint, 6 words per instance)
-    uint64_t sig;                                              // LCB_PATH_SIG: every vertex ever inserted into the path set
     uint64_t inst, fp;                                          // big and huge modes
     uint64_t ordKey, ordIdx, good, goodPos, touch, vKey, vCount, vLast, vTouched;   // huge mode
     uint64_t total;
@@ -181,7 +164,6 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.body = o; o = lcb_align16(o + 8ull * bodyCap);
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
     L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
-    L.sig = o; o = lcb_align16(o + (LCB_PATH_SIG ? 4ull * (2ull * pathCap + 8) : 0ull));
     L.inst = o; o = lcb_align16(o + 9ull * 4 * instCap);
     L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
     const uint32_t idxCap = voteCap ? instCap : 0;             // the index / list / vote arrays only exist in huge mode
@@ -307,9 +289,6 @@ struct LcbStateT {
     int32_t* pKeys;
     uint32_t* pSlots;
     uint32_t pathCap, pathShift;
-#if LCB_PATH_SIG
-    int32_t* sig; uint32_t nSig, sigCap;      // every vertex ever inserted (null: not recorded for this seed)
-#endif
     unsigned long long* body;  // right body: (strand << 32) | g of the iterator whose outgoing edge was pushed
     uint32_t bodyCap;
     uint4* best;
@@ -321,7 +300,6 @@ struct LcbStateT {
     int32_t ckFlank;
     // wave-uniform scalars
     uint32_t nInst, nGood, cur, nPath, nRight, nLeft, nBest, status;
-    uint32_t lastIns;                // slot of the path set the newest insert wrote (a home slot read before that insert is stale if it is this one)
     int32_t rightFlank, leftFlank;   // rightBodyFlank_, leftBodyFlank_ (path.h:692-693)
     uint32_t* dbg;             // flight recorder of this workgroup (may be null)
     const uint32_t* abort;     // stop flag of an asynchronous batch (null: none)
@@ -469,9 +447,6 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
     if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
     constexpr bool PL = LcbCfg<ST::MODE>::PC != 0;
     LCB_SYNC_IF(PL);               // every lane has finished probing before lane 0 publishes the key
-#if LCB_PATH_SIG
-    if (S.sig) { if (S.nSig < S.sigCap && S.lane == 0) S.sig[S.nSig] = vid; S.nSig++; }
-#endif
     if (S.lane == 0) {
         S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
         if (LcbCfg<ST::MODE>::BW) {
@@ -481,49 +456,6 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
         }
     }
     S.nPath++;
-    S.lastIns = h;
-    LCB_SYNC_IF(PL);
-}
-
-// The probe of a push with the home slot's key already at hand (key0 = pKeys[hash(vid)], possibly read one push earlier): walks the
-// chain to vid or to the first empty slot - where vid goes if it is not in the set, so the insert needs no probe of its own.
-template <bool PROF, class ST>
-__device__ inline bool lcb_path_probe_from(ST& S, int32_t vid, int32_t key0, uint32_t& slot)
-{
-    uint32_t h = lcb_hash(vid, S.pathShift);
-    const uint32_t mask = S.pathCap - 1;
-    uint32_t probe = 0;
-    int32_t k = key0;
-    while (k != vid && k != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; k = S.pKeys[h]; }
-    if (PROF && probe > S.pfMaxProbe) S.pfMaxProbe = probe;
-    slot = h;
-    return k == vid;
-}
-
-// lcb_path_insert with the empty slot already found (lcb_path_probe_from). Wave-uniform; lane 0 writes.
-template <class ST>
-__device__ inline void lcb_path_insert_at(ST& S, int32_t vid, uint32_t h)
-{
-    if ((S.nPath + 1) * 2 > S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
-#ifdef LCB_EMU_HIP_RUNTIME_H
-    // (builds of the CPU wavefront emulator only: the slot found with a key that was read one push ahead must still be empty)
-    if (S.pKeys[h] != LCB_EMPTY_KEY) { fprintf(stderr, "emu: lcb_path_insert_at would overwrite an occupied slot of the path set\n"); abort(); }
-#endif
-    constexpr bool PL = LcbCfg<ST::MODE>::PC != 0;
-    LCB_SYNC_IF(PL);               // every lane has finished probing before lane 0 publishes the key
-#if LCB_PATH_SIG
-    if (S.sig) { if (S.nSig < S.sigCap && S.lane == 0) S.sig[S.nSig] = vid; S.nSig++; }
-#endif
-    if (S.lane == 0) {
-        S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
-        if (LcbCfg<ST::MODE>::BW) {
-            const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
-            S.bloom[a >> 5] |= 1u << (a & 31);
-            S.bloom[b >> 5] |= 1u << (b & 31);
-        }
-    }
-    S.nPath++;
-    S.lastIns = h;
     LCB_SYNC_IF(PL);
 }
 
@@ -974,26 +906,35 @@ __device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const LcbUs
     return o;
 }
 
+// (The three words are combined with shifts, never selected by a computed index: a select among members of the struct turns into a
+// dynamically indexed load, which keeps the whole LcbOcc in scratch memory - 64 B per lane written and read back in every push.)
 __device__ __forceinline__ bool lcb_occ_bit(const LcbOcc& o, uint32_t g)
 {
-    const uint32_t w = (g >> 5) - o.wbase;                // 0..2 for g and g-1
-    const uint32_t word = w == 0 ? o.uw0 : (w == 1 ? o.uw1 : o.uw2);
-    return (word >> (g & 31)) & 1u;
+    const uint32_t off = g - (o.wbase << 5);                // 0..95 for g and g-1
+    const uint64_t lo = (uint64_t)o.uw0 | ((uint64_t)o.uw1 << 32);
+    return off < 64u ? ((lo >> off) & 1ull) != 0 : ((o.uw2 >> (off - 64u)) & 1u) != 0;
 }
 
 // lcb_range_any_used over [a, b), served from the cached words when the range lies inside them.
-__device__ inline bool lcb_range_any_used_c(const LcbUsed& U, const LcbOcc& o, uint32_t a, uint32_t b)
+__device__ __forceinline__ bool lcb_range_any_used_c(const LcbUsed& U, const LcbOcc& o, uint32_t a, uint32_t b)
 {
     if (a >= b) return false;
     const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
     if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(U, a, b);
-    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-    const uint32_t ia = wa - o.wbase, ib = wb - o.wbase;
-    uint32_t acc = 0;
-    acc |= (ia == 0 ? o.uw0 : (ia == 1 ? o.uw1 : o.uw2)) & ma & (ia == ib ? mb : 0xFFFFFFFFu);
-    if (ib > ia) acc |= (ib == 1 ? o.uw1 : o.uw2) & mb;
-    if (ib == ia + 2) acc |= o.uw1;
-    return acc != 0;
+    const uint32_t oa = a - (o.wbase << 5), ob = b - (o.wbase << 5);          // bit offsets into the 96 cached bits, oa < ob <= 96
+    const uint64_t lo = (uint64_t)o.uw0 | ((uint64_t)o.uw1 << 32);
+    bool any = false;
+    if (oa < 64u) {
+        const uint32_t e = ob < 64u ? ob : 64u;                               // bits [oa, e) of the low 64
+        const uint64_t m = (e == 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << oa) - 1ull);
+        any = (lo & m) != 0;
+    }
+    if (ob > 64u) {
+        const uint32_t s = oa > 64u ? oa - 64u : 0u, e = ob - 64u;            // bits [s, e) of the third word, e <= 32
+        const uint32_t m = (e == 32u ? 0xFFFFFFFFu : ((1u << e) - 1u)) & ~((1u << s) - 1u);
+        any = any || (o.uw2 & m) != 0;
+    }
+    return any;
 }
 
 // What a push needs to know about the walked edge (wave-uniform, in scalar registers).
@@ -1011,36 +952,24 @@ struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posI
 // BACK=false: PointPushFront(e), e = IngoingEdge of iterator (gIt, itPositive): vertex = start vertex.
 // rec0: the occurrence records o0 + lane of the pushed vertex, already loaded by the caller.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
-// What the caller of a push may have requested ahead of it (LCB_PUSH_AHEAD, compact variant): the finished first chunk of occurrences
-// and the key in the home slot of the pushed vertex.
-struct LcbPushAhead { LcbOcc occ; int32_t key0; uint32_t home; };
-
 template <bool BACK, bool STATS, bool PROF, class ST>
-__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0, const LcbPushAhead* ahead = nullptr)
+__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
     const uint32_t o0 = E.o0, o1 = E.o1;
     // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
-    LcbOcc occ = ahead ? ahead->occ : lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
-    uint32_t slot = 0;
-    bool inPath;
-    if (ahead) {
-        // (a key read before the newest insert wrote that very slot is stale: read it again)
-        const int32_t key0 = ahead->home != S.lastIns ? ahead->key0 : S.pKeys[ahead->home];
-        inPath = lcb_path_probe_from<PROF>(S, vertex, key0, slot);
-    } else {
-        inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
-        if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
-    }
+    LcbOcc occ = lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
+    bool inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
+    if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
     if (inPath) return false;
     const uint32_t length = lcb_absdiff(E.posN, E.posIt);
     const int32_t ech = E.ech;
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
     if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
     const int32_t distance = (int32_t)dist64;
-    if (ahead) lcb_path_insert_at(S, vertex, slot); else lcb_path_insert(S, vertex);
+    lcb_path_insert(S, vertex);
     if (S.status) return false;
 
     const int64_t B = S.P.maxBranch;
@@ -1364,19 +1293,6 @@ __device__ __forceinline__ LcbEdge lcb_edge_of(const LcbEdgeBatch& b, uint32_t l
     return e;
 }
 
-// LCB_PUSH_AHEAD: what the push of edge l of the batch will need, requested now (rec = the occurrence records of its first chunk).
-template <class ST>
-__device__ __forceinline__ LcbPushAhead lcb_push_ahead(const ST& S, const LcbEdgeBatch& b, uint32_t l, const uint4& rec)
-{
-    LcbPushAhead a;
-    const uint32_t p0 = lcb_rl(b.o0, l), p1 = lcb_rl(b.o1, l);
-    a.occ = lcb_finish_occ(S.T, S.U, rec, p0 + S.lane < p1);
-    const int32_t idN = lcb_rl(b.idN, l);
-    a.home = lcb_hash(lcb_rl(b.itPos, l) != 0 ? idN : -idN, S.pathShift);
-    a.key0 = S.pKeys[a.home];
-    return a;
-}
-
 // ExtendPathForward / ExtendPathBackward (blocksfinder.h:770-895)
 template <bool FORWARD, bool STATS, bool PROF, int NW, class ST>
 __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestScore, int64_t& nowScore)
@@ -1407,24 +1323,13 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
             if (nE == 0) break;                                      // defensive: a voted vertex is always reached
             // occurrence records of the first edge; those of edge l+1 are requested before edge l is pushed
             uint4 rec = lcb_load_rec(T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
-            // (compact variant, LCB_PUSH_AHEAD: a pipeline two edges deep - records of edge l+2, bounds / `used` words / home slot of edge l+1)
-            constexpr bool AHEAD = LCB_PUSH_AHEAD != 0 && ST::MODE == 0;
-            uint4 recA = uint4{0u, 0u, 0u, 0u};                      // AHEAD: records of edge l+1
-            LcbPushAhead pa, paN;
-            if (AHEAD) {
-                pa = lcb_push_ahead(S, bt, 0, rec);
-                if (nE > 1) { const uint32_t p0 = lcb_rl(bt.o0, 1), p1 = lcb_rl(bt.o1, 1); recA = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
-            }
             for (uint32_t l = 0; l < nE; l++) {
                 const LcbEdge E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (AHEAD) {
-                    if (l + 2 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 2), p1 = lcb_rl(bt.o1, l + 2); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
-                    if (l + 1 < nE) paN = lcb_push_ahead(S, bt, l + 1, recA);
-                } else if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
                 LCB_MARK(S, 6, 3); LCB_MARK(S, 8, E.gIt);
                 const uint64_t tp0 = PROF ? wall_clock64() : 0;
-                success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec, AHEAD ? &pa : nullptr);
+                success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec);
                 const uint64_t tp1 = PROF ? wall_clock64() : 0;
                 if (PROF) S.pfTPush += tp1 - tp0;
                 LCB_MARK(S, 6, 4);
@@ -1442,7 +1347,7 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
                     }
                     if (PROF) S.pfTScore += wall_clock64() - tp1;
                 }
-                if (AHEAD) { rec = recA; recA = recN; pa = paN; } else rec = recN;
+                rec = recN;
             }
             if (nE < 64 || (positive ? lcb_rl(bt.idN, 63) : -lcb_rl(bt.idN, 63)) == next) break;
             g = (uint32_t)((int64_t)g + 64 * dir);
@@ -1491,22 +1396,12 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
             LcbEdgeBatch bt;
             lcb_batch_from_body(S, from, nE, bt);
             uint4 rec = lcb_load_rec(S.T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
-            constexpr bool AHEAD = LCB_PUSH_AHEAD != 0 && MODE == 0;     // (the pipeline of lcb_extend)
-            uint4 recA = uint4{0u, 0u, 0u, 0u};
-            LcbPushAhead pa, paN;
-            if (AHEAD) {
-                pa = lcb_push_ahead(S, bt, 0, rec);
-                if (nE > 1) { const uint32_t p0 = lcb_rl(bt.o0, 1), p1 = lcb_rl(bt.o1, 1); recA = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
-            }
             for (uint32_t l = 0; l < nE && !S.status; l++) {
                 const LcbEdge E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (AHEAD) {
-                    if (l + 2 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 2), p1 = lcb_rl(bt.o1, l + 2); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
-                    if (l + 1 < nE) paN = lcb_push_ahead(S, bt, l + 1, recA);
-                } else if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
-                lcb_push<true, STATS, PROF>(S, E, false, rec, AHEAD ? &pa : nullptr);
-                if (AHEAD) { rec = recA; recA = recN; pa = paN; } else rec = recN;
+                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+                lcb_push<true, STATS, PROF>(S, E, false, rec);
+                rec = recN;
             }
             from += nE;
         }
@@ -1554,9 +1449,7 @@ struct LcbLaunchArgs {
     const uint32_t* live;
     uint32_t cursorBase, nSeeds;
     const uint32_t* usedTab;       // page table of the `used` view of the seed wave 0 is working on (read by the helpers at each vote)
-#if LCB_PATH_SIG
-    int32_t* sigArena; unsigned long long* sigCursor; unsigned long long sigBase, sigCap;
-#endif
+    const uint32_t* roundIdx; LcbSeedOut* roundOut; uint32_t* roundState;
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
@@ -1591,9 +1484,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         sArgs.seeds = seeds; sArgs.out = out; sArgs.ctr = W.ctr; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
         sArgs.arenaBase = W.arenaBase; sArgs.fpBase = W.fpBase; sArgs.arenaCursor = W.arenaCursor; sArgs.fpCursor = W.fpCursor;
         sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.live = W.live; sArgs.nSeeds = W.live ? *W.nLive : nSeeds;
-#if LCB_PATH_SIG
-        sArgs.sigArena = W.sigArena; sArgs.sigCursor = W.sigCursor; sArgs.sigBase = W.sigBase; sArgs.sigCap = W.sigCap;
-#endif
+        sArgs.roundIdx = W.roundIdx; sArgs.roundOut = W.roundOut; sArgs.roundState = W.roundState;
     }
 
     LcbStateT<MODE> S;
@@ -1645,7 +1536,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.abort = W.abort;
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
-    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0; S.lastIns = 0xFFFFFFFFu;
+    S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
     S.pfPush = S.pfVote = S.pfMaxProbe = S.pfMaxInst = 0; S.pfTVote = S.pfTPush = S.pfTScore = 0; S.nFp = 0;
@@ -1700,10 +1591,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         const int32_t vid = lcb_rfl(sd.vid), ch = lcb_rfl(sd.ch);
         S.U = lcb_used_of(T, lcb_rfl(sd.view));
         if (NW > 1 && S.lane == 0) sArgs.usedTab = S.U.tab;      // published to the helpers by the vote's first barrier
-#if LCB_PATH_SIG
-        S.sig = sArgs.sigArena ? (int32_t*)(slot + L.sig) : nullptr;      // (the host asks for it in job launches only)
-        S.nSig = 0; S.sigCap = 2u * W.pathCap + 8u;
-#endif
         lcb_process_seed<MODE, STATS, PROF, NW>(S, vid, ch, bestScore);
         if (S.status == LCB_ST_VOTE_OVF) {
             // the vote table may hold stale keys after an overflow (the helpers have cleared their slices; wave 0 wipes all)
@@ -1736,22 +1623,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
             else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
         }
-#if LCB_PATH_SIG
-        unsigned long long sgo = 0;
-        uint32_t nsg = 0;
-        if (S.sig && S.status == LCB_ST_OK) {
-            LCB_WAVE_SYNC();
-            nsg = S.nSig > S.sigCap ? 0xFFFFFFFFu : S.nSig;
-            if (nsg != 0xFFFFFFFFu && nsg) {
-                uint32_t olo = 0, ohi = 0;
-                if (S.lane == 0) { sgo = atomicAdd(sArgs.sigCursor, (unsigned long long)nsg) - sArgs.sigBase; olo = (uint32_t)sgo; ohi = (uint32_t)(sgo >> 32); }
-                olo = lcb_rfl(olo); ohi = lcb_rfl(ohi);
-                sgo = ((unsigned long long)ohi << 32) | olo;
-                if (sgo + nsg > sArgs.sigCap) nsg = 0xFFFFFFFFu;
-                else for (uint32_t e = S.lane; e < nsg; e += 64) sArgs.sigArena[sgo + e] = S.sig[e];
-            }
-        }
-#endif
         // (no local arrays here: the compiler would move them to LDS, 48 B x every lane of the workgroup)
         uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
         if (STATS) {
@@ -1766,9 +1637,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             o->nInst = n;   // kept on ARENA_OVF so the host can track the allocator
             o->bestScore = bestScore; o->arenaOff = off;
             o->fpOff = fpo; o->nFp = nfp; o->poolInst = S.endInst;
-#if LCB_PATH_SIG
-            o->sigOff = sgo; o->nSig = nsg; o->pad2 = 0;
-#endif
         }
         // (only in launches whose headers the host polls: the release writes back the L2 of the whole XCD, 8 % of a config-3 pass
         // when every seed of every launch did it; a synchronous launch is read after its stream has drained)
@@ -1777,6 +1645,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             LcbSeedOut* o = sArgs.out + s;
             if (S.abort) __hip_atomic_store(&o->status, (uint32_t)S.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             else o->status = S.status;
+            if (sArgs.roundIdx && S.status == LCB_ST_OK) {          // a round launch: the final result is known to the commit kernel behind it
+                const uint32_t r = sArgs.roundIdx[s];
+                LcbSeedOut* q = sArgs.roundOut + r;
+                q->nInst = n; q->status = LCB_ST_OK; q->bestScore = bestScore; q->arenaOff = off; q->fpOff = fpo; q->nFp = nfp; q->poolInst = S.endInst;
+                sArgs.roundState[r] = LCB_RS_DONE;
+            }
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }
@@ -1800,7 +1674,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
 // Process() returns nothing and reads no bit as 0: its header is final here. Later rounds consist almost entirely of such
 // seeds (their neighbourhood is covered by committed blocks); the others are queued for the process kernel, and the host
 // reads the headers of the queued seeds only. One thread per seed.
-__device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
+__device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive,
+                                       const uint32_t* roundIdx, uint32_t* roundState)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     bool alive = false;
@@ -1819,6 +1694,7 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
             alive = !isUsed && (int32_t)(positive ? T.posCh[g] : T.posRevCh[g]) == sd.ch;
         }
         (void)out;      // a dead seed needs no header: the host looks at the live list only (its result is empty by definition)
+        if (!alive && roundIdx) roundState[roundIdx[s]] = LCB_RS_DEAD;     // ... and the commit kernel of a round passes over it
     }
     // compact the live seeds in seed order within the wave (heavy seeds come first in the sorted seed list)
     const unsigned long long m = __ballot(alive);
@@ -1831,30 +1707,45 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
     }
 }
 
-// ---- device-side ordered commit -----------------------------------------------------
+// ---- device-resident ordered commit ----------------------------------------------------
 // The thread-0 section of ProcessVertex::operator() (blocksfinder.h:372-414) with Finalize's MarkUsed (blocksfinder.h:312-332) for
-// the clean prefix of a round: ONE workgroup walks the round's live seeds in order, phase by phase -
-//   (a) phase start: the phase-start result of every live seed of the phase must still be exact: no bit inside its footprint has been
-//       marked since the round was launched (the marks of this round are kept in a second bitmap, `delta`);
+// the clean prefix of a round, where the results are: the kernel is chained behind every launch of a round on the launch's stream
+// (no host synchronisation in between) and walks the round's seeds in order, phase by phase, over the headers the process kernels
+// left in roundOut and the instances / footprints in the launch arenas -
+//   (0) a phase is entered once every seed of it has a final result (a seed that overflowed its kernel variant gets its result from a
+//       later launch of the round: the kernel returns and the invocation behind that launch goes on from the same phase);
+//   (a) phase start: the phase-start result of every seed of the phase must still be exact: no bit inside its footprint has been
+//       marked since the round was launched (the marks of this round are kept in a second bitmap, `delta`, and as a list of ranges
+//       through which the next round un-marks it);
 //   (b) ordered commit: a result of more than one instance whose instances touch no used position on the chromosomes committed to
 //       earlier in this phase (the weak check, blocksfinder.h:377-398) is finalised: its [Front, Back) ranges are marked in the live
 //       bitmap (and in delta) and the seed is appended to the committed list -
-// and stops at the first seed that needs a new computation (a void phase-start result, or a conflict: blocksfinder.h:406). The host
-// then assigns the block ids / BlockInstances of the committed seeds (blocksfinder.h:314-329) and goes on from the stop with its
-// planner. Validation is spread over the wavefronts of the workgroup, the commit itself is lane-parallel over instances and words.
+// and stops for good at the first seed that needs a new computation (a void phase-start result, or a conflict: blocksfinder.h:406).
+// The host reads the state words and the committed list, assigns the block ids / BlockInstances of the committed seeds
+// (blocksfinder.h:314-329), mirrors the marks in its own copy of the bitmap and goes on from the stop with its planner.
+// ONE workgroup: phases are sequential by definition (a phase's validation needs the marks of the phases before it); inside a phase
+// the validation is spread over the wavefronts (lanes = footprint intervals) and the commit is lane-parallel over instances and words.
+enum { LCB_CS_NEXT = 0,        // first seed of the next phase to commit (everything before it is committed or passed over)
+       LCB_CS_NCOMMITTED,      // entries of the committed list
+       LCB_CS_STOPKIND,        // 0 none so far, 1 a phase-start result of the phase at STOPAT is void, 2 seed STOPAT conflicts (its phase is committed up to it)
+       LCB_CS_STOPAT,
+       LCB_CS_MARKED,          // something was committed in this round
+       LCB_CS_WORDS = 8 };
 struct LcbCommitArgs {
     const uint32_t* chrStart;      // [nChr+1]
     uint32_t* used;                // the live bitmap (marked here)
-    uint32_t* delta;               // marks since the round was launched (cleared by the host before the kernel)
-    uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared by the host
-    const uint32_t* seedIdx;       // [nLive] index of the live seed in the round, ascending
-    const uint32_t* off;           // [nLive+1] into inst
-    const uint4* inst;             // (chr, front idx, back idx, strand)
-    const uint32_t* fpOff;         // [nLive+1] into fp
-    const uint2* fp;               // footprint intervals [lo, hi] over flat positions
-    uint32_t nLive, phase, nPos;   // phase: seeds per phase (256); nPos: positions of the bitmaps
-    uint32_t* committed;           // out: live indices of the committed seeds, in order
-    uint32_t* result;              // out: [0] number of committed seeds, [1] live index of the stop (nLive: none), [2] 0 none / 1 phase start / 2 conflict
+    uint32_t* delta;               // marks since the round was launched
+    uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared per round
+    const uint32_t* roundState;    // [n] LCB_RS_* per seed of the round
+    const LcbSeedOut* roundOut;    // [n] headers of the final results
+    const uint4* arena;            // (chr, front idx, back idx, strand)
+    const uint2* fpArena;          // footprint intervals [lo, hi] over flat positions
+    uint32_t n, phase, nPos;       // seeds of the round, seeds per phase (256), positions of the bitmaps
+    uint32_t* state;               // LCB_CS_* (host-visible; one thread reads and writes it)
+    uint32_t* committed;           // out (host-visible): round indices of the committed seeds, in order
+    uint2* deltaList;              // ranges marked in `delta` this round ...
+    uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete and the host clears the whole bitmap)
+    uint32_t deltaCap;
 };
 
 // any set bit of `bits` in [a, b)? (bitmap words are read past the L1: other wavefronts mark them with atomics)
@@ -1887,62 +1778,80 @@ __device__ inline void lcb_bits_set(uint32_t* bits, uint32_t a, uint32_t b)
 template <int NW>
 __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
 {
-    __shared__ uint32_t sStop[4];          // [0] void phase-start result seen, [1] first live index of the next phase
+    __shared__ uint32_t sFlag[8];          // [0] a seed of the phase has no final result yet, [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
-    uint32_t nCommitted = 0, stopAt = A.nLive, stopKind = 0;
-    bool marked = false;                   // something was committed in this round (wave-uniform, identical in every wavefront)
-    for (uint32_t lq = 0; lq < A.nLive && !stopKind;) {
-        const uint32_t ph = A.seedIdx[lq] / A.phase;
-        if (tid == 0) { sStop[0] = 0; sStop[1] = A.nLive; }
+    if (tid == 0) { sFlag[2] = A.state[LCB_CS_MARKED]; sFlag[5] = A.state[LCB_CS_NCOMMITTED]; sFlag[6] = A.state[LCB_CS_NEXT]; sFlag[7] = A.state[LCB_CS_STOPKIND]; }
+    __syncthreads();
+    uint32_t ps = sFlag[6];
+    if (sFlag[7]) return;                  // the commit of this round has stopped for good
+    bool marked = sFlag[2] != 0;           // wave-uniform, identical in every wavefront
+    uint32_t nCommitted = sFlag[5], stopKind = 0, stopAt = 0;
+    while (ps < A.n) {
+        const uint32_t pe = ps + A.phase < A.n ? ps + A.phase : A.n, ph = ps / A.phase;
+        __syncthreads();                   // (sFlag is read below the previous iteration's writes)
+        if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; sFlag[3] = 0; }
         __syncthreads();
-        // the live seeds of this phase: [lq, lqEnd)
-        for (uint32_t q = lq + 1 + tid; q < A.nLive && q <= lq + A.phase; q += nT) if (A.seedIdx[q] / A.phase != ph) { atomicMin(&sStop[1], q); break; }
+        // (0) every seed of the phase has its final result (bit 0: one has not; bit 1: one has a result, i.e. is not dead)
+        for (uint32_t q = ps + tid; q < pe; q += nT) { const uint32_t r = A.roundState[q]; if (r != LCB_RS_DEAD) atomicOr(&sFlag[0], r == LCB_RS_NONE ? 1u : 2u); }
         __syncthreads();
-        const uint32_t lqEnd = sStop[1];
+        if (sFlag[0] & 1u) break;          // a later launch of the round brings it: the next invocation goes on here
+        if (!(sFlag[0] & 2u)) { ps = pe; continue; }     // only dead seeds: nothing to validate, nothing to commit
         // (a) every phase-start result of the phase is still exact (nothing to check before the first commit of the round)
         if (marked) {
-            for (uint32_t q = lq + wave; q < lqEnd; q += NW) {
+            for (uint32_t q = ps + wave; q < pe; q += NW) {
+                if (A.roundState[q] != LCB_RS_DONE) continue;
+                const LcbSeedOut o = A.roundOut[q];
                 bool hit = false;
-                for (uint32_t k = A.fpOff[q] + lane; k < A.fpOff[q + 1]; k += 64) { const uint2 f = A.fp[k]; if (lcb_bits_any(A.delta, f.x, (f.y < A.nPos ? f.y : A.nPos - 1u) + 1u)) hit = true; }
-                if (__ballot(hit) != 0 && lane == 0) atomicOr(&sStop[0], 1u);
+                for (uint32_t k = lane; k < o.nFp; k += 64) { const uint2 f = A.fpArena[o.fpOff + k]; if (lcb_bits_any(A.delta, f.x, (f.y < A.nPos ? f.y : A.nPos - 1u) + 1u)) hit = true; }
+                if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
             }
             __syncthreads();
-            if (sStop[0]) { stopAt = lq; stopKind = 1; break; }
+            if (sFlag[1]) { stopAt = ps; stopKind = 1; break; }
         }
         // (b) ordered commit: wavefront 0, lanes over the instances of a seed
         if (wave == 0) {
-            for (uint32_t q = lq; q < lqEnd; q++) {
-                const uint32_t o0 = A.off[q], o1 = A.off[q + 1];
-                if (o1 - o0 <= 1) continue;                                              // blocksfinder.h:375
+            uint32_t kind = 0, at = 0;
+            for (uint32_t q = ps; q < pe; q++) {
+                if (A.roundState[q] != LCB_RS_DONE) continue;
+                const LcbSeedOut o = A.roundOut[q];
+                if (o.nInst <= 1) continue;                                              // blocksfinder.h:375
+                const uint4* inst = A.arena + o.arenaOff;
                 bool conflict = false;
-                for (uint32_t k = o0 + lane; k < o1; k += 64) {
-                    const uint4 in = A.inst[k];
+                for (uint32_t k = lane; k < o.nInst; k += 64) {
+                    const uint4 in = inst[k];
                     if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
                     const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
                     if (lcb_bits_any(A.used, lo, hi)) conflict = true;
                 }
-                if (__ballot(conflict) != 0) { stopAt = q; stopKind = 2; break; }
+                if (__ballot(conflict) != 0) { at = q; kind = 2; break; }
                 LCB_WAVE_SYNC();
-                for (uint32_t k = o0 + lane; k < o1; k += 64) {                          // Finalize: MarkUsed over [Front, Back)
-                    const uint4 in = A.inst[k];
+                for (uint32_t k = lane; k < o.nInst; k += 64) {                          // Finalize: MarkUsed over [Front, Back)
+                    const uint4 in = inst[k];
                     A.chrStamp[in.x] = ph + 1;
                     const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
-                    lcb_bits_set(A.used, lo, hi);
-                    lcb_bits_set(A.delta, lo, hi);
+                    if (hi > lo) {
+                        lcb_bits_set(A.used, lo, hi);
+                        lcb_bits_set(A.delta, lo, hi);
+                        const uint32_t slot = atomicAdd(A.deltaCount, 1u);
+                        if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};
+                    }
                 }
                 LCB_WAVE_SYNC();
                 if (lane == 0) A.committed[nCommitted] = q;
                 nCommitted++;
                 marked = true;
             }
-            if (lane == 0) { sStop[2] = marked ? 1u : 0u; sStop[3] = stopKind; }
+            if (lane == 0) { sFlag[2] = marked ? 1u : 0u; sFlag[3] = kind; sFlag[4] = at; sFlag[5] = nCommitted; }
         }
         __syncthreads();
-        marked = sStop[2] != 0;                                                      // what wavefront 0 did is known to all
-        if (sStop[3]) { stopKind = sStop[3]; break; }
-        lq = lqEnd;
+        marked = sFlag[2] != 0; nCommitted = sFlag[5];                               // what wavefront 0 did is known to all
+        if (sFlag[3]) { stopKind = sFlag[3]; stopAt = sFlag[4]; break; }
+        ps = pe;
     }
-    if (tid == 0) { A.result[0] = nCommitted; A.result[1] = stopAt; A.result[2] = stopKind; }
+    if (tid == 0) {
+        A.state[LCB_CS_NEXT] = ps; A.state[LCB_CS_NCOMMITTED] = nCommitted; A.state[LCB_CS_MARKED] = marked ? 1u : 0u;
+        if (stopKind) { A.state[LCB_CS_STOPKIND] = stopKind; A.state[LCB_CS_STOPAT] = stopAt; }
+    }
 }
 
 #endif

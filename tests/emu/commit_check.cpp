@@ -1,10 +1,13 @@
-// commit_check — TEST-ONLY: the device-side commit kernel body (lcb_commit_body, lcb_kernel.h) on the wavefront emulator against a
+// commit_check — TEST-ONLY: the device-resident commit kernel body (lcb_commit_body, lcb_kernel.h) on the wavefront emulator against a
 // plain sequential restatement of what it has to do (the thread-0 section of ProcessVertex::operator(), blocksfinder.h:372-414, over
 // a round's results: phase-start validation against the round's marks, weak conflict check, MarkUsed), on random rounds:
 //   commit_check [cases] [seed]
-// Random chromosomes, pre-marked bits, live seeds with 0-5 instances and footprints around them, tiny phases (so that a case has many
-// phase boundaries, conflicts inside phases and void phase-start results). Compared: the committed list, where and why it stopped,
-// the live bitmap and the per-chromosome stamps' effect (through the conflicts).
+// Random chromosomes, pre-marked bits, live seeds with 0-5 instances and footprints around them, dead seeds, tiny phases (so that a
+// case has many phase boundaries, conflicts inside phases and void phase-start results). The results of a round arrive in 1-4
+// "launches" (a random share of the seeds gets its final result only from a later one, like seeds that overflowed their kernel
+// variant) and the kernel body is invoked behind each, carrying its state from one invocation to the next; the outcome must be the
+// one of the sequential walk over the complete round. Compared: the committed list, where and why it stopped, the live bitmap, the
+// delta bitmap and the list of its ranges (every set bit of delta lies in a listed range: what the next round un-marks through).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +30,7 @@ int main(int argc, char** argv)
     std::mt19937 rng(argc > 2 ? (unsigned)atoi(argv[2]) : 12345u);
     auto rnd = [&](uint32_t n) { return n ? (uint32_t)(rng() % n) : 0u; };
     int bad = 0;
-    long commits = 0, stops1 = 0, stops2 = 0, clean = 0;
+    long commits = 0, stops1 = 0, stops2 = 0, clean = 0, waits = 0;
     for (int c = 0; c < cases; c++) {
         const uint32_t nChr = 1 + rnd(6), phase = 1u << rnd(4);                       // 1 .. 8 seeds per phase
         std::vector<uint32_t> chrStart(1, 0);
@@ -89,26 +92,57 @@ int main(int argc, char** argv)
             }
             lq = lqEnd;
         }
-        // ---- the kernel body under the emulator (2, 4 or 8 wavefronts)
-        std::vector<uint32_t> committed(nLive, 0xFFFFFFFFu);
-        uint32_t result[4] = {0, 0, 0, 0};
-        LcbCommitArgs A;
-        A.chrStart = chrStart.data(); A.used = used.data(); A.delta = delta.data(); A.chrStamp = stamp.data();
-        A.seedIdx = seedIdx.data(); A.off = off.data(); A.inst = inst.data(); A.fpOff = fpOff.data(); A.fp = fp.data();
-        A.nLive = nLive; A.phase = phase; A.nPos = nPos; A.committed = committed.data(); A.result = result;
-        const int nw = c % 3;
-        if (nw == 0) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
-        else if (nw == 1) emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
-        else emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
-        bool ok = result[0] == rCommitted.size() && result[1] == rStop && result[2] == rKind && used == rUsed && delta == rDelta;
-        for (size_t i = 0; ok && i < rCommitted.size(); i++) ok = committed[i] == rCommitted[i];
+        // ---- the kernel body under the emulator (2, 4, 8 or 16 wavefronts), behind each of 1-4 launches of the round
+        std::vector<uint32_t> committed(nRound, 0xFFFFFFFFu), state(LCB_CS_WORDS, 0u), roundState(nRound, LCB_RS_NONE);
+        std::vector<LcbSeedOut> roundOut(nRound);
+        std::vector<uint2> deltaList(64 + rnd(2000));
+        uint32_t deltaCount = 0;
+        const uint32_t nLaunch = 1 + rnd(4);
+        std::vector<uint32_t> launchOf(nRound);                  // the launch that brings a seed's final result
+        for (uint32_t i = 0; i < nRound; i++) launchOf[i] = rnd(3) == 0 ? rnd(nLaunch) : 0u;
+        std::vector<int32_t> liveOf(nRound, -1);
+        for (uint32_t q = 0; q < nLive; q++) liveOf[seedIdx[q]] = (int32_t)q;
+        const int nw = c % 4;
+        uint32_t waited = 0;
+        for (uint32_t l = 0; l < nLaunch; l++) {
+            for (uint32_t i = 0; i < nRound; i++) {
+                if (launchOf[i] != l) continue;
+                if (liveOf[i] < 0) { roundState[i] = LCB_RS_DEAD; continue; }
+                const uint32_t q = (uint32_t)liveOf[i];
+                LcbSeedOut o; memset(&o, 0, sizeof(o));
+                o.nInst = off[q + 1] - off[q]; o.arenaOff = off[q]; o.nFp = fpOff[q + 1] - fpOff[q]; o.fpOff = fpOff[q];
+                roundOut[i] = o; roundState[i] = LCB_RS_DONE;
+            }
+            LcbCommitArgs A;
+            A.chrStart = chrStart.data(); A.used = used.data(); A.delta = delta.data(); A.chrStamp = stamp.data();
+            A.roundState = roundState.data(); A.roundOut = roundOut.data(); A.arena = inst.data(); A.fpArena = fp.data();
+            A.n = nRound; A.phase = phase; A.nPos = nPos; A.state = state.data(); A.committed = committed.data();
+            A.deltaList = deltaList.data(); A.deltaCount = &deltaCount; A.deltaCap = (uint32_t)deltaList.size();
+            if (nw == 0) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
+            else if (nw == 1) emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
+            else if (nw == 2) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
+            else emu_run_block(0, 16, [&]() { lcb_commit_body<16>(A); });
+            if (l + 1 < nLaunch && !state[LCB_CS_STOPKIND] && state[LCB_CS_NEXT] < nRound) waited++;
+        }
+        // the restatement speaks of live indices, the kernel of indices in the round
+        const uint32_t kStop = state[LCB_CS_STOPKIND] ? state[LCB_CS_STOPAT] : nRound, kKind = state[LCB_CS_STOPKIND];
+        const uint32_t rStopSeed = rKind == 0 ? nRound : (rKind == 1 ? (seedIdx[rStop] / phase) * phase : seedIdx[rStop]);
+        bool ok = state[LCB_CS_NCOMMITTED] == rCommitted.size() && kStop == rStopSeed && kKind == rKind && used == rUsed && delta == rDelta;
+        if (ok && rKind == 0) ok = state[LCB_CS_NEXT] == nRound;
+        for (size_t i = 0; ok && i < rCommitted.size(); i++) ok = committed[i] == seedIdx[rCommitted[i]];
+        if (ok && deltaCount <= deltaList.size()) {              // every set bit of delta lies in a listed range
+            std::vector<uint32_t> cover(words, 0);
+            for (uint32_t r = 0; r < deltaCount; r++) setBits(cover, deltaList[r].x, deltaList[r].y);
+            ok = cover == delta;
+        }
+        waits += waited;
         if (!ok) {
             bad++;
-            if (bad <= 5) fprintf(stderr, "case %d (nLive %u, phase %u, %d waves): kernel committed %u stop %u kind %u | expected %zu stop %u kind %u | bitmap %s\n", c, nLive, phase,
-                                  nw == 0 ? 2 : (nw == 1 ? 4 : 8), result[0], result[1], result[2], rCommitted.size(), rStop, rKind, used == rUsed ? "equal" : "DIFFERENT");
+            if (bad <= 5) fprintf(stderr, "case %d (%u seeds, %u live, phase %u, %d waves, %u launches): kernel committed %u stop %u kind %u | expected %zu stop %u kind %u | bitmap %s delta %s\n", c, nRound, nLive, phase,
+                                  2 << nw, nLaunch, state[LCB_CS_NCOMMITTED], kStop, kKind, rCommitted.size(), rStopSeed, rKind, used == rUsed ? "equal" : "DIFFERENT", delta == rDelta ? "equal" : "DIFFERENT");
         }
         commits += (long)rCommitted.size(); stops1 += rKind == 1; stops2 += rKind == 2; clean += rKind == 0;
     }
-    fprintf(stderr, "commit_check: %d cases, %ld commits, %ld rounds committed completely, %ld stops at a phase start, %ld stops at a conflict, %d mismatches\n", cases, commits, clean, stops1, stops2, bad);
+    fprintf(stderr, "commit_check: %d cases, %ld commits, %ld rounds committed completely, %ld stops at a phase start, %ld stops at a conflict, %ld invocations that had to wait for a later launch, %d mismatches\n", cases, commits, clean, stops1, stops2, waits, bad);
     return bad ? 1 : 0;
 }

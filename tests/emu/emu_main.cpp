@@ -16,6 +16,7 @@
 #include <omp.h>
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -44,8 +45,6 @@ struct EmuCtx {
     std::vector<uint4> arena;
     std::vector<LcbKSeed> ks;
     std::vector<size_t> which;
-    std::vector<int32_t> sigArena;        // LCB_PATH_SIG builds: path vertices of the seeds of the last run
-    unsigned long long sigCursor = 0;
 };
 
 struct Emu {
@@ -65,7 +64,6 @@ struct Emu {
     std::vector<LcbSeedOut> out;
     std::vector<LcbSeedCtr> octr;                // per-seed counters of the last run()
     std::vector<uint4> arena;
-    std::vector<std::vector<int32_t>> osig;      // LCB_PATH_SIG builds: per seed of the last run(), sorted |id| of its path vertices
     lcb_counters ctr{};
     uint64_t launches = 0, criticalPushes = 0, totalPushes = 0, firstPushes = 0;   // sum over launches of the largest per-seed push count
 
@@ -95,7 +93,7 @@ struct Emu {
             if (getenv("EMU_PATH_CAP")) { W.pathCap = (uint32_t)atoi(getenv("EMU_PATH_CAP")); W.bodyCap = W.pathCap / 2; }   // tiny path sets: long probe chains, colliding home slots
             W.bestCap = mode == 0 ? LcbCfg<0>::IC : (mode == 1 ? LcbCfg<1>::IC : (mode == 2 ? LcbCfg<2>::IC : 8192));
             W.instCap = mode == 2 ? LcbCfg<2>::IC : (mode == 3 ? 8192 : 0); W.voteCap = mode == 3 ? 65536 : 0;
-            W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr;
+            W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr; W.roundIdx = nullptr; W.roundOut = nullptr; W.roundState = nullptr;
             LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
             c.slot.assign(L.total, 0);
             int32_t* pk = (int32_t*)(c.slot.data() + L.pKeys);
@@ -146,11 +144,6 @@ struct Emu {
         W.cursorBase = c.cursor[0];
         W.arenaBase = *W.arenaCursor;
         W.fpBase = *W.fpCursor;
-#if LCB_PATH_SIG
-        if (c.sigArena.empty()) c.sigArena.resize(1 << 20);
-        c.sigCursor = 0;
-        W.sigArena = c.sigArena.data(); W.sigCursor = &c.sigCursor; W.sigBase = 0; W.sigCap = c.sigArena.size();
-#endif
         const LcbKSeed* sp = c.ks.data();
         const uint32_t n = (uint32_t)c.ks.size();
         if (!n) return;
@@ -200,7 +193,6 @@ struct Emu {
         }
         out.assign(seeds.size(), LcbSeedOut{});
         octr.assign(seeds.size(), LcbSeedCtr{});
-        osig.assign(seeds.size(), std::vector<int32_t>());
         arena.clear(); fpArena.clear();
         uint64_t maxPush = 0;
         for (auto& c : ctx)
@@ -211,13 +203,6 @@ struct Emu {
                     arena.insert(arena.end(), c.arena.begin() + o.arenaOff, c.arena.begin() + o.arenaOff + o.nInst);
                     fpArena.insert(fpArena.end(), c.fpArena.begin() + o.fpOff, c.fpArena.begin() + o.fpOff + o.nFp);
                     o.arenaOff = ao; o.fpOff = fo;
-#if LCB_PATH_SIG
-                    if (o.nSig == 0xFFFFFFFFu) { fprintf(stderr, "emu: path signature did not fit\n"); exit(2); }
-                    std::vector<int32_t>& sg = osig[c.which[j]];
-                    for (uint32_t e = 0; e < o.nSig; e++) { const int32_t v = c.sigArena[o.sigOff + e]; sg.push_back(v < 0 ? -v : v); }
-                    std::sort(sg.begin(), sg.end());
-                    sg.erase(std::unique(sg.begin(), sg.end()), sg.end());
-#endif
                 }
                 out[c.which[j]] = o;
                 if (o.status != 0) continue;     // an overflowed attempt is re-run in a larger mode (runRetry) and counted there
@@ -240,9 +225,11 @@ struct Emu {
     // Like the product's retry chain (device.hip): seeds that overflow the LDS capacities of this mode are run again in the next
     // larger mode (small -> medium -> big), against the same `used` views.
     std::unique_ptr<Emu> next;
+    std::function<void()> afterFirstLaunch;      // (processRound: the commit kernel behind the first launch of a round)
     void runRetry(const std::vector<LcbKSeed>& seeds)
     {
         run(seeds);
+        if (afterFirstLaunch) afterFirstLaunch();
         std::vector<size_t> again;
         for (size_t i = 0; i < out.size(); i++) if (out[i].status >= LCB_ST_INST_OVF && out[i].status <= LCB_ST_BEST_OVF) again.push_back(i);
         if (again.empty() || mode >= 3) return;
@@ -262,7 +249,6 @@ struct Emu {
             }
             out[again[k]] = o;
             octr[again[k]] = next->octr[k];
-            osig[again[k]] = next->osig[k];
         }
         ctr.n_walk += next->ctr.n_walk; ctr.n_occ += next->ctr.n_occ; ctr.n_compat_call += next->ctr.n_compat_call; ctr.n_compat_step += next->ctr.n_compat_step;
         ctr.n_inst_out += next->ctr.n_inst_out; ctr.n_vote += next->ctr.n_vote; ctr.n_push += next->ctr.n_push; ctr.n_process += next->ctr.n_process;
@@ -292,10 +278,6 @@ struct EmuProcessor : LcbProcessor {
             for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
-        if (pathSink) {      // LCB_PATH_SIG builds: the path vertices the kernel reported (engine's relaxViews)
-            if (!LCB_PATH_SIG) throw LcbError("this emulator build has no path signatures (-DLCB_PATH_SIG=1)");
-            pathSink->assign(emu->osig.begin(), emu->osig.begin() + n);
-        }
         if (ctrSink) {       // stats-mode kernels: the per-seed event counters (engine's countEvents)
             ctrSink->assign((size_t)n, lcb_counters{});
             for (int64_t i = 0; i < n && !getenv("EMU_NOSTATS"); i++) {
@@ -309,12 +291,12 @@ struct EmuProcessor : LcbProcessor {
         for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
     }
     void reset() override { emu->used.assign(emu->usedWords, 0u); emu->T.used = emu->used.data(); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
-    // begin / end (the engine overlaps the next round's launch with this round's commit): the emulated launch must see the
-    // state of the moment of the begin, so the live bitmap is snapshotted there and the seeds run against the snapshot at the end
+    // begin / end (the engine plans a stop's speculative jobs while the results the stop needs are computed): the emulated launch
+    // must see the state of the moment of the begin, so the live bitmap is snapshotted there and the seeds run against the snapshot at the end
     std::vector<lcb_seed> begunSeeds; std::vector<uint32_t> begunUsed; bool begunValid = false;
-    bool processBegin(const lcb_seed* sd, int64_t n, bool anySize) override
+    bool processBegin(const lcb_seed* sd, int64_t n) override
     {
-        if (getenv("EMU_NO_OVERLAP") && !anySize) return false;
+        if (getenv("EMU_NO_EARLY")) return false;   // (the engine then computes the stop's own jobs after the dry run)
         if (begunValid) return false;               // (one call in flight, like the device)
         begunSeeds.assign(sd, sd + n);
         begunUsed.assign(emu->used.begin(), emu->used.begin() + emu->usedWords);
@@ -332,23 +314,75 @@ struct EmuProcessor : LcbProcessor {
     }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
-    // device-side commit (EMU_DEVICE_COMMIT=1): the commit kernel body of lcb_kernel.h, 4 emulated wavefronts, on the emulator's bitmap
-    std::vector<uint32_t> dcDelta, dcStamp, dcCommitted;
-    bool commitRound(const std::vector<int32_t>& live, const std::vector<uint32_t>& off, const std::vector<lcb_instance>& inst, const std::vector<uint32_t>& fpOff,
-                     const std::vector<lcb_fp>& fp, int64_t phase, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
+    // device-resident commit of a round (processRound): the commit kernel body of lcb_kernel.h on EMU_COMMIT_NW (default 4) emulated
+    // wavefronts, on the emulator's bitmap, invoked like on the device behind every "launch" of the round - once after the first launch
+    // (seeds that overflowed their kernel variant have no final result yet: the kernel must wait for them) and once after the retries
+    std::vector<uint32_t> dcDelta, dcStamp, dcCommitted, dcState, dcRound;
+    std::vector<LcbSeedOut> dcOut;
+    std::vector<uint2> dcList;
+    uint32_t dcDeltaCount = 0;
+    int64_t commitKernels = 0, commitWaited = 0;
+    bool processRound(const lcb_seed* sd, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
+                      std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
     {
-        if (!getenv("EMU_DEVICE_COMMIT") || live.empty()) return false;
+        if (getenv("EMU_HOST_COMMIT") || n <= 0) return false;
         static_assert(sizeof(lcb_instance) == sizeof(uint4) && sizeof(lcb_fp) == sizeof(uint2), "layouts the commit kernel reads");
-        dcDelta.assign(emu->usedWords, 0u); dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign(live.size(), 0u);
-        uint32_t result[4] = {0, 0, 0, 0};
-        LcbCommitArgs A;
-        A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.delta = dcDelta.data(); A.chrStamp = dcStamp.data();
-        A.seedIdx = (const uint32_t*)live.data(); A.off = off.data(); A.inst = (const uint4*)inst.data(); A.fpOff = fpOff.data(); A.fp = (const uint2*)fp.data();
-        A.nLive = (uint32_t)live.size(); A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
-        A.committed = dcCommitted.data(); A.result = result;
-        emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
-        committed.assign(dcCommitted.begin(), dcCommitted.begin() + result[0]);
-        stopAt = result[1]; stopKind = (int)result[2];
+        // the previous round's marks leave the delta bitmap through the list of their ranges, as on the device
+        if (dcDelta.size() != emu->usedWords) dcDelta.assign(emu->usedWords, 0u);
+        if (dcDeltaCount > dcList.size()) dcDelta.assign(emu->usedWords, 0u);
+        else for (uint32_t r = 0; r < dcDeltaCount; r++) for (uint32_t w = dcList[r].x >> 5; w <= (dcList[r].y - 1) >> 5; w++) dcDelta[w] = 0;
+        for (uint32_t w : dcDelta) if (w) throw LcbError("emu: the delta bitmap was not clean at the start of a round");
+        dcDeltaCount = 0;
+        dcList.assign(getenv("EMU_DELTA_CAP") ? (size_t)atoi(getenv("EMU_DELTA_CAP")) : 4096, uint2{0u, 0u});
+        dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign((size_t)n, 0u); dcState.assign(LCB_CS_WORDS, 0u);
+        dcRound.assign((size_t)n, LCB_RS_NONE); dcOut.assign((size_t)n, LcbSeedOut{});
+        const int nw = getenv("EMU_COMMIT_NW") ? atoi(getenv("EMU_COMMIT_NW")) : 4;
+        // EMU_COMMIT_HOLD=k: the result of every k-th seed stays hidden from the commit kernel behind the first launch, as if the seed
+        // had overflowed its kernel variant and got its result from a later launch of the round (the goldens have no such seeds)
+        const int hold = getenv("EMU_COMMIT_HOLD") ? atoi(getenv("EMU_COMMIT_HOLD")) : 0;
+        bool first = true;
+        auto commitKernel = [&]() {
+            // what the process (and screening) kernels of a round launch leave on the device: headers of final results, dead seeds
+            for (int64_t i = 0; i < n; i++) {
+                const LcbSeedOut& o = emu->out[(size_t)i];
+                if (o.status != 0 || dcRound[(size_t)i] != LCB_RS_NONE) continue;
+                if (first && hold > 0 && (i % hold) == hold - 1) continue;
+                dcOut[(size_t)i] = o;
+                dcRound[(size_t)i] = (o.nInst == 0 && o.nFp == 0) ? LCB_RS_DEAD : LCB_RS_DONE;
+            }
+            LcbCommitArgs A;
+            A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.delta = dcDelta.data(); A.chrStamp = dcStamp.data();
+            A.roundState = dcRound.data(); A.roundOut = dcOut.data(); A.arena = emu->arena.data(); A.fpArena = emu->fpArena.data();
+            A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
+            A.state = dcState.data(); A.committed = dcCommitted.data(); A.deltaList = dcList.data(); A.deltaCount = &dcDeltaCount; A.deltaCap = (uint32_t)dcList.size();
+            const uint32_t before = dcState[LCB_CS_NEXT];
+            if (nw == 16) emu_run_block(0, 16, [&]() { lcb_commit_body<16>(A); });
+            else if (nw == 8) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
+            else if (nw == 2) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
+            else emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
+            commitKernels++;
+            if (!dcState[LCB_CS_STOPKIND] && dcState[LCB_CS_NEXT] < (uint32_t)n) commitWaited++;
+            (void)before;
+            first = false;
+        };
+        std::vector<LcbKSeed> ks;
+        for (int64_t i = 0; i < n; i++) ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, 0u, 0u});
+        emu->afterFirstLaunch = commitKernel;
+        try { emu->runRetry(ks); } catch (...) { emu->afterFirstLaunch = nullptr; throw; }
+        emu->afterFirstLaunch = nullptr;
+        commitKernel();                            // behind the last launch: every seed has its final result
+        off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
+        for (int64_t i = 0; i < n; i++) {
+            const LcbSeedOut& o = emu->out[(size_t)i];
+            if (o.status) throw LcbError("emulated kernel overflow");
+            off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
+            for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
+            for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
+        }
+        off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
+        committed.assign(dcCommitted.begin(), dcCommitted.begin() + dcState[LCB_CS_NCOMMITTED]);
+        stopKind = (int)dcState[LCB_CS_STOPKIND]; stopAt = dcState[LCB_CS_STOPAT];
+        if (stopKind == 0 && dcState[LCB_CS_NEXT] < (uint32_t)n) throw LcbError("emu: the commit kernel behind the last launch of a round did not reach its end");
         return true;
     }
     // side lanes (EMU_SIDE_LANES=n): a background batch is computed on the spot and handed out job by job, EMU_SIDE_DELAY polls late
@@ -490,18 +524,6 @@ int main(int argc, char** argv)
                     for (uint8_t* u : flipped) *u = 0;
                     if (compareSeed((int64_t)i, seeds[i], o, emu.arena.data(), ref.data(), n2, score2)) { fprintf(stderr, "FAIL: the footprint of seed %zu does not cover what it read (%zu positions outside it were set)\n", i, flipped.size()); bad++; }
                 }
-#if LCB_PATH_SIG
-                {   // the kernel's path signature against the oracle's list of every vertex that was ever part of the path
-                    static orc_worker* wk = orc_worker_new(og, &op);
-                    int64_t sc2 = 0, nfp2 = 0;
-                    orc_worker_process(wk, seeds[i].vid, seeds[i].ch, ref.data(), (int64_t)ref.size(), &sc2, nullptr, nullptr, 0, &nfp2);
-                    std::vector<int64_t> pv((size_t)orc_worker_path_vertices(wk, nullptr, 0));
-                    orc_worker_path_vertices(wk, pv.data(), (int64_t)pv.size());
-                    std::vector<int32_t> want(pv.begin(), pv.end());
-                    std::sort(want.begin(), want.end()); want.erase(std::unique(want.begin(), want.end()), want.end());
-                    if (want != emu.osig[i]) { fprintf(stderr, "FAIL: seed %zu: path signature of %zu vertices, the oracle's path had %zu\n", i, emu.osig[i].size(), want.size()); bad++; }
-                }
-#endif
                 {
                     static orc_counters prev; static int shown = 0;
                     const uint64_t dc = octr.n_compat_call - prev.n_compat_call, ds = octr.n_compat_step - prev.n_compat_step;
@@ -542,11 +564,8 @@ int main(int argc, char** argv)
                 cfg.roundFixed = envInt("LCB_ROUND_FIXED") != 0; cfg.maxJobs = envInt("LCB_MAX_JOBS");
                 if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F"));
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
-                cfg.overlap = !getenv("EMU_NO_OVERLAP");    // the early launch of the next round (off by default in the product) is exercised here
-                cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls
-                cfg.relaxViews = getenv("EMU_RELAX") != nullptr;   // needs the -DLCB_PATH_SIG=1 build
-                cfg.deviceCommit = getenv("EMU_DEVICE_COMMIT") != nullptr;   // the commit kernel body under the emulator (needs EMU_NO_OVERLAP, EMU_NOSTATS)
-                cfg.earlyCritical = getenv("EMU_EARLY_CRITICAL") != nullptr; // the stop's own jobs begun before the dry run (needs side lanes, EMU_NO_OVERLAP, EMU_NOSTATS)
+                cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls (host commit only)
+                cfg.hostCommit = getenv("EMU_HOST_COMMIT") != nullptr;       // default: the commit kernel body under the emulator commits the clean prefix of every round
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -557,11 +576,10 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
-                fprintf(stderr, "       early rounds %lld | device-side commit: %lld results, %lld whole rounds | side lanes: %lld batches, %lld jobs, %lld taken\n", (long long)es.earlyRounds,
-                        (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken);
-                fprintf(stderr, "       early critical launches %lld\n", (long long)es.earlyCritical);
-                if (getenv("EMU_EARLY_CRITICAL") && es.recomputeLaunches > 0 && es.earlyCritical == 0) { fprintf(stderr, "early critical launches asked for but none happened\n"); return 1; }
-                if (getenv("EMU_DEVICE_COMMIT") && es.rounds > 1 && es.blocksFound > 0 && es.deviceCommits == 0) { fprintf(stderr, "device-side commit asked for but nothing was committed there\n"); return 1; }
+                fprintf(stderr, "       device-resident commit: %lld results, %lld whole rounds, %lld kernels (%lld waited for a later launch) | side lanes: %lld batches, %lld jobs, %lld taken | early critical launches %lld\n",
+                        (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)proc.commitKernels, (long long)proc.commitWaited, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.earlyCritical);
+                if (getenv("EMU_EXPECT_EARLY") && es.recomputeLaunches > 0 && es.earlyCritical == 0) { fprintf(stderr, "early critical launches expected but none happened\n"); return 1; }
+                if (getenv("EMU_EXPECT_DEVICE_COMMIT") && es.rounds > 1 && es.blocksFound > 0 && es.deviceCommits == 0) { fprintf(stderr, "device-resident commit expected but nothing was committed there\n"); return 1; }
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);

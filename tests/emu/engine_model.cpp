@@ -80,13 +80,13 @@ struct OracleProc : LcbProcessor {
         return 1;
     }
     void sideRelease(int lane) override { lanes[(size_t)lane].busy = false; }
-    // the engine's early critical launch (MODEL_EARLY=1): computed at the begin (nothing changes the state before the end), handed out at the end
+    // the engine's early critical launch (with side lanes; MODEL_NO_EARLY=1 refuses it): computed at the begin (nothing changes the state before the end), handed out at the end
     bool begun = false;
     int64_t bReady = 0;
     std::vector<uint64_t> bOff, bFpOff; std::vector<lcb_instance> bInst; std::vector<lcb_fp> bFp;
-    bool processBegin(const lcb_seed* seeds, int64_t n, bool anySize) override
+    bool processBegin(const lcb_seed* seeds, int64_t n) override
     {
-        if (!anySize || begun) return false;
+        if (begun || getenv("MODEL_NO_EARLY")) return false;
         const int64_t t0 = now;
         process(seeds, nullptr, n, bOff, bInst, bFpOff, bFp);
         bReady = now; now = t0;                 // on the virtual clock the launch runs beside whatever the engine does until the end
@@ -119,7 +119,6 @@ struct OracleProc : LcbProcessor {
         std::vector<std::vector<lcb_instance>> ri((size_t)n);
         std::vector<std::vector<lcb_fp>> rf((size_t)n);
         std::vector<int64_t> pushes((size_t)n, 0), pool((size_t)n, 0);
-        if (pathSink) pathSink->assign((size_t)n, std::vector<int32_t>());
         const int64_t chunk = 16;
         const int64_t nChunks = (n + chunk - 1) / chunk;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
@@ -150,14 +149,6 @@ struct OracleProc : LcbProcessor {
                     rf[(size_t)i][(size_t)e] = lcb_fp{lo ? lo - 1 : 0u, hi};      // the - strand reads bit g-1
                 }
                 pushes[(size_t)i] = (int64_t)c.n_push; pool[(size_t)i] = nfp;
-                if (pathSink) {
-                    std::vector<int64_t> pvb((size_t)orc_worker_path_vertices(ow[(size_t)t], nullptr, 0));
-                    orc_worker_path_vertices(ow[(size_t)t], pvb.data(), (int64_t)pvb.size());
-                    std::vector<int32_t>& pv = (*pathSink)[(size_t)i];
-                    pv.assign(pvb.begin(), pvb.end());
-                    std::sort(pv.begin(), pv.end());
-                    pv.erase(std::unique(pv.begin(), pv.end()), pv.end());
-                }
             }
             for (uint8_t* u : undo) *u = 0;
         }
@@ -246,8 +237,6 @@ int main(int argc, char** argv)
         if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F", 0));
         if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
         cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
-        cfg.relaxViews = envInt("MODEL_RELAX", 0) != 0;
-        cfg.earlyCritical = envInt("MODEL_EARLY", 0) != 0;
         std::vector<lcb_block> blocks;
         LcbEngineStats es;
         const auto t0 = std::chrono::steady_clock::now();
@@ -271,8 +260,10 @@ int main(int argc, char** argv)
         fprintf(stderr, "model: %zu seeds, %zu blocks, failures %lld, rounds %lld, job launches %lld (%lld jobs, %lld used), conflict launches %lld, over-predicted %lld, %.1f s\n",
                 seeds.size(), blocks.size(), (long long)es.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds, (long long)es.jobsUsed,
                 (long long)es.conflictLaunches, (long long)es.overPredicted, sec);
-        if (cfg.earlyCritical) fprintf(stderr, "model: early critical launches %lld of %lld stops\n", (long long)es.earlyCritical, (long long)es.recomputeLaunches);
+        if (es.earlyCritical) fprintf(stderr, "model: early critical launches %lld of %lld stops\n", (long long)es.earlyCritical, (long long)es.recomputeLaunches);
         fprintf(stderr, "model: host ms: engine %.0f = processor %.0f + dry runs %.0f + commit / validation / other %.0f\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs);
+        fprintf(stderr, "model:   of the rest: round setup %.0f, validation %.0f, commit %.0f, marks to the processor %.0f, mirror of device commits %.0f\n", es.sectionMs[LCB_SEC_SETUP],
+                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_MIRROR]);
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
                 (tRound + tJobs + tBig) / 1000);

@@ -7,14 +7,14 @@ Each case runs `find` with the shipped (non-stats) kernel instantiation and rand
 views, F prediction, job cap), `seeds-init` / `seeds-final` with the footprint-completeness check (EMU_FP_CHECK: every unused position
 outside a seed's footprint is set to used and the oracle must still reproduce the result), `seeds-init` with event counters, and one
 multi-wavefront variant (wide or big mode
-with helper wavefronts) on the heaviest seeds, and `find` once more with the round-3 engine features (side lanes with random delays,
-late batches and refused batches, the early critical launch, the device-side commit kernel body). Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
+with helper wavefronts) on the heaviest seeds, and `find` once more with the engine's asynchronous features (side lanes with random delays,
+late batches and refused batches, the early critical launch, the device-resident commit kernel body with results that arrive late). Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
 cases inside the CPU suite; the open-ended campaign is this script.
 """
 import os, random, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BIN = ROOT + "/sibeliaz_amd/bin"
-EMU = os.environ.get("LCB_FUZZ_EMU") or ROOT + "/tests/emu/build/emu_check"      # (another build of the harness, e.g. build/emu_check_ahead)
+EMU = os.environ.get("LCB_FUZZ_EMU") or ROOT + "/tests/emu/build/emu_check"      # (another build of the harness)
 
 
 def case_params(i, small=False):
@@ -37,14 +37,19 @@ def case_params(i, small=False):
             ("seeds-init", {}),
             rnd.choice([("medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}),
                         ("medium", {"EMU_NW": "8", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "4", "EMU_LIMIT": "150"})])]
-    # round 3: the engine's asynchronous job batches (eager / late stand-ins, delayed visibility, refused batches), the early critical
-    # launch and the device-side commit kernel body (drawn after everything else: earlier cases keep their runs)
-    env3 = {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_SIDE_LANES": rnd.choice(["1", "2", "4"]),
+    # the engine's asynchronous job batches (eager / late stand-ins, delayed visibility, refused batches) with the early critical launch
+    # (or a processor that refuses it), and the device-resident commit kernel body behind every launch of a round - or the host-only
+    # commit - with results that arrive from later launches of their round (drawn after everything else: earlier cases keep their runs)
+    env3 = {"EMU_NOSTATS": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_SIDE_LANES": rnd.choice(["1", "2", "4"]),
             "EMU_SIDE_DELAY": rnd.choice(["0", "1", "3", "1000"]), "EMU_CONCURRENCY": rnd.choice(["4", "64", "16384"])}
     if rnd.random() < 0.5: env3["EMU_SIDE_LATE"] = "1"
-    if rnd.random() < 0.6: env3["EMU_EARLY_CRITICAL"] = "1"
+    if rnd.random() >= 0.6: env3["EMU_NO_EARLY"] = "1"
     if rnd.random() < 0.3: env3["EMU_SIDE_CAP"] = rnd.choice(["8", "50"])
-    if rnd.random() < 0.4: env3["EMU_DEVICE_COMMIT"] = "1"
+    if rnd.random() >= 0.4: env3["EMU_HOST_COMMIT"] = "1"
+    else:
+        env3["EMU_COMMIT_NW"] = rnd.choice(["2", "4", "8", "16"])
+        if rnd.random() < 0.6: env3["EMU_COMMIT_HOLD"] = rnd.choice(["3", "17", "200"])
+        if rnd.random() < 0.3: env3["EMU_DELTA_CAP"] = rnd.choice(["1", "7"])
     runs.append(("find", env3))
     return synth, (k, b, m, a), runs, (strains, segs)
 

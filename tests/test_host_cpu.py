@@ -34,14 +34,16 @@ def test_ctypes_structs_have_the_layout_of_the_header(built, tmp_path):
     from sibeliaz_amd import api
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lcb.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lcb_stats), sizeof(lcb_hooks), '
-                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, early_critical), offsetof(lcb_hooks, early_critical), '
-                   'offsetof(lcb_device_opts, stream_priority)); return 0; }\n')
+                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, kernel_side_ms), offsetof(lcb_hooks, host_commit), '
+                   'offsetof(lcb_device_opts, side_lanes)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     want = [C.sizeof(api.Stats), C.sizeof(api.Hooks), C.sizeof(api.DeviceOpts), sibeliaz_amd.SEED_DTYPE.itemsize, sibeliaz_amd.BLOCK_DTYPE.itemsize,
-            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.early_critical.offset, api.Hooks.early_critical.offset, api.DeviceOpts.stream_priority.offset]
+            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.kernel_side_ms.offset, api.Hooks.host_commit.offset, api.DeviceOpts.side_lanes.offset]
     assert got == want
+    header = open(os.path.join(ROOT, "include", "lcb.h")).read()
+    assert int(re.search(r"#define LCB_ABI_VERSION (\d+)", header).group(1)) == api.ABI_VERSION == sibeliaz_amd.load_library().lcb_abi_version()
 
 
 def test_device_fails_loudly_without_gpu(built, case):
@@ -147,8 +149,6 @@ def test_cli_usage_errors(built, case, tmp_path):
 
 EMU = os.path.join(ROOT, "tests", "emu", "build", "emu_check")
 EMU_SHARE = os.path.join(ROOT, "tests", "emu", "build", "emu_check_share8")   # tiny LCB_VOTE_SHARE_MIN: all-waves reduce/clear path
-EMU_SIG = os.path.join(ROOT, "tests", "emu", "build", "emu_check_sig")        # -DLCB_PATH_SIG=1: path signatures for the engine's relaxViews rule
-EMU_AHEAD = os.path.join(ROOT, "tests", "emu", "build", "emu_check_ahead")    # -DLCB_PUSH_AHEAD=1: the compact variant's pushes as a software pipeline
 
 
 @pytest.fixture(scope="session")
@@ -159,7 +159,7 @@ def emu_built():
 
 @pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
-                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NO_OVERLAP": "1"}),     # without the early launch of the next round
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_HOST_COMMIT": "1"}),     # the shipped kernels, ordered commit on the host only
                                             # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
                                             ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1500"}),
                                             # every kernel variant: wide (LDS path set), big (index in LDS, fields in the workspace), huge (all in the workspace)
@@ -176,10 +176,6 @@ def emu_built():
                                             # predicted `used` views spanning many copy-on-write pages (the EMU_SHARE build has 128-position pages)
                                             ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64"}),
-                                            # round-3 candidate (-DLCB_PATH_SIG=1): the kernels report the path's vertices (checked against the oracle's
-                                            # list seed by seed), the engine's relaxViews rule uses them
-                                            ("twogenomes", "seeds-init", {"EMU_LIMIT": "400", "EMU_SIG": "1"}), ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SIG": "1"}),
-                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_SIG": "1", "EMU_RELAX": "1"}),
                                             # footprint completeness (EMU_FP_CHECK): every unused position outside a seed's footprint set to used -> same result
                                             ("nruns_abund", "seeds-init", {"EMU_NOSTATS": "1", "EMU_LIMIT": "700", "EMU_FP_CHECK": "1"}),
                                             ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150", "EMU_FP_CHECK": "1"}),
@@ -190,22 +186,23 @@ def emu_built():
                                             ("tandem4", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "LCB_MAX_JOBS": "16", "EMU_SIDE_DELAY": "2"}),
                                             ("twogenomes", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
                                             ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1"}),
-                                            # device-side ordered commit: the commit kernel body of lcb_kernel.h under the emulator (4 wavefronts) validates,
-                                            # conflict-checks and marks the clean prefix of every round; the host mirrors it and takes over at the stop
-                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1"}),
-                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
-                                            ("collinear6", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1"}),
-                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_DEVICE_COMMIT": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1"}),
-                                            # early critical launch (lcb_hooks.early_critical): the stop's own jobs are begun before the dry run that plans the
-                                            # rest; with a lane for the rest, with batches the lanes refuse (the rest then runs synchronously behind the early jobs)
-                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2"}),
-                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4"}),
-                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_OVERLAP": "1", "EMU_EARLY_CRITICAL": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
-                                            # round-3 candidate (-DLCB_PUSH_AHEAD=1): the compact variant requests what the next two pushes need ahead of them;
-                                            # counters, footprints, a small path set (colliding home slots: the stale-key guard), the engine
-                                            ("collinear6", "seeds-init", {"EMU_LIMIT": "600", "EMU_AHEAD": "1"}), ("nruns_abund", "seeds-final", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1000", "EMU_FP_CHECK": "1", "EMU_AHEAD": "1"}),
-                                            ("collinear6", "seeds-init", {"EMU_NOSTATS": "1", "EMU_LIMIT": "800", "EMU_PATH_CAP": "4096", "EMU_AHEAD": "1"}),
-                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_AHEAD": "1"}),
+                                            # device-resident ordered commit (the default whenever the engine does not count events): the commit kernel body
+                                            # of lcb_kernel.h under the emulator (2 / 4 / 8 / 16 wavefronts) behind every launch of a round - validates, conflict-checks and
+                                            # marks the clean prefix; EMU_COMMIT_HOLD hides every k-th result from the kernel behind the first launch (a seed that got its
+                                            # result from a later launch of the round: the kernel waits at its phase and the next invocation goes on there);
+                                            # EMU_DELTA_CAP: a list of the round's marked ranges so short that it overflows (whole-bitmap clear before the next round)
+                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1"}),
+                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "EMU_COMMIT_NW": "16"}),
+                                            ("collinear6", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1", "EMU_SHARE": "1", "EMU_DELTA_CAP": "3", "EMU_COMMIT_NW": "2"}),
+                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "EMU_COMMIT_HOLD": "97", "EMU_COMMIT_NW": "8"}),
+                                            ("twogenomes", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_COMMIT_HOLD": "5", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
+                                            # early critical launch (always with side lanes): the stop's own jobs are begun before the dry run that plans the rest;
+                                            # with a lane for the rest, with batches the lanes refuse (the rest then runs synchronously behind the early jobs), and
+                                            # with a processor that refuses the early launch (EMU_NO_EARLY: the stop's own jobs run after the dry run)
+                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "EMU_HOST_COMMIT": "1"}),
+                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4"}),
+                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
+                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
@@ -214,10 +211,7 @@ def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
     from tests.conftest import Case
     c = Case(name, case_dir)
-    exe = EMU_SHARE if env.get("EMU_SHARE") else (EMU_SIG if env.get("EMU_SIG") else emu_built)
-    if env.get("EMU_AHEAD"):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/emu_check_ahead"])
-        exe = EMU_AHEAD
+    exe = EMU_SHARE if env.get("EMU_SHARE") else emu_built
     r = subprocess.run([exe, c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), mode, str(tmp_path / "emu")], capture_output=True, text=True,
                        env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -226,22 +220,20 @@ def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode
 
 
 @pytest.mark.parametrize("name", ["nruns_abund", "inv_k25", "collinear6"])
-@pytest.mark.parametrize("relax", ["0", "1"])
-def test_engine_model_reproduces_the_oracle(built, case_dir, name, relax):
+def test_engine_model_reproduces_the_oracle(built, case_dir, name):
     """tests/emu/engine_model: the product's round engine driven by the CPU oracle (with the oracle's own footprints) instead of
     the device - the tool that prices engine policies at sizes the emulator cannot reach. It must reproduce the oracle's
-    FindBlocks exactly, also with the experimental relaxed view rule (LcbEngineConfig::relaxViews: a predicted mark that did not
-    come true voids a job's result only if the job can have read it)."""
+    FindBlocks exactly."""
     from tests.conftest import Case
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/engine_model"])
     c = Case(name, case_dir)
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "engine_model"), c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a)],
-                       capture_output=True, text=True, env=dict(os.environ, MODEL_RELAX=relax, MODEL_THREADS="2"))
+                       capture_output=True, text=True, env=dict(os.environ, MODEL_THREADS="2"))
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
 
 
-@pytest.mark.parametrize("env", [{}, {"LCB_MAX_JOBS": "64", "LCB_EAGER_PHASES": "2"}, {"MODEL_RELAX": "1", "LCB_PREDICT_F": "2"},
-                                 {"MODEL_SIDE_LANES": "2", "MODEL_EARLY": "1"}])      # asynchronous job batches on a virtual clock + the early critical launch
+@pytest.mark.parametrize("env", [{}, {"LCB_MAX_JOBS": "64", "LCB_EAGER_PHASES": "2"}, {"LCB_PREDICT_F": "2"},
+                                 {"MODEL_SIDE_LANES": "2"}])      # asynchronous job batches on a virtual clock + the early critical launch
 def test_engine_model_at_scale(built, tmp_path_factory, env):
     """The round engine over 176 000 seeds (config 2 at a tenth of the segments: the emulator cannot reach this size) with the
     oracle as the processor: rounds that grow to 256 phases, hundreds of job launches against predicted views, all with the
@@ -264,8 +256,10 @@ def test_engine_model_at_scale(built, tmp_path_factory, env):
 
 
 def test_device_commit_kernel_on_random_rounds(built):
-    """lcb_commit_body (the device-side ordered commit) on the wavefront emulator with 2 / 4 / 8 wavefronts against a plain
-    sequential restatement of blocksfinder.h:372-414 over random rounds: committed list, stop position and kind, the live bitmap."""
+    """lcb_commit_body (the device-resident ordered commit) on the wavefront emulator with 2 / 4 / 8 / 16 wavefronts against a
+    plain sequential restatement of blocksfinder.h:372-414 over random rounds whose results arrive in several launches (the kernel body is
+    invoked behind each and carries its state on): committed list, stop position and kind, the live bitmap, the delta bitmap and the list
+    of its ranges."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/commit_check"])
     for seed in ("1", "2026"):
         r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "commit_check"), "300", seed], capture_output=True, text=True)
