@@ -40,3 +40,17 @@ allp = sorted((d for v in seeds.values() for d in v), key=lambda d: -d["ticks"])
 for d in allp: print("   seed st=%d ticks=%.1f ms push=%d vote=%d inst=%d" % (d["st"], d["ticks"] / 1e5, d["push"], d["vote"], d["inst"]))
 PY
 grep -v "^#seed" $O/trace.tsv > $O/launch_trace.tsv; rm -f $O/trace.tsv
+# the flight-recorder sites (LCB_MARK) compiled out: what they cost
+run() {
+  local v=$1; shift
+  timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-roofline "$@" > $O/$v.json 2> $O/$v.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("$O/$v.json")); c = d["config"]
+    print("$v: %.0f seeds/s, %.1f ms, kernel(sum) %.1f ms, launches %s stops %s jobs %s host %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"]["launches_per_step"], c["job_launches"], c["jobs"], c["host_ms_per_step"]))
+except Exception as e:
+    print("$v: FAILED", e); print(open("$O/$v.err").read()[-800:])
+PY
+}
+for w in ecoli62 mice16_test; do LCB_LIB=$PWD/sibeliaz_amd/libsibeliaz_amd_nomark.so run nomark_$w --workload $w; run stock_$w --workload $w; done

@@ -50,7 +50,9 @@
 #endif
 // The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
 // when the recorder is off. The recorder is what localises a hang on the device (host watchdog, device.hip).
+#ifndef LCB_FLIGHT_RECORDER
 #define LCB_FLIGHT_RECORDER 1
+#endif
 
 // Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
