@@ -76,10 +76,20 @@ WORKLOADS = {
     "mice16_test": dict(synth="--strains 16 --chromosomes 20 --segments 120 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.005 "
                               "--indel 0.0005 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1004",
                         k=25, b=200, m=50, a=150, desc="16 synthetic strains x 20 chromosomes (217 Mbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 5 at test size]"),
+    # bounded samples of the two k = 25 shapes for the -t 1 leg of the CPU baseline (a quarter of the segments)
+    "primates8_tiny": dict(synth="--strains 8 --chromosomes 24 --segments 60 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "
+                                 "--indel 0.001 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1003",
+                           k=25, b=200, m=50, a=150, desc="8 synthetic strains x 24 chromosomes (config 4 shape with 1/4 of the test size's segments), k=25, b=200, m=50, a=150"),
+    "mice16_tiny": dict(synth="--strains 16 --chromosomes 20 --segments 30 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.005 "
+                              "--indel 0.0005 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1004",
+                        k=25, b=200, m=50, a=150, desc="16 synthetic strains x 20 chromosomes (config 5 shape with 1/4 of the test size's segments), k=25, b=200, m=50, a=150"),
     # same genomes as config 2, other parameters (k=25, b=400, m=100)
     "ecoli10_k25": _wl(10, 1200, 1001, "10 synthetic E. coli-like strains (45 Mbp), k=25, b=400, m=100, a=150", k=25, b=400, m=100),
 }
-SAMPLES = {"ecoli62": ("ecoli62_small", "ecoli62_tiny"), "ecoli10": ("ecoli10", "ecoli10_small"), "ecoli10_k25": ("ecoli10_k25", "ecoli10_small")}
+SAMPLES = {"ecoli62": ("ecoli62_small", "ecoli62_tiny"), "ecoli10": ("ecoli10", "ecoli10_small"), "ecoli10_k25": ("ecoli10_k25", "ecoli10_small"),
+           # the k = 25 shapes (configs 4 / 5 at test size): the reference needs seconds for them, so the "sample" of the -t 32 / -t 64 / all-threads legs
+           # is the workload itself
+           "primates8_test": ("primates8_test", "primates8_tiny"), "mice16_test": ("mice16_test", "mice16_tiny")}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
@@ -338,19 +348,21 @@ def main():
     sync()
     t0 = time.time()
     last = None
-    kernel_ms, launches, process_ms, plan_ms = 0.0, 0, 0.0, 0.0
+    kernel_ms, kernel_busy_ms, kernel_side_ms, launches, process_ms, plan_ms = 0.0, 0.0, 0.0, 0, 0.0, 0.0
     for _ in range(args.steps):
         last = step()
         kernel_ms += last[1]["kernel_ms"]    # the native engine reports (and resets) this rank's hipEvent totals per call
+        kernel_busy_ms += last[1].get("kernel_busy_ms", 0.0) or last[1]["kernel_ms"]   # union of the kernels' intervals over all streams
+        kernel_side_ms += last[1].get("kernel_side_ms", 0.0)
         launches += last[1]["launches"]
         process_ms += last[1]["process_ms"]
         plan_ms += last[1]["plan_ms"]
     sync()
     elapsed = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed, kernel_ms, float(launches)], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tmax = torch.tensor([elapsed, kernel_ms, float(launches), kernel_busy_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, launches = float(tmax[0].item()), float(tmax[1].item()), int(tmax[2].item())
+        elapsed, kernel_ms, launches, kernel_busy_ms = float(tmax[0].item()), float(tmax[1].item()), int(tmax[2].item()), float(tmax[3].item())
 
     if rank == 0:
         blocks, st = last
@@ -373,9 +385,14 @@ def main():
             # the counts are a property of (input, parameters): the ones of the named workloads are kept in bench_event_counts.json
             # (counted by `bench.py --recount` on the MI355X) so that a default run need not repeat the 3-minute counting pass
             known = json.load(open(os.path.join(ROOT, "bench_event_counts.json"))).get(args.workload) if os.path.exists(os.path.join(ROOT, "bench_event_counts.json")) else None
+            counts_src = None
             # (--verify-counts counts them again when other sources than the ones of this build counted them)
             if known and not args.recount and known["lcb_synth"] == w["synth"] and known["seeds"] == S and (known.get("source_hash") == source_hash() or not args.verify_counts):
                 ctr = known["event_counts"]
+                # the counts are a property of (input, parameters), pinned to the CPU oracle at full size; whether the sources of this build are the
+                # ones that last re-counted them on the device is reported, not required
+                counts_src = {"file": "bench_event_counts.json", "counted_by": known.get("source", ""), "source_hash_of_that_build": known.get("source_hash"),
+                              "source_hash_of_this_build": source_hash(), "same_sources": known.get("source_hash") == source_hash()}
             elif os.path.exists(ctr_file) and not args.recount:
                 ctr = json.load(open(ctr_file))
             else:
@@ -393,7 +410,7 @@ def main():
                 dev.kernel_time()
                 log("bench: stats-mode pass %.1fs: %s" % (time.time() - t, ctr))
         abytes = algorithmic_bytes(ctr) if ctr else 0
-        kernel_s_per_step = kernel_ms / 1000.0 / args.steps
+        kernel_s_per_step = kernel_busy_ms / 1000.0 / args.steps     # GPU time = the union of the kernels' intervals (never more than the step)
         lps = launches / float(args.steps)
         achieved = abytes / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
         triad = dev.hbm_triad() if dev is not None else 0.0
@@ -428,14 +445,16 @@ def main():
                          "traffic_profiled": {"hbm_bytes_per_launch": traffic, "source": traffic_src} if traffic else None,
                          "kernel": "lcb_process_kernel (all variants)", "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": abytes / max(1.0, lps), "avg_launch_ms": kernel_ms / max(1, launches),
-                         "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_ms / args.steps, "bytes_per_seed": abytes / S,
+                         "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_busy_ms / args.steps, "bytes_per_seed": abytes / S,
+                         "kernel_ms_sum_over_streams_per_step": kernel_ms / args.steps, "kernel_ms_on_side_lanes_per_step": kernel_side_ms / args.steps,
+                         "event_counts_source": counts_src if not args.no_roofline else None,
                          "peak_measured_stream_triad": triad, "frac_of_measured_peak": achieved / triad if triad > 0 else None,
                          "event_counts": ctr,
                          "note": "latency-bound integer walk: a launch is as long as its longest seed; the event counts of the named workloads are the CPU oracle's at full size "
                                  "(bench_event_counts.json; a stats-mode pass of the device reproduces them, n_compat_call / n_compat_step as upper bounds within 0.02%: "
-                                 "speculative results walk older bitmaps). kernel_ms_per_step is the SUM of the hipEvent-timed durations of every "
-                                 "process-kernel launch on every stream: the background (side-lane) kernels overlap the synchronous ones, so the sum can exceed the time the "
-                                 "GPU was busy and even ms_per_step - it is what a rocprofv3 --stats table of the same command sums to"},
+                                 "speculative results walk older bitmaps). achieved = algorithmic bytes / kernel_ms_per_step, and kernel_ms_per_step is the UNION of the "
+                                 "hipEvent-timed intervals of every process-kernel launch on every stream (the time the GPU was busy with them: the side-lane kernels run "
+                                 "beside the synchronous ones); kernel_ms_sum_over_streams_per_step is their plain sum - what a rocprofv3 --stats table of the same command sums to"},
         }
         if dev is not None:
             dev.close()

@@ -393,6 +393,7 @@ struct lcb_device_impl {
             A.roundState = rc.dState; A.roundOut = rc.dOut; A.arena = hArena; A.fpArena = hFp;
             A.n = rc.n; A.phase = rc.phase; A.nPos = T.nPos;
             A.state = rc.hState; A.committed = rc.hCommitted; A.deltaList = rc.dDeltaList; A.deltaCount = rc.dDeltaCount; A.deltaCap = rc.deltaCap;
+            A.pageShift = 10; while ((T.nPos >> A.pageShift) >= LCB_COMMIT_PAGES) A.pageShift++;
             hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, stream, A);
             HIP_CHECK(hipGetLastError());
             rc.kernels++;

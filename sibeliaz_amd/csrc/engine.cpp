@@ -41,14 +41,54 @@
 
 namespace {
 
-// Disjoint, sorted position ranges [lo, hi).
+// Disjoint, sorted position ranges [lo, hi), behind a coarse bitmap: bit q of `page` is set iff a range touches the positions
+// [q << shift, (q + 1) << shift). Almost every question the engine asks ("does a mark of this epoch lie inside this footprint
+// interval?") is answered "no" by two or three words of that bitmap without a search in the ranges - the validation loops and the
+// dry runs ask it hundreds of millions of times per pass.
+thread_local int g_pageShift = 12;          // set per engine run from the number of positions (at most 2^16 pages)
 struct RangeSet {
     std::vector<std::pair<uint64_t, uint64_t>> r;
-    void clear() { r.clear(); }
+    std::vector<uint64_t> page;
+    int shift = g_pageShift;
+    // For the mark set of a predicted view: the ranges not yet known to have come true (allPending). A mark that is true stays true,
+    // so the list only shrinks - the validity questions about a view are asked again at every stop of the round.
+    mutable std::vector<uint32_t> pend;
+    mutable bool pendInit = false;
+    void clear() { r.clear(); page.clear(); pend.clear(); pendInit = false; }
+    // cond(q) for every range q that is not known to be true yet (isTrue(q): it has come true - it is never asked about again); stops at the first false
+    template <class T, class F>
+    bool allPending(T isTrue, F cond) const
+    {
+        if (!pendInit) { pend.resize(r.size()); for (size_t i = 0; i < r.size(); i++) pend[i] = (uint32_t)i; pendInit = true; }
+        for (size_t k = 0; k < pend.size();) {
+            const auto& q = r[pend[k]];
+            if (isTrue(q)) { pend[k] = pend.back(); pend.pop_back(); continue; }
+            if (!cond(q)) return false;
+            k++;
+        }
+        return true;
+    }
     bool empty() const { return r.empty(); }
+    bool pageAny(uint64_t lo, uint64_t hi) const      // any range that touches a page of [lo, hi] (inclusive)?
+    {
+        if (r.empty()) return false;
+        const uint64_t p0 = lo >> shift, p1 = hi >> shift, nBits = (uint64_t)page.size() << 6;
+        if (p0 >= nBits) return false;
+        const uint64_t q1 = p1 < nBits ? p1 : nBits - 1, w0 = p0 >> 6, w1 = q1 >> 6;
+        for (uint64_t w = w0; w <= w1; w++) {
+            uint64_t m = ~0ull;
+            if (w == w0) m &= ~0ull << (p0 & 63);
+            if (w == w1) m &= ~0ull >> (63 - (q1 & 63));
+            if (page[(size_t)w] & m) return true;
+        }
+        return false;
+    }
     void add(uint64_t lo, uint64_t hi)
     {
         if (hi <= lo) return;
+        const uint64_t p1 = (hi - 1) >> shift;
+        if ((p1 >> 6) >= page.size()) page.resize((size_t)(p1 >> 6) + 1, 0ull);
+        for (uint64_t q = lo >> shift; q <= p1; q++) page[(size_t)(q >> 6)] |= 1ull << (q & 63);
         auto it = std::lower_bound(r.begin(), r.end(), std::make_pair(lo, (uint64_t)0));
         if (it != r.begin() && (it - 1)->second >= lo) --it;
         auto first = it;
@@ -59,6 +99,7 @@ struct RangeSet {
     // any position p of the set with lo <= p <= hi ?
     bool hits(uint64_t lo, uint64_t hi) const
     {
+        if (!pageAny(lo, hi)) return false;
         auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(hi, UINT64_MAX));
         if (it == r.begin()) return false;
         --it;
@@ -68,6 +109,7 @@ struct RangeSet {
     bool covers(uint64_t lo, uint64_t hi) const
     {
         if (hi <= lo) return true;
+        if (!pageAny(lo, lo)) return false;
         auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(lo, UINT64_MAX));
         if (it == r.begin()) return false;
         --it;
@@ -76,6 +118,7 @@ struct RangeSet {
     // any position p of the set with lo <= p <= hi that is NOT in `except` (null = empty) ?
     bool hitsOutside(uint64_t lo, uint64_t hi, const RangeSet* except) const
     {
+        if (!pageAny(lo, hi)) return false;
         if (!except || except->empty()) return hits(lo, hi);
         auto it = std::upper_bound(r.begin(), r.end(), std::make_pair(lo, UINT64_MAX));
         if (it != r.begin()) --it;
@@ -158,6 +201,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     if (rank < 0 || rank >= world) throw LcbError("bad rank");
     if (cfg.countEvents && world > 1) throw LcbError("event counting runs on one rank");
 
+    g_pageShift = 12;
+    while ((g->nPos() >> g_pageShift) > 65536) g_pageShift++;       // the coarse bitmap of a RangeSet: at most 8 KB
     lcb_committer com(g, *p);
     proc.reset();
     LcbEngineStats st;
@@ -340,7 +385,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         auto validNow = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, bool* viewOk, const lcb_fp* f, size_t nf) -> bool {
             const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
             if (P && !(viewOk && *viewOk)) {
-                for (auto& q : P->r) if (!com.allUsed(q.first, q.second)) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; st.overPredicted++; return false; }
+                if (!P->allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
+                                   [&](const std::pair<uint64_t, uint64_t>& q) { if (debug) std::cerr << "   (1) over-predicted [" << q.first << "," << q.second << ")\n"; return false; })) { st.overPredicted++; return false; }
                 if (viewOk) *viewOk = true;
             }
             const uint32_t last = (uint32_t)epochMarks.size() - 1;
@@ -359,8 +405,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         // Every predicted mark of the job's view is true by now - or, inside a dry run, still predicted (simP).
         auto sidePlausible = [&](const SideJob& sj, const RangeSet* simP) -> bool {
             if (sj.set < 0) return true;
-            for (auto& q : viewSets[(size_t)sj.set].r) if (!com.allUsed(q.first, q.second) && !(simP && simP->covers(q.first, q.second))) return false;
-            return true;
+            return viewSets[(size_t)sj.set].allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
+                                                       [&](const std::pair<uint64_t, uint64_t>& q) { return simP && simP->covers(q.first, q.second); });
         };
         // The commit needs the E / F of seed i now and a job for it is in flight: its result is taken (waiting for that one job)
         // if its view came true - at this point every commit the view predicted has either happened or will never happen -,
@@ -455,10 +501,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             // would this result still be exact if the predicted marks came true? (conditions (1) and (2) against live + simP)
             auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf) -> bool {
                 const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
-                if (P) for (auto& q : P->r) if (!com.allUsed(q.first, q.second) && !simP.covers(q.first, q.second)) {
-                    // a predicted mark that is neither true yet nor predicted now (partly true + partly predicted is rare: treat as invalid)
-                    return false;
-                }
+                // a predicted mark that is neither true yet nor predicted now voids the result (partly true + partly predicted is rare: treated as void)
+                if (P && !P->allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
+                                        [&](const std::pair<uint64_t, uint64_t>& q) { return simP.covers(q.first, q.second); })) return false;
                 const uint32_t last = (uint32_t)epochMarks.size() - 1;
                 for (uint32_t e = std::max((uint32_t)epoch, checkedTo); e <= last; e++) {
                     if (epochMarks[e].empty()) continue;

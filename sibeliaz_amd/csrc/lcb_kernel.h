@@ -50,6 +50,15 @@
 #endif
 // The flight-recorder sites (LCB_MARK) are compiled into every kernel variant and cost one predictable branch each
 // when the recorder is off. The recorder is what localises a hang on the device (host watchdog, device.hip).
+// Diagnostic build (-DLCB_PROF_PUSH=1, instrumented variant only): the vote-section slots of the per-seed profile carry the sections of a
+// push instead - [8] until the vertex is in the path set, [9] search + classification of the occurrences, [10] cross-lane rule + apply,
+// [11] rebuilding the ordered index.
+#ifndef LCB_PROF_PUSH
+#define LCB_PROF_PUSH 0
+#endif
+#ifndef LCB_VOTE_TICKETS
+#define LCB_VOTE_TICKETS 1         // (0: the static deal of voters to wavefronts, for the A/B)
+#endif
 #ifndef LCB_FLIGHT_RECORDER
 #define LCB_FLIGHT_RECORDER 1
 #endif
@@ -279,6 +288,7 @@ struct LcbStateT {
     uint32_t* vLast;
     uint16_t* vTouched;        // slots claimed in the current vote, in claim order
     uint32_t* vNClaimed;       // LDS counter: number of them
+    uint32_t* vTicket;         // LDS counter: next entry of the touch list to hand to a wavefront (votes shared by more than two wavefronts)
     uint32_t* vOvf;            // LDS flag: a walk of the current vote could not place a vertex
     uint32_t voteCap, voteShift;
     uint32_t* scr;             // LDS scratch, 4 * 64 words
@@ -554,8 +564,12 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // One voter = one instance whose end vertex is the path end (blocksfinder.h:716-717). Its scalars live in SGPRs.
 
 // The voter walks of one vote. The voters are the instances of the touch list that are in the voting list (the good list
-// if it has two entries, else all instances; blocksfinder.h:713). Wave w of nWaves takes the voters with ordinal == w
-// (mod nWaves); all waves accumulate into the shared vote table with atomics, so the split needs no merging.
+// if it has two entries, else all instances; blocksfinder.h:713). With two wavefronts wave w takes the voters with ordinal == w
+// (mod 2); with more (wide, big, huge: votes of dozens of voters whose windows take one to six 64-step chunks) the wavefronts draw
+// the entries of the touch list one by one from an LDS ticket counter - a wavefront that is done with a short window takes the
+// next voter instead of waiting at the barrier for the one that drew three long ones (measured with the static deal: the walking
+// wavefront waits 2.0 / 3.6 us of a 8.3 / 13.3 us vote in the wide / big variant). All waves accumulate into the shared vote table
+// with atomics, so the split needs no merging - and no order: the arg-max is order-free.
 // `exact`: the walks stop at vertices of the path (blocksfinder.h:736-741). Where the path set lives in the HBM slot behind an LDS
 // Bloom filter (compact, big, huge) a per-step membership test costs a dependent global round trip for every chunk in which the
 // filter says "maybe" for one lane - with a path of thousands of vertices that is almost every chunk. A walk meets a path vertex
@@ -582,7 +596,32 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     unsigned long long pend = 0;
     uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
     bool scanned = false;
+    const bool tickets = LCB_VOTE_TICKETS && nWaves > 2;
     auto nextVoter = [&](LcbVoter& v) -> bool {
+        if (tickets) {
+            // one entry of the touch list per draw; its fields are wave-uniform loads (the next voter is drawn while the current one
+            // is walked, so their latency hides behind a walk)
+            for (;;) {
+                uint32_t t = 0;
+                if (S.lane == 0) t = atomicAdd(S.vTicket, 1u);
+                t = lcb_rfl(t);
+                if (t >= nTouch) return false;
+                const uint32_t i = lcb_rfl((uint32_t)S.touch[t]);
+                const uint32_t e = useGood ? lcb_rfl((uint32_t)S.goodPos[i]) : i;      // position in the voting list (its order breaks ties)
+                if (e == LCB_NONE16) continue;
+                const uint32_t fl = lcb_rfl(S.iFlags[i]), fp = lcb_rfl(S.iFrontPos[i]), bp = lcb_rfl(S.iBackPos[i]);
+                v.e = e; v.i = i;
+                v.g0 = lcb_rfl(forward ? S.iBackG[i] : S.iFrontG[i]);
+                v.pos0 = forward ? bp : fp;
+                v.lo = lcb_rfl(S.iLo[i]);
+                const uint32_t hi = lcb_rfl(S.iHi[i]);
+                v.weight = lcb_absdiff(fp, bp) + 1u;                                   // blocksfinder.h:719
+                v.positive = (fl & LCB_FLAG_POS) != 0;
+                v.dir = (forward == v.positive) ? 1 : -1;
+                v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                      // steps for which it.Valid() holds
+                return true;
+            }
+        }
         for (;;) {
             while (pend == 0) {
                 if (scanned) chunkBase += 64;
@@ -789,6 +828,7 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u) | (exact ? 16u : 0u);
             S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
             S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
+            *S.vTicket = 0;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
@@ -797,7 +837,7 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
         const uint64_t tw1 = PROF ? wall_clock64() : 0;
         __syncthreads();                                           // B: all walks done
         const uint64_t tw2 = PROF ? wall_clock64() : 0;
-        if (PROF) { S.pfTWalk += tw1 - tw0; S.pfTWaitB += tw2 - tw1; }
+        if (PROF && !LCB_PROF_PUSH) { S.pfTWalk += tw1 - tw0; S.pfTWaitB += tw2 - tw1; }
         nTouched = lcb_rfl(*S.vNClaimed);
         if (nTouched > claimCap) nTouched = claimCap;
         if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
@@ -821,11 +861,11 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
             LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
             lcb_vote_clear(S, 0, nTouched);
         }
-        if (PROF) S.pfTReduce += wall_clock64() - tw2;
+        if (PROF && !LCB_PROF_PUSH) S.pfTReduce += wall_clock64() - tw2;
     } else {
         const uint64_t tw0 = PROF ? wall_clock64() : 0;
         lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, nList, flank, 0, 1, exact);
-        if (PROF) S.pfTWalk += wall_clock64() - tw0;
+        if (PROF && !LCB_PROF_PUSH) S.pfTWalk += wall_clock64() - tw0;
         LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
         nTouched = lcb_rfl(*S.vNClaimed);
         if (nTouched > claimCap) nTouched = claimCap;
@@ -958,6 +998,7 @@ template <bool BACK, bool STATS, bool PROF, class ST>
 __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
+    const uint64_t tq0 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
     const uint32_t o0 = E.o0, o1 = E.o1;
@@ -976,7 +1017,9 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
 
     const int64_t B = S.P.maxBranch;
     uint32_t nTouch = 0;                                             // instances this push extends or creates
+    if (PROF && LCB_PROF_PUSH) S.pfTWalk += wall_clock64() - tq0;
     for (uint32_t base = o0; base < o1; base += 64) {
+        const uint64_t tq1 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
         const uint32_t j = base + S.lane;
         const bool active = j < o1;
         const uint32_t n = S.nInst;
@@ -1053,6 +1096,8 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                 } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
             }
         }
+        const uint64_t tq2 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
+        if (PROF && LCB_PROF_PUSH) S.pfTWaitB += tq2 - tq1;
         // Occurrences that fall into the same gap (same chromosome, same upper bound u) interact sequentially in the
         // reference; lanes are ordered by g, so a gap is a contiguous lane segment:
         //  * after the first EXT_X in the gap every later occurrence is Within() that instance -> SKIP;
@@ -1141,7 +1186,10 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         S.nInst += m;
         if (m) { const uint32_t top = lcb_fp_slot(S, S.nInst - 1) + 1; if (top > S.nFp) S.nFp = top; if (S.nInst > S.nFp) S.nFp = S.nInst; }
         LCB_SYNC_IF(LcbCfg<ST::MODE>::INST_LDS && LcbCfg<ST::MODE>::IDX_LDS);
+        const uint64_t tq3 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
+        if (PROF && LCB_PROF_PUSH) S.pfTReduce += tq3 - tq2;
         if (m) lcb_order_merge(S, m);
+        if (PROF && LCB_PROF_PUSH) S.pfTScan += wall_clock64() - tq3;
     }
     if (BACK) {
         if (record) {
@@ -1531,13 +1579,13 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.iFlags = instBase + 6 * instStride;
     S.iFrontDist = (int32_t*)(instBase + 7 * instStride);
     S.iBackDist = (int32_t*)(instBase + 8 * instStride);
-    S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1];
+    S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1]; S.vTicket = &sMisc[2];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
     S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     S.abort = W.abort;
     LCB_MARK(S, 0, 1);
-    if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
+    if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
     S.rightFlank = S.leftFlank = 0;
     S.cWalk = S.cOcc = S.cCompatCall = S.cCompatStep = S.cVote = S.cPush = 0;
@@ -1727,6 +1775,11 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
 // (blocksfinder.h:314-329), mirrors the marks in its own copy of the bitmap and goes on from the stop with its planner.
 // ONE workgroup: phases are sequential by definition (a phase's validation needs the marks of the phases before it); inside a phase
 // the validation is spread over the wavefronts (lanes = footprint intervals) and the commit is lane-parallel over instances and words.
+// A footprint interval spans thousands of positions (an instance and the look-ahead windows around it), so testing it word by word
+// against the delta bitmap costs hundreds of dependent loads per lane - measured on the MI355X: 48 ms per round of config 3, twice the
+// pass time. The round's marks are few, so a coarse summary of delta in LDS (one bit per 2^pageShift positions, rebuilt from the list
+// of ranges at the start of an invocation) answers almost every interval with two or three LDS words; only intervals that touch a
+// marked page are tested exactly.
 enum { LCB_CS_NEXT = 0,        // first seed of the next phase to commit (everything before it is committed or passed over)
        LCB_CS_NCOMMITTED,      // entries of the committed list
        LCB_CS_STOPKIND,        // 0 none so far, 1 a phase-start result of the phase at STOPAT is void, 2 seed STOPAT conflicts (its phase is committed up to it)
@@ -1748,7 +1801,9 @@ struct LcbCommitArgs {
     uint2* deltaList;              // ranges marked in `delta` this round ...
     uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete and the host clears the whole bitmap)
     uint32_t deltaCap;
+    uint32_t pageShift;            // the coarse LDS summary of delta has one bit per 2^pageShift positions (nPos >> pageShift <= LCB_COMMIT_PAGES)
 };
+#define LCB_COMMIT_PAGES 32768u    // bits of the summary (4 KB of LDS)
 
 // any set bit of `bits` in [a, b)? (bitmap words are read past the L1: other wavefronts mark them with atomics)
 __device__ inline bool lcb_bits_any(const uint32_t* bits, uint32_t a, uint32_t b)
@@ -1781,12 +1836,21 @@ template <int NW>
 __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
 {
     __shared__ uint32_t sFlag[8];          // [0] a seed of the phase has no final result yet, [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
+    __shared__ uint32_t sPage[LCB_COMMIT_PAGES / 32];      // coarse summary of delta
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
     if (tid == 0) { sFlag[2] = A.state[LCB_CS_MARKED]; sFlag[5] = A.state[LCB_CS_NCOMMITTED]; sFlag[6] = A.state[LCB_CS_NEXT]; sFlag[7] = A.state[LCB_CS_STOPKIND]; }
     __syncthreads();
     uint32_t ps = sFlag[6];
     if (sFlag[7]) return;                  // the commit of this round has stopped for good
     bool marked = sFlag[2] != 0;           // wave-uniform, identical in every wavefront
+    const uint32_t sh = A.pageShift;
+    {   // the summary of what earlier invocations of this round marked (a list that overflowed: every page counts as marked)
+        const uint32_t nD = marked ? *A.deltaCount : 0u;
+        for (uint32_t w = tid; w < LCB_COMMIT_PAGES / 32; w += nT) sPage[w] = nD > A.deltaCap ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        if (nD <= A.deltaCap) for (uint32_t r = tid; r < nD; r += nT) { const uint2 d = A.deltaList[r]; for (uint32_t q = d.x >> sh; q <= (d.y - 1u) >> sh; q++) atomicOr(&sPage[q >> 5], 1u << (q & 31)); }
+        __syncthreads();
+    }
     uint32_t nCommitted = sFlag[5], stopKind = 0, stopAt = 0;
     while (ps < A.n) {
         const uint32_t pe = ps + A.phase < A.n ? ps + A.phase : A.n, ph = ps / A.phase;
@@ -1804,7 +1868,13 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                 if (A.roundState[q] != LCB_RS_DONE) continue;
                 const LcbSeedOut o = A.roundOut[q];
                 bool hit = false;
-                for (uint32_t k = lane; k < o.nFp; k += 64) { const uint2 f = A.fpArena[o.fpOff + k]; if (lcb_bits_any(A.delta, f.x, (f.y < A.nPos ? f.y : A.nPos - 1u) + 1u)) hit = true; }
+                for (uint32_t k = lane; k < o.nFp; k += 64) {
+                    const uint2 f = A.fpArena[o.fpOff + k];
+                    const uint32_t a = f.x, b = f.y < A.nPos ? f.y : A.nPos - 1u;                 // positions a .. b
+                    bool page = false;
+                    for (uint32_t q = a >> sh; q <= b >> sh && !page; q++) page = ((sPage[q >> 5] >> (q & 31)) & 1u) != 0;
+                    if (page && lcb_bits_any(A.delta, a, b + 1u)) hit = true;
+                }
                 if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
             }
             __syncthreads();
@@ -1834,6 +1904,7 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                     if (hi > lo) {
                         lcb_bits_set(A.used, lo, hi);
                         lcb_bits_set(A.delta, lo, hi);
+                        for (uint32_t q = lo >> sh; q <= (hi - 1u) >> sh; q++) atomicOr(&sPage[q >> 5], 1u << (q & 31));
                         const uint32_t slot = atomicAdd(A.deltaCount, 1u);
                         if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};
                     }

@@ -118,6 +118,7 @@ int main(int argc, char** argv)
             A.roundState = roundState.data(); A.roundOut = roundOut.data(); A.arena = inst.data(); A.fpArena = fp.data();
             A.n = nRound; A.phase = phase; A.nPos = nPos; A.state = state.data(); A.committed = committed.data();
             A.deltaList = deltaList.data(); A.deltaCount = &deltaCount; A.deltaCap = (uint32_t)deltaList.size();
+            A.pageShift = 1u + (uint32_t)(c % 7);                  // tiny pages: intervals span many of them
             if (nw == 0) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
             else if (nw == 1) emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
             else if (nw == 2) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });

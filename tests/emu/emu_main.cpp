@@ -355,6 +355,7 @@ struct EmuProcessor : LcbProcessor {
             A.roundState = dcRound.data(); A.roundOut = dcOut.data(); A.arena = emu->arena.data(); A.fpArena = emu->fpArena.data();
             A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
             A.state = dcState.data(); A.committed = dcCommitted.data(); A.deltaList = dcList.data(); A.deltaCount = &dcDeltaCount; A.deltaCap = (uint32_t)dcList.size();
+            A.pageShift = getenv("EMU_COMMIT_PAGE_SHIFT") ? (uint32_t)atoi(getenv("EMU_COMMIT_PAGE_SHIFT")) : 5u; while ((A.nPos >> A.pageShift) >= LCB_COMMIT_PAGES) A.pageShift++;
             const uint32_t before = dcState[LCB_CS_NEXT];
             if (nw == 16) emu_run_block(0, 16, [&]() { lcb_commit_body<16>(A); });
             else if (nw == 8) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });

@@ -172,10 +172,22 @@ void emu_run_block(uint32_t blockId, int nWaves, const std::function<void()>& bo
         top[6] = (uint64_t)(uintptr_t)&laneEntry;    // popped by `ret` after the six callee-saved registers
         l.sp = top; l.done = false; l.parked = false; l.kind = 0;
     }
+    // EMU_SCHED=rr: the waves take turns at every wave-level operation (interleaved progress: what work the waves draw from shared
+    // counters depends on it); EMU_SCHED=rev: maximal skew with the LAST wave first. Default: maximal skew, wave 0 first.
+    static const char* schedEnv = getenv("EMU_SCHED");
+    const bool rr = schedEnv && !strcmp(schedEnv, "rr"), rev = schedEnv && !strcmp(schedEnv, "rev");
     for (;;) {
         // run each wave as far as it can go on its own (maximal skew between waves)
         int atBarrier = 0, done = 0;
-        for (int w = 0; w < nWaves; w++) {
+        if (rr) {
+            for (bool progress = true; progress;) {
+                progress = false;
+                for (int w = 0; w < nWaves; w++) { sweepWave(w); if (settleWave(w) == 1) progress = true; }
+            }
+            for (int w = 0; w < nWaves; w++) { const int r = settleWave(w); if (r == 2) atBarrier++; if (r == 3) done++; }
+        } else
+        for (int q = 0; q < nWaves; q++) {
+            const int w = rev ? nWaves - 1 - q : q;
             for (;;) {
                 sweepWave(w);
                 const int r = settleWave(w);

@@ -170,6 +170,12 @@ def emu_built():
                                             ("inv_k25", "medium", {"EMU_NW": "16", "EMU_LIMIT": "120", "EMU_SHARE": "1"}),
                                             ("inv_k25", "big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SHARE": "1"}),
                                             ("inv_k25", "big", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200"}),      # the shipped big variant: 16 wavefronts
+                                            # other schedules of the emulated wavefronts (the default runs wave 0 as far as it gets first: it then draws every
+                                            # voter ticket itself): taking turns at every wave-level operation, and the last wavefront first
+                                            ("inv_k25", "medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SCHED": "rr"}),
+                                            ("inv_k25", "medium", {"EMU_NW": "16", "EMU_LIMIT": "120", "EMU_SCHED": "rev"}),
+                                            ("inv_k25", "big", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SCHED": "rr", "EMU_FP_CHECK": "1"}),
+                                            ("twogenomes", "medium", {"EMU_NW": "8", "EMU_LIMIT": "300", "EMU_SCHED": "rr"}),
                                             ("inv_k25", "huge", {"EMU_NW": "4", "EMU_LIMIT": "200"}),
                                             ("inv_k25", "seeds-init", {"EMU_NW": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "300"}),     # the shipped compact variant: 2 wavefronts
                                             ("collinear6", "seeds-init", {"EMU_NW": "4", "EMU_LIMIT": "100", "EMU_SHARE": "1"}),
