@@ -247,24 +247,28 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // ---- device-resident commit of a round's clean prefix (processRound of the processor), one rank only
     const bool useDevCommit = world == 1 && !cfg.hostCommit && !cfg.countEvents && !(cfg.exchangeAlways && cfg.allgather);
     std::vector<uint32_t> dcCommitted;
-    // ---- asynchronous job batches (side lanes of the processor), one rank only
-    const bool useSide = world == 1 && !cfg.syncJobs && !cfg.countEvents && !(cfg.exchangeAlways && cfg.allgather) && proc.sideLanes() > 0;
-    // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs
-    const bool useEarly = useSide;
+    // ---- asynchronous job batches (side lanes of the processor). With several ranks (`multi`: every launch is dealt to the ranks) a
+    // batch is dealt like a launch - job k of it runs on a lane of rank k % world - and results travel through exchangeSide below.
+    const bool multi = world > 1 || (cfg.exchangeAlways && cfg.allgather);
+    const bool useSide = !cfg.syncJobs && !cfg.countEvents && proc.sideLanes() > 0;
+    // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs (one rank)
+    const bool useEarly = useSide && !multi;
     std::vector<lcb_seed> earlySeeds;
-    struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // state: 0 in flight, 1 taken, 2 dropped
+    struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // lane: index into `batches`; k: job of the batch; state: 0 in flight, 1 taken, 2 dropped
+    struct SideBatch { int lane; int pending; };    // the processor's lane on THIS rank (-1: this rank has no job of the batch), jobs in flight (on all ranks)
+    std::vector<SideBatch> batches;                 // of this round
+    std::vector<uint8_t> sideSent;                  // multi: per job of sideJobs, 1 = this rank has published its result (exchangeSide)
     std::vector<SideJob> sideJobs;                  // of this round
     size_t sideScan = 0;                            // jobs before this index are no longer in flight
     int64_t frozenTo = 0;                           // seeds of the round before this index have their final phase-start result
     std::vector<int32_t> sideE, sideF;              // per seed of the round: its job in flight for E / F (index into sideJobs), or -1
-    std::vector<int> lanePending((size_t)std::max(0, proc.sideLanes()), 0);   // jobs in flight per lane
-    std::vector<int> laneOrder;                     // lanes with a batch in flight, oldest first
+    std::vector<int> laneOrder;                     // batches with jobs in flight, oldest first
     std::vector<lcb_instance> sInst;
     std::vector<lcb_fp> sFp;
-    auto laneDone = [&](int lane) {                 // one job of the lane fewer in flight; the last one frees the lane
-        if (--lanePending[(size_t)lane] == 0) {
-            proc.sideRelease(lane);
-            auto it = std::find(laneOrder.begin(), laneOrder.end(), lane);
+    auto laneDone = [&](int b) {                    // one job of the batch fewer in flight; the last one frees its lane (on every rank)
+        if (--batches[(size_t)b].pending == 0) {
+            if (batches[(size_t)b].lane >= 0) proc.sideRelease(batches[(size_t)b].lane);
+            auto it = std::find(laneOrder.begin(), laneOrder.end(), b);
             if (it != laneOrder.end()) laneOrder.erase(it);
         }
     };
@@ -283,9 +287,31 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     uint64_t launchOrdinal = 0;
     std::vector<lcb_seed> shareSeeds;
     std::vector<uint32_t> shareView;
+    // All-gather of one variable-size buffer per rank (sizes first, then the payload padded to the largest): recvBuf holds world
+    // strides of `stride` bytes. The size exchange carries an error flag and a tag of the call, so that a rank that failed - or ranks
+    // that disagree about the collective they are in - stop ALL ranks with an error instead of leaving the others blocked.
+    auto gatherV = [&](uint64_t failed, const std::string& what, uint64_t tag, uint64_t& stride, std::vector<uint64_t>* sizes) {
+        uint64_t head[4] = {sendBuf.size(), failed, launchOrdinal, tag};
+        std::vector<uint64_t> heads((size_t)world * 4);
+        if (cfg.allgather(cfg.allgatherUser, head, sizeof(head), heads.data())) throw LcbError("all-gather failed");
+        uint64_t maxBytes = 0;
+        if (sizes) sizes->assign((size_t)world, 0);
+        for (int r = 0; r < world; r++) {
+            if (heads[4 * r + 1]) throw LcbError(r == rank ? "rank " + std::to_string(r) + " failed: " + what : "rank " + std::to_string(r) + " failed; stopping all ranks");
+            if (heads[4 * r + 2] != head[2] || heads[4 * r + 3] != head[3])
+                throw LcbError("ranks disagree about the launch they are in (are the engine and device options identical on every rank?)");
+            maxBytes = std::max(maxBytes, heads[4 * r]);
+            if (sizes) (*sizes)[(size_t)r] = heads[4 * r];
+        }
+        sendBuf.resize((size_t)maxBytes);
+        recvBuf.resize((size_t)maxBytes * world);
+        if (maxBytes && cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
+        st.exchanges++;
+        stride = maxBytes;
+    };
     auto processSharded = [&](const lcb_seed* sd, const uint32_t* view, int64_t n, Results& out, uint64_t tag) {
         launchOrdinal++;
-        if (world == 1 && !(cfg.exchangeAlways && cfg.allgather)) {
+        if (!multi) {
             const auto tp = std::chrono::steady_clock::now();
             proc.ctrSink = cfg.countEvents ? &out.ctr : nullptr;
             proc.process(sd, view, n, out.off, out.inst, out.fpOff, out.fp);
@@ -304,20 +330,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             st.processMs += msSince(tp);
             pack(mine, (int64_t)shareSeeds.size(), sendBuf);
         } catch (std::exception& e) { failed = 1; what = e.what(); sendBuf.clear(); }
-        uint64_t head[4] = {sendBuf.size(), failed, launchOrdinal, ((uint64_t)n << 20) ^ tag};
-        std::vector<uint64_t> heads((size_t)world * 4);
-        if (cfg.allgather(cfg.allgatherUser, head, sizeof(head), heads.data())) throw LcbError("all-gather failed");
         uint64_t maxBytes = 0;
-        for (int r = 0; r < world; r++) {
-            if (heads[4 * r + 1]) throw LcbError(r == rank ? "rank " + std::to_string(r) + " failed: " + what : "rank " + std::to_string(r) + " failed; stopping all ranks");
-            if (heads[4 * r + 2] != head[2] || heads[4 * r + 3] != head[3])
-                throw LcbError("ranks disagree about the launch they are in (are the engine and device options identical on every rank?)");
-            maxBytes = std::max(maxBytes, heads[4 * r]);
-        }
-        sendBuf.resize((size_t)maxBytes);
-        recvBuf.resize((size_t)maxBytes * world);
-        if (maxBytes && cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
-        st.exchanges++;
+        gatherV(failed, what, ((uint64_t)n << 20) ^ tag, maxBytes, nullptr);
         // seed i came from rank i % world, local index i / world
         out.off.assign((size_t)n + 1, 0); out.fpOff.assign((size_t)n + 1, 0);
         std::vector<const unsigned char*> base((size_t)world);
@@ -371,7 +385,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         e0Checked.assign((size_t)nRound, 0);
         liveIdx.clear();
         for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
-        if (useSide) { sideJobs.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
+        if (useSide) { sideJobs.clear(); sideSent.clear(); batches.clear(); laneOrder.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
         const int64_t recomputedBefore = st.recomputedSeeds;
         st.sectionMs[LCB_SEC_SETUP] += msSince(tSetup);
 
@@ -430,24 +444,80 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             c.inst = sInst; c.fp = sFp; c.ctr = lcb_counters{};
             return true;
         };
+        // Several ranks: the result of a background job lives on the rank that ran it. exchangeSide is a collective every rank enters at
+        // the same point of the (identical) commit: each rank publishes the results of its own jobs that have finished since its last
+        // exchange - the owner of job `need` (-1: none) waits for that one first - and all ranks store all published results, in the
+        // same order. Decisions rest on published results only, so the ranks stay in step whatever the timing of their lanes.
+        bool needStored = false;
+        auto exchangeSide = [&](int32_t need) {
+            const auto tp = std::chrono::steady_clock::now();
+            launchOrdinal++;
+            uint64_t failed = 0;
+            std::string what;
+            sendBuf.clear();
+            try {
+                for (size_t q = sideScan; q < sideJobs.size(); q++) {
+                    const SideJob& sj = sideJobs[q];
+                    if (sj.state != 0 || (int)(sj.k % world) != rank || sideSent[q]) continue;
+                    sInst.clear(); sFp.clear();
+                    const int r = proc.sidePoll(batches[(size_t)sj.lane].lane, sj.k / world, (int32_t)q == need, sInst, sFp);
+                    if (r == 0) continue;
+                    sideSent[q] = 1;
+                    const uint32_t h[4] = {(uint32_t)q, (uint32_t)r, r == 1 ? (uint32_t)sInst.size() : 0u, r == 1 ? (uint32_t)sFp.size() : 0u};
+                    const size_t at = sendBuf.size();
+                    sendBuf.resize(at + 16 + (size_t)h[2] * sizeof(lcb_instance) + (size_t)h[3] * sizeof(lcb_fp));
+                    memcpy(sendBuf.data() + at, h, 16);
+                    if (h[2]) memcpy(sendBuf.data() + at + 16, sInst.data(), (size_t)h[2] * sizeof(lcb_instance));
+                    if (h[3]) memcpy(sendBuf.data() + at + 16 + (size_t)h[2] * sizeof(lcb_instance), sFp.data(), (size_t)h[3] * sizeof(lcb_fp));
+                }
+            } catch (std::exception& e) { failed = 1; what = e.what(); sendBuf.clear(); }
+            uint64_t stride = 0;
+            std::vector<uint64_t> sizes;
+            gatherV(failed, what, 0x51DEull ^ ((uint64_t)(need + 1) << 20), stride, &sizes);
+            needStored = false;
+            for (int r = 0; r < world; r++) {
+                const unsigned char* b = recvBuf.data() + (size_t)r * stride;
+                for (uint64_t at = 0; at + 16 <= sizes[(size_t)r];) {
+                    uint32_t h[4];
+                    memcpy(h, b + at, 16);
+                    const size_t bytes = 16 + (size_t)h[2] * sizeof(lcb_instance) + (size_t)h[3] * sizeof(lcb_fp);
+                    if (h[0] >= sideJobs.size() || at + bytes > sizes[(size_t)r]) throw LcbError("engine: a published background result does not fit the batch it names");
+                    sInst.resize(h[2]); sFp.resize(h[3]);
+                    if (h[2]) memcpy(sInst.data(), b + at + 16, (size_t)h[2] * sizeof(lcb_instance));
+                    if (h[3]) memcpy(sFp.data(), b + at + 16 + (size_t)h[2] * sizeof(lcb_instance), (size_t)h[3] * sizeof(lcb_fp));
+                    at += bytes;
+                    if (sideJobs[h[0]].state != 0) continue;           // (dropped since its owner saw it finish: identical on every rank)
+                    const bool ok = storeSide((int32_t)h[0], (int)h[1], (int32_t)h[0] == need);
+                    if ((int32_t)h[0] == need) needStored = ok;
+                }
+            }
+            while (sideScan < sideJobs.size() && sideJobs[sideScan].state != 0) sideScan++;
+            st.processMs += msSince(tp);
+        };
         auto takeSide = [&](int64_t i, bool isF) -> bool {
             const int32_t ref = (isF ? sideF : sideE)[(size_t)i];
             if (ref < 0) return false;
             if (sideJobs[(size_t)ref].state != 0 || !sidePlausible(sideJobs[(size_t)ref], nullptr)) { dropSide(ref); return false; }
+            if (multi) {
+                exchangeSide(ref);
+                if (sideJobs[(size_t)ref].state == 0) throw LcbError("engine: the owner of a background job did not publish its result");
+                return needStored;
+            }
             sInst.clear(); sFp.clear();
             const auto tp = std::chrono::steady_clock::now();
-            const int r = proc.sidePoll(sideJobs[(size_t)ref].lane, sideJobs[(size_t)ref].k, true, sInst, sFp);
+            const int r = proc.sidePoll(batches[(size_t)sideJobs[(size_t)ref].lane].lane, sideJobs[(size_t)ref].k, true, sInst, sFp);
             st.processMs += msSince(tp);
             return storeSide(ref, r, true);
         };
         // Background jobs that have finished become candidate results like the jobs of a synchronous launch (a dry run then judges
         // them by their footprints; their lane is free once all its jobs are in). Called at every stop.
         auto harvestSide = [&]() {
+            if (multi) { if (sideScan < sideJobs.size()) exchangeSide(-1); return; }
             const auto tp = std::chrono::steady_clock::now();
             for (size_t q = sideScan; q < sideJobs.size(); q++) {
                 if (sideJobs[q].state != 0) { if (q == sideScan) sideScan++; continue; }
                 sInst.clear(); sFp.clear();
-                const int r = proc.sidePoll(sideJobs[q].lane, sideJobs[q].k, false, sInst, sFp);
+                const int r = proc.sidePoll(batches[(size_t)sideJobs[q].lane].lane, sideJobs[q].k, false, sInst, sFp);
                 if (r != 0) storeSide((int32_t)q, r, false);
             }
             st.processMs += msSince(tp);
@@ -622,15 +692,39 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (!midPhase) while (nCrit < jobs.size() && !jobs[nCrit].isF && jobs[nCrit].seed < ph0 + phase && jobs[nCrit].devView == 0) nCrit++;
             if ((midPhase && jobs[0].seed != stopAt) || jobs[0].devView != 0) throw LcbError("engine: the first job of a plan is not the stop's own");
             // Side lanes: everything else runs in the background (the oldest batch gives way if no lane is free).
-            int lane = -1;
+            int lane = -1;                            // the batch (index into `batches`) that took the rest of the plan, or < 0
             if (useSide && jobs.size() > nCrit) {
                 const auto tp = std::chrono::steady_clock::now();
-                lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
+                // One rank: the processor's lane, or -1 (no lane is free) / -2 (the batch fits no lane). Several ranks: this rank's share
+                // of the batch (jobs k with k % world == rank) on a lane of its own processor; the ranks agree on the worst answer, so
+                // that all of them either have the batch or fall back together.
+                auto beginBatch = [&]() -> int {
+                    const lcb_seed* sd = sub.data() + nCrit; const uint32_t* vw = subView.data() + nCrit;
+                    const int64_t n = (int64_t)(sub.size() - nCrit);
+                    int mine;
+                    if (!multi) mine = proc.sideBegin(sd, vw, n, nViews, vmarks.data(), (int64_t)vmarks.size());
+                    else {
+                        shareSeeds.clear(); shareView.clear();
+                        for (int64_t k = rank; k < n; k += world) { shareSeeds.push_back(sd[k]); shareView.push_back(vw[k]); }
+                        mine = shareSeeds.empty() ? -3 : proc.sideBegin(shareSeeds.data(), shareView.data(), (int64_t)shareSeeds.size(), nViews, vmarks.data(), (int64_t)vmarks.size());
+                        launchOrdinal++;
+                        sendBuf.assign(1, (unsigned char)(mine == -1 ? 1 : (mine == -2 ? 2 : 0)));
+                        uint64_t stride = 0;
+                        gatherV(0, std::string(), 0xBA7C4ull, stride, nullptr);
+                        unsigned char worst = 0;
+                        for (int r = 0; r < world; r++) worst = std::max(worst, recvBuf[(size_t)r * stride]);
+                        if (worst) { if (mine >= 0) proc.sideRelease(mine); return worst == 1 ? -1 : -2; }
+                    }
+                    if (mine < 0 && mine != -3) return mine;
+                    batches.push_back(SideBatch{mine >= 0 ? mine : -1, (int)n});
+                    return (int)batches.size() - 1;
+                };
+                lane = beginBatch();
                 if (lane == -1 && !laneOrder.empty()) {      // (-2: the batch fits no lane - nothing would be gained by stopping another one)
                     // every lane holds a batch with jobs still running: the oldest one gives way (what it has finished is kept)
                     const int old = laneOrder.front();
                     for (size_t q = sideScan; q < sideJobs.size(); q++) if (sideJobs[q].lane == old && sideJobs[q].state == 0) dropSide((int32_t)q);
-                    lane = proc.sideBegin(sub.data() + nCrit, subView.data() + nCrit, (int64_t)(sub.size() - nCrit), nViews, vmarks.data(), (int64_t)vmarks.size());
+                    lane = beginBatch();
                 }
                 st.processMs += msSince(tp);
             }
@@ -664,7 +758,6 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             if (lane >= 0) {
                 st.sideBatches++; st.sideJobs += (int64_t)(jobs.size() - nCrit);
                 laneOrder.push_back(lane);
-                lanePending[(size_t)lane] = (int)(jobs.size() - nCrit);
                 for (size_t k = nCrit; k < jobs.size(); k++) {
                     const Job& jb = jobs[k];
                     if (jb.isF) st.conflictSeeds++;
@@ -672,6 +765,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     if (ref >= 0) dropSide(ref);     // (a job the dry run found unfit was dropped there already)
                     ref = (int32_t)sideJobs.size();
                     sideJobs.push_back(SideJob{jb.seed, jb.isF, jb.set, epoch, lane, (int64_t)(k - nCrit), 0});
+                    sideSent.push_back(0);
                 }
             }
             for (size_t k = 0; k < nSync; k++) {

@@ -641,10 +641,12 @@ int main(int argc, char** argv)
                 if (nb != (int64_t)blocks.size() || st.blocks_found != es.blocksFound || st.failures != es.failures) diffs++;
                 for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
                     if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
-                fprintf(stderr, "find-ranks rank %d/%d: blocks %zu/%lld failures %lld/%lld rounds %lld job launches %lld (%lld jobs, %lld used) views %lld exchanges %lld diffs %d\n", r, world,
+                fprintf(stderr, "find-ranks rank %d/%d: blocks %zu/%lld failures %lld/%lld rounds %lld job launches %lld (%lld jobs, %lld used) views %lld exchanges %lld | side lanes: %lld batches, %lld jobs, %lld taken, %lld void, %lld failed | diffs %d\n", r, world,
                         blocks.size(), (long long)nb, (long long)es.failures, (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches,
-                        (long long)es.recomputedSeeds, (long long)es.jobsUsed, (long long)es.viewsBuilt, (long long)es.exchanges, diffs);
+                        (long long)es.recomputedSeeds, (long long)es.jobsUsed, (long long)es.viewsBuilt, (long long)es.exchanges, (long long)es.sideBatches, (long long)es.sideJobs,
+                        (long long)es.sideTaken, (long long)es.sideVoid, (long long)es.sideFailed, diffs);
                 if (es.exchanges == 0) { fprintf(stderr, "FAIL: no exchange happened\n"); bad++; }
+                if (getenv("EMU_SIDE_LANES") && es.recomputeLaunches > 2 && es.sideBatches == 0) { fprintf(stderr, "FAIL: side lanes asked for but no batch ran in the background\n"); bad++; }
                 bad += diffs;
             }
         } else { fprintf(stderr, "unknown mode\n"); return 2; }

@@ -29,6 +29,9 @@ CASES = [
     # configs 4 / 5 (k = 25, many chromosomes, repeat families filtered by a = 150) at the size of a parity test
     ("config4_primates8_test", "primates8_test", 150),
     ("config5_mice16_test", "mice16_test", 150),
+    # ... and at the Gbp scale one box generates in about a minute (8 x 24 chromosomes = 1.24 Gbp, 16 x 20 = 1.0 Gbp)
+    ("config4_primates8_scaled", "primates8_scaled", 150),
+    ("config5_mice16_scaled", "mice16_scaled", 150),
 ]
 
 

@@ -59,11 +59,17 @@ def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
     assert len(re.findall(r"rank \d ok ", r.stdout)) == 2, r.stdout[-500:]
 
 
-@pytest.mark.parametrize("name,ranks,env", [("inv_k25", 2, {}), ("nruns_abund", 3, {"EMU_VIEWS": "3"}), ("tandem4", 4, {"EMU_ROUNDS": "7"})])
+@pytest.mark.parametrize("name,ranks,env", [("inv_k25", 2, {}), ("nruns_abund", 3, {"EMU_VIEWS": "3"}), ("tandem4", 4, {"EMU_ROUNDS": "7"}),
+                                            # the multi-rank engine is the single-rank engine: asynchronous job batches dealt to the ranks' side lanes, results
+                                            # published through collective exchanges (batches computed at once / late / visible late / refused by a lane)
+                                            ("nruns_abund", 2, {"EMU_SIDE_LANES": "2"}), ("tandem4", 3, {"EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "EMU_SIDE_DELAY": "2", "EMU_ROUNDS": "8"}),
+                                            ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16"}),
+                                            ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"})])
 def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, env):
     """The multi-rank round engine with the wave emulator as each rank's device: every launch (rounds AND job launches against
     predicted `used` views) is dealt to the ranks, per-seed results and REAL footprints cross pack / all-gather / unpack, every
-    rank commits identically and ends with the reference's block list (emu_check find-ranks)."""
+    rank commits identically and ends with the reference's block list (emu_check find-ranks). With side lanes a stop's speculative
+    jobs run in the background of every rank and their results are published through exchangeSide."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Case
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "all"])
@@ -71,5 +77,5 @@ def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, en
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "emu_check"), c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), "find-ranks",
                         str(tmp_path / "emu")], capture_output=True, text=True, env=dict(os.environ, EMU_NOSTATS="1", EMU_THREADS="2", EMU_RANKS=str(ranks), **env))
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = re.findall(r"find-ranks rank \d+/%d: .* exchanges (\d+) diffs 0" % ranks, r.stderr)
+    lines = re.findall(r"find-ranks rank \d+/%d: .* exchanges (\d+) .*diffs 0" % ranks, r.stderr)
     assert len(lines) == ranks and all(int(x) > 0 for x in lines), r.stderr[-1000:]
