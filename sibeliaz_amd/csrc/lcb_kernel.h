@@ -1033,68 +1033,64 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
             positive = ((int32_t)occ.rec.w == vertex);               // JunctionIterator::IsPositiveStrand
-            // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g (LDS work first: the chromosome bounds and `used`
-            // words of the occurrence are still in flight)
-            uint32_t a = 0, b = n;
-            while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
-            u = a;
-            uint32_t x = 0, p = 0, xFl = 0, pFl = 0;
-            if (u < n) { x = oIdx[u]; xFl = S.iFlags[x]; }
-            if (u > 0) { p = oIdx[u - 1]; pFl = S.iFlags[p]; }
+            // instanceSet.upper_bound(Instance(seqIt, 0)): the number of keys <= g, by binary descent over power-of-two steps - the trip
+            // count depends on n only, so the loop is wave-uniform (no exec-mask bookkeeping per step); LDS work first: the chromosome
+            // bounds and `used` words of the occurrence are still in flight
+            for (uint32_t step = n ? 1u << (63u - (uint32_t)__clzll((long long)n)) : 0u; step; step >>= 1) {
+                const uint32_t t = u + step;
+                const uint32_t key = oKey[(t <= n ? t : n) - 1u];
+                if (t <= n && key <= g) u = t;
+            }
+            // Both neighbours and the candidate are read whether or not they are needed (indices clamped into the index): three rounds
+            // of independent LDS (big / huge: global) reads instead of five dependent ones
+            uint32_t x = 0, p = 0;
+            if (n) { x = oIdx[u < n ? u : n - 1u]; p = oIdx[u ? u - 1u : 0u]; }
+            const uint32_t xFl = n ? S.iFlags[x] : 0u, pFl = n ? S.iFlags[p] : 0u;
+            const uint32_t xf = n ? S.iFrontG[x] : 0u, xb = n ? S.iBackG[x] : 0u;
             const bool hasX = u < n && (xFl >> LCB_FLAG_BITS) == chr;
             const bool hasP = u > 0 && (pFl >> LCB_FLAG_BITS) == chr;
-            bool skip = false;
-            if (hasX) {                                              // Instance::Within (path.h:170-175)
-                const uint32_t f = S.iFrontG[x], bk = S.iBackG[x];
-                skip = g >= (f < bk ? f : bk) && g <= (f < bk ? bk : f);
-            }
-            if (skip) act = LCB_ACT_SKIP;
-            else {
-                usesP = BACK ? positive : !positive;
-                const bool has = usesP ? hasP : hasX;
-                bool compat = false;
-                uint32_t cFl = 0;
-                if (has) {
-                    cand = usesP ? p : x;
-                    cFl = usesP ? pFl : xFl;
-                    if (STATS) stCall = 1;
-                    const bool cpos = (cFl & LCB_FLAG_POS) != 0;
-                    if (cpos == positive) {                          // path.h:382-385
-                        const uint32_t cg = BACK ? S.iBackG[cand] : S.iFrontG[cand];
-                        const uint32_t cp = BACK ? S.iBackPos[cand] : S.iFrontPos[cand];
-                        const int32_t cd = BACK ? S.iBackDist[cand] : S.iFrontDist[cand];
-                        // Compatible(start, end, e): BACK: start = cand.Back(), end = seqIt; FRONT: start = seqIt, end = cand.Front()
-                        const int64_t startPos = BACK ? cp : pos, endPos = BACK ? pos : cp;
-                        const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
-                        const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
-                        const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
-                        if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
-                        bool okDist = realDiff >= 0;
-                        if (okDist && (realDiff > B || ancestralDiff > B)) {
-                            // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
-                            const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
-                            const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
-                            okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
-                            if (okDist && !BACK) {
-                                const int32_t idE = T.posId[ge];
-                                okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
-                            }
-                        }
-                        compat = okDist && !lcb_range_any_used_c(S.U, occ, ga, gb);
-                        // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
-                        // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
-                        // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
-                        // Equal path distance <=> same vertex (distances are strictly monotone along the path).
-                        if (cd == distance) compat = false;
+            const bool skip = hasX && g >= (xf < xb ? xf : xb) && g <= (xf < xb ? xb : xf);     // Instance::Within (path.h:170-175)
+            usesP = BACK ? positive : !positive;
+            const bool has = !skip && (usesP ? hasP : hasX);
+            cand = usesP ? p : x;
+            const uint32_t cFl = usesP ? pFl : xFl;
+            const uint32_t cg = n ? (BACK ? S.iBackG[cand] : S.iFrontG[cand]) : 0u;
+            const uint32_t cp = n ? (BACK ? S.iBackPos[cand] : S.iFrontPos[cand]) : 0u;
+            const int32_t cd = n ? (BACK ? S.iBackDist[cand] : S.iFrontDist[cand]) : 0;
+            bool compat = false;
+            if (STATS && has) stCall = 1;
+            if (has && ((cFl & LCB_FLAG_POS) != 0) == positive) {    // path.h:382-385
+                // Compatible(start, end, e): BACK: start = cand.Back(), end = seqIt; FRONT: start = seqIt, end = cand.Front()
+                const int64_t startPos = BACK ? cp : pos, endPos = BACK ? pos : cp;
+                const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
+                const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
+                const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
+                if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
+                bool okDist = realDiff >= 0;
+                if (okDist && (realDiff > B || ancestralDiff > B)) {
+                    // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
+                    const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
+                    const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
+                    okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
+                    if (okDist && !BACK) {
+                        const int32_t idE = T.posId[ge];
+                        okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
                     }
                 }
-                lo = occ.lo;
-                usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
-                if (compat) {
-                    const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
-                    act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
-                } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
+                compat = okDist && !lcb_range_any_used_c(S.U, occ, ga, gb);
+                // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
+                // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
+                // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
+                // Equal path distance <=> same vertex (distances are strictly monotone along the path).
+                if (cd == distance) compat = false;
             }
+            lo = occ.lo;
+            usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
+            if (skip) act = LCB_ACT_SKIP;
+            else if (compat) {
+                const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
+                act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
+            } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
         }
         const uint64_t tq2 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
         if (PROF && LCB_PROF_PUSH) S.pfTWaitB += tq2 - tq1;
@@ -1832,10 +1828,32 @@ __device__ inline void lcb_bits_set(uint32_t* bits, uint32_t a, uint32_t b)
     }
 }
 
+// any set bit of `bits` in [a, b)? For ranges of thousands of positions: the words are requested eight at a time (independent loads,
+// one latency per batch instead of one per word) and read past the L1 like lcb_bits_any.
+__device__ inline bool lcb_bits_any_long(const uint32_t* bits, uint32_t a, uint32_t b)
+{
+    if (a >= b) return false;
+    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    for (uint32_t w = wa; w <= wb; w += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) v[k] = w + k <= wb ? __hip_atomic_load(bits + w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (w == wa) v[0] &= ma;
+        if (wb - w < 8) {
+            const uint32_t last = wb - w;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) if (k == last) v[k] &= mb;
+        }
+        if (v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | v[7]) return true;
+    }
+    return false;
+}
+
 template <int NW>
 __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
 {
-    __shared__ uint32_t sFlag[8];          // [0] a seed of the phase has no final result yet, [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
+    __shared__ uint32_t sFlag[8];          // [0] phase flags (bit 0: a seed without a final result, 1: a seed with a result, 2: a seed with a block), [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
     __shared__ uint32_t sPage[LCB_COMMIT_PAGES / 32];      // coarse summary of delta
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
     if (tid == 0) { sFlag[2] = A.state[LCB_CS_MARKED]; sFlag[5] = A.state[LCB_CS_NCOMMITTED]; sFlag[6] = A.state[LCB_CS_NEXT]; sFlag[7] = A.state[LCB_CS_STOPKIND]; }
@@ -1857,68 +1875,85 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
         __syncthreads();                   // (sFlag is read below the previous iteration's writes)
         if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; sFlag[3] = 0; }
         __syncthreads();
-        // (0) every seed of the phase has its final result (bit 0: one has not; bit 1: one has a result, i.e. is not dead)
-        for (uint32_t q = ps + tid; q < pe; q += nT) { const uint32_t r = A.roundState[q]; if (r != LCB_RS_DEAD) atomicOr(&sFlag[0], r == LCB_RS_NONE ? 1u : 2u); }
+        // (0) every seed of the phase has its final result: all threads look at the seeds' states at once (a walk over the 256 states
+        // of a phase by one wavefront costs a dependent load per seed - 30 ms per round of config 3 when the kernel did that)
+        for (uint32_t q = ps + tid; q < pe; q += nT) {
+            const uint32_t r = A.roundState[q];
+            if (r == LCB_RS_NONE) atomicOr(&sFlag[0], 1u);
+            else if (r == LCB_RS_DONE) atomicOr(&sFlag[0], A.roundOut[q].nInst > 1u ? 6u : 2u);
+        }
         __syncthreads();
-        if (sFlag[0] & 1u) break;          // a later launch of the round brings it: the next invocation goes on here
-        if (!(sFlag[0] & 2u)) { ps = pe; continue; }     // only dead seeds: nothing to validate, nothing to commit
-        // (a) every phase-start result of the phase is still exact (nothing to check before the first commit of the round)
+        const uint32_t flags = sFlag[0];
+        if (flags & 1u) break;             // a later launch of the round brings it: the next invocation goes on here
+        if (!(flags & 2u) || (!marked && !(flags & 4u))) { ps = pe; continue; }     // only dead seeds, or nothing to validate against and nothing to commit
+        // (a) every phase-start result of the phase is still exact (nothing to check before the first commit of the round): the wavefronts
+        // take the seeds of the phase 64 at a time (lanes = seeds: which of them have a result), then one seed at a time (lanes = intervals)
         if (marked) {
-            for (uint32_t q = ps + wave; q < pe; q += NW) {
-                if (A.roundState[q] != LCB_RS_DONE) continue;
-                const LcbSeedOut o = A.roundOut[q];
-                bool hit = false;
-                for (uint32_t k = lane; k < o.nFp; k += 64) {
-                    const uint2 f = A.fpArena[o.fpOff + k];
-                    const uint32_t a = f.x, b = f.y < A.nPos ? f.y : A.nPos - 1u;                 // positions a .. b
-                    bool page = false;
-                    for (uint32_t q = a >> sh; q <= b >> sh && !page; q++) page = ((sPage[q >> 5] >> (q & 31)) & 1u) != 0;
-                    if (page && lcb_bits_any(A.delta, a, b + 1u)) hit = true;
+            for (uint32_t c0 = ps + 64u * wave; c0 < pe; c0 += 64u * NW) {
+                const uint32_t q = c0 + lane;
+                unsigned long long done = __ballot(q < pe && A.roundState[q] == LCB_RS_DONE);
+                while (done) {
+                    const uint32_t qq = c0 + (uint32_t)__ffsll((long long)done) - 1u;
+                    done &= done - 1;
+                    const uint32_t nFp = lcb_rfl(A.roundOut[qq].nFp);
+                    const unsigned long long fpOff = A.roundOut[qq].fpOff;
+                    bool hit = false;
+                    for (uint32_t k = lane; k < nFp; k += 64) {
+                        const uint2 f = A.fpArena[fpOff + k];
+                        const uint32_t a = f.x, b = f.y < A.nPos ? f.y : A.nPos - 1u;                 // positions a .. b
+                        bool page = false;
+                        for (uint32_t pg = a >> sh; pg <= b >> sh && !page; pg++) page = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
+                        if (page && lcb_bits_any_long(A.delta, a, b + 1u)) hit = true;
+                    }
+                    if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
                 }
-                if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
             }
             __syncthreads();
             if (sFlag[1]) { stopAt = ps; stopKind = 1; break; }
         }
-        // (b) ordered commit: wavefront 0, lanes over the instances of a seed
-        if (wave == 0) {
+        // (b) ordered commit: wavefront 0 finds the seeds with a block 64 at a time, then lanes = the instances of a seed
+        if (wave == 0 && (flags & 4u)) {
             uint32_t kind = 0, at = 0;
-            for (uint32_t q = ps; q < pe; q++) {
-                if (A.roundState[q] != LCB_RS_DONE) continue;
-                const LcbSeedOut o = A.roundOut[q];
-                if (o.nInst <= 1) continue;                                              // blocksfinder.h:375
-                const uint4* inst = A.arena + o.arenaOff;
-                bool conflict = false;
-                for (uint32_t k = lane; k < o.nInst; k += 64) {
-                    const uint4 in = inst[k];
-                    if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
-                    const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
-                    if (lcb_bits_any(A.used, lo, hi)) conflict = true;
-                }
-                if (__ballot(conflict) != 0) { at = q; kind = 2; break; }
-                LCB_WAVE_SYNC();
-                for (uint32_t k = lane; k < o.nInst; k += 64) {                          // Finalize: MarkUsed over [Front, Back)
-                    const uint4 in = inst[k];
-                    A.chrStamp[in.x] = ph + 1;
-                    const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
-                    if (hi > lo) {
-                        lcb_bits_set(A.used, lo, hi);
-                        lcb_bits_set(A.delta, lo, hi);
-                        for (uint32_t q = lo >> sh; q <= (hi - 1u) >> sh; q++) atomicOr(&sPage[q >> 5], 1u << (q & 31));
-                        const uint32_t slot = atomicAdd(A.deltaCount, 1u);
-                        if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};
+            for (uint32_t c0 = ps; c0 < pe && !kind; c0 += 64u) {
+                const uint32_t q0 = c0 + lane;
+                unsigned long long cand = __ballot(q0 < pe && A.roundState[q0] == LCB_RS_DONE && A.roundOut[q0].nInst > 1u);    // blocksfinder.h:375
+                while (cand) {
+                    const uint32_t q = c0 + (uint32_t)__ffsll((long long)cand) - 1u;
+                    cand &= cand - 1;
+                    const uint32_t nInst = lcb_rfl(A.roundOut[q].nInst);
+                    const uint4* inst = A.arena + A.roundOut[q].arenaOff;
+                    bool conflict = false;
+                    for (uint32_t k = lane; k < nInst; k += 64) {
+                        const uint4 in = inst[k];
+                        if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
+                        const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                        if (lcb_bits_any_long(A.used, lo, hi)) conflict = true;
                     }
+                    if (__ballot(conflict) != 0) { at = q; kind = 2; break; }
+                    LCB_WAVE_SYNC();
+                    for (uint32_t k = lane; k < nInst; k += 64) {                            // Finalize: MarkUsed over [Front, Back)
+                        const uint4 in = inst[k];
+                        A.chrStamp[in.x] = ph + 1;
+                        const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                        if (hi > lo) {
+                            lcb_bits_set(A.used, lo, hi);
+                            lcb_bits_set(A.delta, lo, hi);
+                            for (uint32_t pg = lo >> sh; pg <= (hi - 1u) >> sh; pg++) atomicOr(&sPage[pg >> 5], 1u << (pg & 31));
+                            const uint32_t slot = atomicAdd(A.deltaCount, 1u);
+                            if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};
+                        }
+                    }
+                    LCB_WAVE_SYNC();
+                    if (lane == 0) A.committed[nCommitted] = q;
+                    nCommitted++;
+                    marked = true;
                 }
-                LCB_WAVE_SYNC();
-                if (lane == 0) A.committed[nCommitted] = q;
-                nCommitted++;
-                marked = true;
             }
             if (lane == 0) { sFlag[2] = marked ? 1u : 0u; sFlag[3] = kind; sFlag[4] = at; sFlag[5] = nCommitted; }
         }
         __syncthreads();
-        marked = sFlag[2] != 0; nCommitted = sFlag[5];                               // what wavefront 0 did is known to all
-        if (sFlag[3]) { stopKind = sFlag[3]; stopAt = sFlag[4]; break; }
+        if (flags & 4u) { marked = sFlag[2] != 0; nCommitted = sFlag[5]; }              // what wavefront 0 did is known to all
+        if ((flags & 4u) && sFlag[3]) { stopKind = sFlag[3]; stopAt = sFlag[4]; break; }
         ps = pe;
     }
     if (tid == 0) {
