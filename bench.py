@@ -17,7 +17,7 @@ The JSON line also carries
                 the engine) / average launch duration, measured in this run with HIP events on the kernels' stream; against the
                 8 TB/s HBM peak, with this GPU's measured STREAM-triad rate beside it. `traffic` (PMC) cannot be measured inside
                 this run and is null; `traffic_profiled` quotes the per-launch figure of the committed rocprofv3 --pmc
-                passes of this same command (profiles/r02/pmc_traffic.json) for the default workload.
+                passes of this same command (profiles/r04/pmc_traffic.json) for the default workload.
   cpu_baseline  the UNMODIFIED reference sibeliaz-lcb (oracle/_ref, built from /root/reference in the build container) timed
                 on this box's host cores: once at -t 32 (the cap of the reference's wrapper script, sibeliaz:139) on the WHOLE
                 workload `value` is measured on, its blocks_coords.gff compared (md5) with the timed run's; and on bounded samples
@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--workload", default="ecoli62")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-cpu-baseline", action="store_true", help="time the reference on the bounded samples only (not on the whole workload)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=360.0, help="seconds all legs of the reference protocol may take together (every leg is cut off at what is left)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stats-mode counting pass (exploration runs)")
     ap.add_argument("--recount", action="store_true", help="repeat the stats-mode counting pass even if the workload's event counts are known")
     ap.add_argument("--verify-counts", action="store_true", help="count the events again (a 3-minute stats-mode pass) when the committed counts were counted by a build of other sources; "
@@ -417,10 +418,10 @@ def main():
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command
         # (scripts/gpu_r2_evidence.sh), committed with the profile summaries; only for the workload they were taken on
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
         if args.workload == "ecoli62" and n_gpus == 1 and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+            traffic_src = "profiles/r04/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
         line = {
             "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -470,7 +471,7 @@ def main():
                                   "gff_md5_equal_to_timed_run": r.returncode == 0 and md5(os.path.join(cli_out, "blocks_coords.gff")) == md5(gff)}
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload in SAMPLES:
             try:
-                cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff)
+                cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff, args.cpu_baseline_budget)
                 if cb:
                     line["cpu_baseline"] = cb
             except Exception as e:       # the reference's legs must never cost the line itself

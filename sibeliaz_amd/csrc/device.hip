@@ -135,20 +135,9 @@ __global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* liv
 }
 
 // The device-resident ordered commit of a round's clean prefix (lcb_commit_body, lcb_kernel.h): one workgroup, chained behind every
-// launch of a round; lcb_commit_unmark_kernel clears the previous round's marks out of the delta bitmap.
+// launch of a round.
 #define LCB_NW_COMMIT 16
 __global__ __launch_bounds__(64 * LCB_NW_COMMIT) void lcb_commit_kernel(LcbCommitArgs A) { lcb_commit_body<LCB_NW_COMMIT>(A); }
-// Before the next round the bits of `delta` that the round's commit set are cleared again through the list of its ranges (a bitmap-sized
-// memset per round would cost more than the commit itself: rounds of one phase come by the thousand).
-__global__ __launch_bounds__(256) void lcb_commit_unmark_kernel(uint32_t* delta, const uint2* list, uint32_t n)
-{
-    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint32_t lo = list[r].x, hi = list[r].y;
-        if (hi <= lo) continue;
-        const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
-        for (uint32_t w = w0 + threadIdx.x; w <= w1; w += 256) delta[w] = 0;      // whole words: every set bit of delta lies in a listed range
-    }
-}
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
 __global__ __launch_bounds__(256) void lcb_triad_kernel(float4* a, const float4* b, const float4* c, float s, size_t n)
@@ -226,15 +215,15 @@ struct lcb_device_impl {
     uint32_t lanePoolPages = 0;                  // private pages per lane (fixed: the live bitmap cannot move while a lane is running)
     int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0, sideNoFit = 0;
     // device-resident commit of a round (processRound): headers of the round's final results and their state per seed of the round,
-    // marks of the current round (bitmap + the list of its ranges), per-chromosome phase stamps, the commit kernel's state
+    // the list of the ranges the current round's commits marked, per-chromosome phase stamps, the commit kernel's state
     struct RoundCtx {
         bool active = false;                     // the current process() call is a round whose commit runs behind its launches
         uint32_t n = 0, phase = 0;
         LcbSeedOut* dOut = nullptr; uint32_t* dState = nullptr; size_t cap = 0;      // [cap] seeds of a round
-        uint32_t* dDelta = nullptr; uint32_t* dChrStamp = nullptr;
-        uint2* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 20;
+        uint32_t* dChrStamp = nullptr;
+        uint2* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 16;      // ranges marked by the current round's commits
         uint32_t* hIdx = nullptr;                // pinned: launch-local seed index -> index in the round
-        uint32_t* hState = nullptr;              // pinned: LCB_CS_* words, then the count of the delta list as of the last read
+        uint32_t* hState = nullptr;              // pinned: LCB_CS_* words
         uint32_t* hCommitted = nullptr; size_t committedCap = 0;                   // pinned
         bool arenaFresh = true;                  // the next launch of the round is its first: the arena allocators start at 0
         int64_t rounds = 0, kernels = 0, abandoned = 0;
@@ -389,7 +378,7 @@ struct lcb_device_impl {
         if (round) {
             // the ordered commit of the round goes on as far as the results reach, behind the kernels that produced them
             LcbCommitArgs A;
-            A.chrStart = T.chrStart; A.used = dUsed; A.delta = rc.dDelta; A.chrStamp = rc.dChrStamp;
+            A.chrStart = T.chrStart; A.used = dUsed; A.chrStamp = rc.dChrStamp;
             A.roundState = rc.dState; A.roundOut = rc.dOut; A.arena = hArena; A.fpArena = hFp;
             A.n = rc.n; A.phase = rc.phase; A.nPos = T.nPos;
             A.state = rc.hState; A.committed = rc.hCommitted; A.deltaList = rc.dDeltaList; A.deltaCount = rc.dDeltaCount; A.deltaCap = rc.deltaCap;
@@ -653,7 +642,7 @@ void lcb_device_destroy_impl(lcb_device* h)
             for (void* q : {(void*)L.hSeeds, (void*)L.hOut, (void*)L.hArena, (void*)L.hFp, (void*)L.hList, (void*)L.hCtl}) if (q) (void)hipHostFree(q);
             for (void* q : {(void*)L.dCtl, (void*)L.views.tab, (void*)L.views.dEntries, (void*)L.views.dVersions, (void*)L.views.dPieces, (void*)L.wide.base, (void*)L.big.base}) if (q) (void)hipFree(q);
         }
-        for (void* q : {(void*)d->rc.dOut, (void*)d->rc.dState, (void*)d->rc.dDelta, (void*)d->rc.dChrStamp, (void*)d->rc.dDeltaList, (void*)d->rc.dDeltaCount}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)d->rc.dOut, (void*)d->rc.dState, (void*)d->rc.dChrStamp, (void*)d->rc.dDeltaList, (void*)d->rc.dDeltaCount}) if (q) (void)hipFree(q);
         for (void* q : {(void*)d->rc.hIdx, (void*)d->rc.hState, (void*)d->rc.hCommitted}) if (q) (void)hipHostFree(q);
         if (d->ctlStream) (void)hipStreamDestroy(d->ctlStream);
         if (d->views.tab) (void)hipFree(d->views.tab);
@@ -1178,9 +1167,7 @@ bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t
         R.committedCap = std::max<size_t>((size_t)n, d->batchCap);
         HIP_CHECK(hipHostMalloc((void**)&R.hCommitted, R.committedCap * 4, hipHostMallocDefault));
     }
-    if (!R.dDelta) {
-        HIP_CHECK(hipMalloc((void**)&R.dDelta, d->usedWords * 4));
-        HIP_CHECK(hipMemsetAsync(R.dDelta, 0, d->usedWords * 4, d->stream));
+    if (!R.dChrStamp) {
         HIP_CHECK(hipMalloc((void**)&R.dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
         HIP_CHECK(hipMalloc((void**)&R.dDeltaList, (size_t)R.deltaCap * sizeof(uint2)));
         HIP_CHECK(hipMalloc((void**)&R.dDeltaCount, 4));
@@ -1189,11 +1176,7 @@ bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t
         HIP_CHECK(hipHostMalloc((void**)&R.hState, 64, hipHostMallocDefault));
         memset(R.hState, 0, 64);
     }
-    // the marks of the previous round leave the delta bitmap through the list of its ranges (hState[8]: their number)
-    const uint32_t nPrev = R.hState[8];
-    if (nPrev > R.deltaCap) HIP_CHECK(hipMemsetAsync(R.dDelta, 0, d->usedWords * 4, d->stream));
-    else if (nPrev) { hipLaunchKernelGGL(lcb_commit_unmark_kernel, dim3(std::min<uint32_t>(nPrev, 1024u)), dim3(256), 0, d->stream, R.dDelta, R.dDeltaList, nPrev); HIP_CHECK(hipGetLastError()); }
-    if (nPrev) HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
+    HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
     HIP_CHECK(hipMemsetAsync(R.dState, 0, (size_t)n * 4, d->stream));
     HIP_CHECK(hipMemsetAsync(R.dChrStamp, 0, ((size_t)d->g->nChr() + 1) * 4, d->stream));
     memset(R.hState, 0, 64);                     // (the stream is idle: every earlier call has been waited for)
@@ -1206,11 +1189,9 @@ bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t
     accLayout(A, offsets, inst, &fpOffsets, &fpOut);
     d->wantFp = false;
     R.active = false;
-    HIP_CHECK(hipMemcpyAsync(R.hState + 8, R.dDeltaCount, 4, hipMemcpyDeviceToHost, d->stream));
-    HIP_CHECK(hipStreamSynchronize(d->stream));
     const uint32_t next = R.hState[LCB_CS_NEXT], nCom = R.hState[LCB_CS_NCOMMITTED];
     stopKind = (int)R.hState[LCB_CS_STOPKIND]; stopAt = R.hState[LCB_CS_STOPAT];
-    if (nCom > (uint32_t)n || next > (uint32_t)n || stopKind < 0 || stopKind > 2 || (stopKind && stopAt >= (uint32_t)n)) throw LcbError("device commit: inconsistent state");
+    if (nCom > (uint32_t)n || next > (uint32_t)n || stopKind < 0 || stopKind > 3 || stopKind == 1 || (stopKind && stopAt >= (uint32_t)n)) throw LcbError("device commit: inconsistent state");
     committed.assign(R.hCommitted, R.hCommitted + nCom);
     if (stopKind == 0 && next < (uint32_t)n) { stopKind = 3; stopAt = next; }     // the commit did not get further (the round's arenas had to be reset): the host goes on from this phase
     R.rounds++;

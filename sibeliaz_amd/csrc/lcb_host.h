@@ -128,7 +128,8 @@ struct LcbProcessor {
     // processor's OWN state - until the first seed that needs a new computation. committed: the indices it committed, in order;
     // stopKind 0: the whole round is committed; 1: a phase-start result of the phase that begins at seed stopAt is void; 2: seed
     // stopAt conflicts (its phase is committed up to it); 3: the processor got no further than the phase that begins at stopAt
-    // (nothing is wrong with it). The engine assigns block ids, mirrors the marks and goes on from the stop.
+    // (nothing is wrong with it: the device hands a phase over when a footprint lies near one of the round's marks and it would have
+    // to look closer). The engine assigns block ids, mirrors the marks and goes on from the stop.
     // false: not supported (nothing was done; the engine calls process() and commits on the host).
     virtual bool processRound(const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
                               std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)

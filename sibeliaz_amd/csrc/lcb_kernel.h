@@ -1033,64 +1033,71 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
             positive = ((int32_t)occ.rec.w == vertex);               // JunctionIterator::IsPositiveStrand
-            // instanceSet.upper_bound(Instance(seqIt, 0)): the number of keys <= g, by binary descent over power-of-two steps - the trip
-            // count depends on n only, so the loop is wave-uniform (no exec-mask bookkeeping per step); LDS work first: the chromosome
-            // bounds and `used` words of the occurrence are still in flight
-            for (uint32_t step = n ? 1u << (63u - (uint32_t)__clzll((long long)n)) : 0u; step; step >>= 1) {
-                const uint32_t t = u + step;
-                const uint32_t key = oKey[(t <= n ? t : n) - 1u];
-                if (t <= n && key <= g) u = t;
-            }
-            // Both neighbours and the candidate are read whether or not they are needed (indices clamped into the index): three rounds
-            // of independent LDS (big / huge: global) reads instead of five dependent ones
-            uint32_t x = 0, p = 0;
-            if (n) { x = oIdx[u < n ? u : n - 1u]; p = oIdx[u ? u - 1u : 0u]; }
-            const uint32_t xFl = n ? S.iFlags[x] : 0u, pFl = n ? S.iFlags[p] : 0u;
-            const uint32_t xf = n ? S.iFrontG[x] : 0u, xb = n ? S.iBackG[x] : 0u;
+            // instanceSet.upper_bound(Instance(seqIt, 0)): first key > g (LDS work first: the chromosome bounds and `used`
+            // words of the occurrence are still in flight).
+            // (Measured and removed, profiles/r04/ab_fourth.txt: a wave-uniform binary descent with both neighbours and the candidate
+            // read unconditionally - three rounds of independent reads instead of five dependent ones - was 1 % SLOWER on every
+            // workload: a step is bound by the instructions the seed's wavefront issues, not by its LDS round trips.)
+            uint32_t a = 0, b = n;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
+            u = a;
+            uint32_t x = 0, p = 0, xFl = 0, pFl = 0;
+            if (u < n) { x = oIdx[u]; xFl = S.iFlags[x]; }
+            if (u > 0) { p = oIdx[u - 1]; pFl = S.iFlags[p]; }
             const bool hasX = u < n && (xFl >> LCB_FLAG_BITS) == chr;
             const bool hasP = u > 0 && (pFl >> LCB_FLAG_BITS) == chr;
-            const bool skip = hasX && g >= (xf < xb ? xf : xb) && g <= (xf < xb ? xb : xf);     // Instance::Within (path.h:170-175)
-            usesP = BACK ? positive : !positive;
-            const bool has = !skip && (usesP ? hasP : hasX);
-            cand = usesP ? p : x;
-            const uint32_t cFl = usesP ? pFl : xFl;
-            const uint32_t cg = n ? (BACK ? S.iBackG[cand] : S.iFrontG[cand]) : 0u;
-            const uint32_t cp = n ? (BACK ? S.iBackPos[cand] : S.iFrontPos[cand]) : 0u;
-            const int32_t cd = n ? (BACK ? S.iBackDist[cand] : S.iFrontDist[cand]) : 0;
-            bool compat = false;
-            if (STATS && has) stCall = 1;
-            if (has && ((cFl & LCB_FLAG_POS) != 0) == positive) {    // path.h:382-385
-                // Compatible(start, end, e): BACK: start = cand.Back(), end = seqIt; FRONT: start = seqIt, end = cand.Front()
-                const int64_t startPos = BACK ? cp : pos, endPos = BACK ? pos : cp;
-                const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
-                const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
-                const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
-                if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
-                bool okDist = realDiff >= 0;
-                if (okDist && (realDiff > B || ancestralDiff > B)) {
-                    // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
-                    const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
-                    const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
-                    okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
-                    if (okDist && !BACK) {
-                        const int32_t idE = T.posId[ge];
-                        okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
+            bool skip = false;
+            if (hasX) {                                              // Instance::Within (path.h:170-175)
+                const uint32_t f = S.iFrontG[x], bk = S.iBackG[x];
+                skip = g >= (f < bk ? f : bk) && g <= (f < bk ? bk : f);
+            }
+            if (skip) act = LCB_ACT_SKIP;
+            else {
+                usesP = BACK ? positive : !positive;
+                const bool has = usesP ? hasP : hasX;
+                bool compat = false;
+                uint32_t cFl = 0;
+                if (has) {
+                    cand = usesP ? p : x;
+                    cFl = usesP ? pFl : xFl;
+                    if (STATS) stCall = 1;
+                    const bool cpos = (cFl & LCB_FLAG_POS) != 0;
+                    if (cpos == positive) {                          // path.h:382-385
+                        const uint32_t cg = BACK ? S.iBackG[cand] : S.iFrontG[cand];
+                        const uint32_t cp = BACK ? S.iBackPos[cand] : S.iFrontPos[cand];
+                        const int32_t cd = BACK ? S.iBackDist[cand] : S.iFrontDist[cand];
+                        // Compatible(start, end, e): BACK: start = cand.Back(), end = seqIt; FRONT: start = seqIt, end = cand.Front()
+                        const int64_t startPos = BACK ? cp : pos, endPos = BACK ? pos : cp;
+                        const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
+                        const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
+                        const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
+                        if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
+                        bool okDist = realDiff >= 0;
+                        if (okDist && (realDiff > B || ancestralDiff > B)) {
+                            // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
+                            const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
+                            const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
+                            okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
+                            if (okDist && !BACK) {
+                                const int32_t idE = T.posId[ge];
+                                okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
+                            }
+                        }
+                        compat = okDist && !lcb_range_any_used_c(S.U, occ, ga, gb);
+                        // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
+                        // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
+                        // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
+                        // Equal path distance <=> same vertex (distances are strictly monotone along the path).
+                        if (cd == distance) compat = false;
                     }
                 }
-                compat = okDist && !lcb_range_any_used_c(S.U, occ, ga, gb);
-                // `inst->Back().GetVertexId() != vertex` (path.h:541; :472 for the front): a candidate that already ends at
-                // the pushed vertex — it was inserted or extended by an occurrence of an EARLIER 64-lane chunk of this very
-                // push (within a chunk the prefix rule below does the same) — is not extended again: else branch.
-                // Equal path distance <=> same vertex (distances are strictly monotone along the path).
-                if (cd == distance) compat = false;
+                lo = occ.lo;
+                usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
+                if (compat) {
+                    const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
+                    act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
+                } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
             }
-            lo = occ.lo;
-            usedS = positive ? lcb_occ_bit(occ, g) : (g > lo ? lcb_occ_bit(occ, g - 1) : false);   // JunctionSequentialIterator::IsUsed
-            if (skip) act = LCB_ACT_SKIP;
-            else if (compat) {
-                const bool fin = (cFl & (BACK ? LCB_FLAG_BACKFIN : LCB_FLAG_FRONTFIN)) != 0;
-                act = fin ? LCB_ACT_NONE : (usesP ? LCB_ACT_EXT_P : LCB_ACT_EXT_X);
-            } else act = usedS ? LCB_ACT_NONE : LCB_ACT_INSERT;
         }
         const uint64_t tq2 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
         if (PROF && LCB_PROF_PUSH) S.pfTWaitB += tq2 - tq1;
@@ -1761,31 +1768,29 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
 //   (0) a phase is entered once every seed of it has a final result (a seed that overflowed its kernel variant gets its result from a
 //       later launch of the round: the kernel returns and the invocation behind that launch goes on from the same phase);
 //   (a) phase start: the phase-start result of every seed of the phase must still be exact: no bit inside its footprint has been
-//       marked since the round was launched (the marks of this round are kept in a second bitmap, `delta`, and as a list of ranges
-//       through which the next round un-marks it);
+//       marked since the round was launched. The kernel decides that with a coarse summary of the round's marks in LDS (one bit per
+//       2^pageShift positions): a footprint interval none of whose pages holds a mark contains no marked bit. Where an interval
+//       touches a marked page the kernel does NOT look closer - it hands the round over to the host at that phase (stop kind 3), whose
+//       range sets answer the exact question in a microsecond; on the device the exact test of one interval is hundreds of dependent
+//       loads (measured: 14-48 ms per round of config 3, more than the round's process kernels);
 //   (b) ordered commit: a result of more than one instance whose instances touch no used position on the chromosomes committed to
 //       earlier in this phase (the weak check, blocksfinder.h:377-398) is finalised: its [Front, Back) ranges are marked in the live
-//       bitmap (and in delta) and the seed is appended to the committed list -
-// and stops for good at the first seed that needs a new computation (a void phase-start result, or a conflict: blocksfinder.h:406).
+//       bitmap (and noted in the list of the round's marks) and the seed is appended to the committed list -
+// and stops for good at the first seed that needs a new computation (a conflict: blocksfinder.h:406) or a closer look (kind 3).
 // The host reads the state words and the committed list, assigns the block ids / BlockInstances of the committed seeds
 // (blocksfinder.h:314-329), mirrors the marks in its own copy of the bitmap and goes on from the stop with its planner.
 // ONE workgroup: phases are sequential by definition (a phase's validation needs the marks of the phases before it); inside a phase
 // the validation is spread over the wavefronts (lanes = footprint intervals) and the commit is lane-parallel over instances and words.
-// A footprint interval spans thousands of positions (an instance and the look-ahead windows around it), so testing it word by word
-// against the delta bitmap costs hundreds of dependent loads per lane - measured on the MI355X: 48 ms per round of config 3, twice the
-// pass time. The round's marks are few, so a coarse summary of delta in LDS (one bit per 2^pageShift positions, rebuilt from the list
-// of ranges at the start of an invocation) answers almost every interval with two or three LDS words; only intervals that touch a
-// marked page are tested exactly.
+// The summary of the round's marks is rebuilt from the list of their ranges at the start of an invocation.
 enum { LCB_CS_NEXT = 0,        // first seed of the next phase to commit (everything before it is committed or passed over)
        LCB_CS_NCOMMITTED,      // entries of the committed list
-       LCB_CS_STOPKIND,        // 0 none so far, 1 a phase-start result of the phase at STOPAT is void, 2 seed STOPAT conflicts (its phase is committed up to it)
+       LCB_CS_STOPKIND,        // 0 none so far, 2 seed STOPAT conflicts (its phase is committed up to it), 3 a footprint of the phase at STOPAT lies near a mark: the host decides
        LCB_CS_STOPAT,
        LCB_CS_MARKED,          // something was committed in this round
        LCB_CS_WORDS = 8 };
 struct LcbCommitArgs {
     const uint32_t* chrStart;      // [nChr+1]
     uint32_t* used;                // the live bitmap (marked here)
-    uint32_t* delta;               // marks since the round was launched
     uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared per round
     const uint32_t* roundState;    // [n] LCB_RS_* per seed of the round
     const LcbSeedOut* roundOut;    // [n] headers of the final results
@@ -1794,10 +1799,10 @@ struct LcbCommitArgs {
     uint32_t n, phase, nPos;       // seeds of the round, seeds per phase (256), positions of the bitmaps
     uint32_t* state;               // LCB_CS_* (host-visible; one thread reads and writes it)
     uint32_t* committed;           // out (host-visible): round indices of the committed seeds, in order
-    uint2* deltaList;              // ranges marked in `delta` this round ...
-    uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete and the host clears the whole bitmap)
+    uint2* deltaList;              // the ranges this round's commits have marked so far (the summary of a later invocation is rebuilt from them) ...
+    uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete: every page then counts as marked)
     uint32_t deltaCap;
-    uint32_t pageShift;            // the coarse LDS summary of delta has one bit per 2^pageShift positions (nPos >> pageShift <= LCB_COMMIT_PAGES)
+    uint32_t pageShift;            // the coarse LDS summary of the round's marks has one bit per 2^pageShift positions (nPos >> pageShift <= LCB_COMMIT_PAGES)
 };
 #define LCB_COMMIT_PAGES 32768u    // bits of the summary (4 KB of LDS)
 
@@ -1854,7 +1859,7 @@ template <int NW>
 __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
 {
     __shared__ uint32_t sFlag[8];          // [0] phase flags (bit 0: a seed without a final result, 1: a seed with a result, 2: a seed with a block), [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
-    __shared__ uint32_t sPage[LCB_COMMIT_PAGES / 32];      // coarse summary of delta
+    __shared__ uint32_t sPage[LCB_COMMIT_PAGES / 32];      // coarse summary of the round's marks
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
     if (tid == 0) { sFlag[2] = A.state[LCB_CS_MARKED]; sFlag[5] = A.state[LCB_CS_NCOMMITTED]; sFlag[6] = A.state[LCB_CS_NEXT]; sFlag[7] = A.state[LCB_CS_STOPKIND]; }
     __syncthreads();
@@ -1901,15 +1906,13 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                     for (uint32_t k = lane; k < nFp; k += 64) {
                         const uint2 f = A.fpArena[fpOff + k];
                         const uint32_t a = f.x, b = f.y < A.nPos ? f.y : A.nPos - 1u;                 // positions a .. b
-                        bool page = false;
-                        for (uint32_t pg = a >> sh; pg <= b >> sh && !page; pg++) page = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
-                        if (page && lcb_bits_any_long(A.delta, a, b + 1u)) hit = true;
+                        for (uint32_t pg = a >> sh; pg <= b >> sh && !hit; pg++) hit = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
                     }
                     if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
                 }
             }
             __syncthreads();
-            if (sFlag[1]) { stopAt = ps; stopKind = 1; break; }
+            if (sFlag[1]) { stopAt = ps; stopKind = 3; break; }
         }
         // (b) ordered commit: wavefront 0 finds the seeds with a block 64 at a time, then lanes = the instances of a seed
         if (wave == 0 && (flags & 4u)) {
@@ -1937,7 +1940,6 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                         const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
                         if (hi > lo) {
                             lcb_bits_set(A.used, lo, hi);
-                            lcb_bits_set(A.delta, lo, hi);
                             for (uint32_t pg = lo >> sh; pg <= (hi - 1u) >> sh; pg++) atomicOr(&sPage[pg >> 5], 1u << (pg & 31));
                             const uint32_t slot = atomicAdd(A.deltaCount, 1u);
                             if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};

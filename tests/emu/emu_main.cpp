@@ -317,7 +317,7 @@ struct EmuProcessor : LcbProcessor {
     // device-resident commit of a round (processRound): the commit kernel body of lcb_kernel.h on EMU_COMMIT_NW (default 4) emulated
     // wavefronts, on the emulator's bitmap, invoked like on the device behind every "launch" of the round - once after the first launch
     // (seeds that overflowed their kernel variant have no final result yet: the kernel must wait for them) and once after the retries
-    std::vector<uint32_t> dcDelta, dcStamp, dcCommitted, dcState, dcRound;
+    std::vector<uint32_t> dcStamp, dcCommitted, dcState, dcRound;
     std::vector<LcbSeedOut> dcOut;
     std::vector<uint2> dcList;
     uint32_t dcDeltaCount = 0;
@@ -327,11 +327,6 @@ struct EmuProcessor : LcbProcessor {
     {
         if (getenv("EMU_HOST_COMMIT") || n <= 0) return false;
         static_assert(sizeof(lcb_instance) == sizeof(uint4) && sizeof(lcb_fp) == sizeof(uint2), "layouts the commit kernel reads");
-        // the previous round's marks leave the delta bitmap through the list of their ranges, as on the device
-        if (dcDelta.size() != emu->usedWords) dcDelta.assign(emu->usedWords, 0u);
-        if (dcDeltaCount > dcList.size()) dcDelta.assign(emu->usedWords, 0u);
-        else for (uint32_t r = 0; r < dcDeltaCount; r++) for (uint32_t w = dcList[r].x >> 5; w <= (dcList[r].y - 1) >> 5; w++) dcDelta[w] = 0;
-        for (uint32_t w : dcDelta) if (w) throw LcbError("emu: the delta bitmap was not clean at the start of a round");
         dcDeltaCount = 0;
         dcList.assign(getenv("EMU_DELTA_CAP") ? (size_t)atoi(getenv("EMU_DELTA_CAP")) : 4096, uint2{0u, 0u});
         dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign((size_t)n, 0u); dcState.assign(LCB_CS_WORDS, 0u);
@@ -351,7 +346,7 @@ struct EmuProcessor : LcbProcessor {
                 dcRound[(size_t)i] = (o.nInst == 0 && o.nFp == 0) ? LCB_RS_DEAD : LCB_RS_DONE;
             }
             LcbCommitArgs A;
-            A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.delta = dcDelta.data(); A.chrStamp = dcStamp.data();
+            A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.chrStamp = dcStamp.data();
             A.roundState = dcRound.data(); A.roundOut = dcOut.data(); A.arena = emu->arena.data(); A.fpArena = emu->fpArena.data();
             A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
             A.state = dcState.data(); A.committed = dcCommitted.data(); A.deltaList = dcList.data(); A.deltaCount = &dcDeltaCount; A.deltaCap = (uint32_t)dcList.size();

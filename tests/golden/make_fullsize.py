@@ -49,7 +49,10 @@ def main():
     ref = os.path.join(ROOT, "oracle", "_ref", "sibeliaz-lcb-ref")
     only = set(sys.argv[2:])
     target = os.path.join(ROOT, "tests", "golden", "fullsize.json")
+    target_scaled = os.path.join(ROOT, "tests", "golden", "fullsize_scaled.json")     # the Gbp-scale cases: checked by scripts/check_fullsize_scaled.py, not by the default suite
     out = json.load(open(target)) if only and os.path.exists(target) else {}
+    if only and os.path.exists(target_scaled):
+        out.update(json.load(open(target_scaled)))
     for name, wl, a in CASES:
         if only and name not in only:
             continue
@@ -73,9 +76,12 @@ def main():
             "coverage": re.search(r"Coverage: ([0-9.]+)", banner).group(1),
         }
         print(name, out[name]["gff_sha256"], out[name]["blocks_found"], flush=True)
-    with open(target, "w") as f:
-        json.dump(out, f, indent=1, sort_keys=True)
-        f.write("\n")
+    for path, keep in ((target, lambda k: not k.endswith("_scaled")), (target_scaled, lambda k: k.endswith("_scaled"))):
+        part = {k: v for k, v in out.items() if keep(k)}
+        if part:
+            with open(path, "w") as f:
+                json.dump(part, f, indent=1, sort_keys=True)
+                f.write("\n")
 
 
 if __name__ == "__main__":

@@ -30,10 +30,10 @@ def _sha256(path):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("name", sorted(FULL))
-def test_fullsize_gff_equals_reference(built, name, tmp_path):
+def check_case(name, g, out_dir):
+    """One full-size case through the C ABI against the reference's hashes (also used by scripts/check_fullsize_scaled.py for the
+    Gbp-scale cases of tests/golden/fullsize_scaled.json, which the default suite cannot afford: 2.5 minutes of generation each)."""
     import bench
-    g = FULL[name]
     w = bench.ensure_workload(g["workload"])
     assert _sha256(w["fasta"]) == g["fasta_sha256"], "lcb-synth did not reproduce the genomes the reference was run on"
     assert _sha256(w["graph"]) == g["graph_sha256"], "lcb-mkgraph did not reproduce the junction file the reference was run on"
@@ -43,7 +43,7 @@ def test_fullsize_gff_equals_reference(built, name, tmp_path):
     dev = sibeliaz_amd.Device(st, p, 0)
     finder = sibeliaz_amd.BlocksFinder(st, g["k"])
     finder.FindBlocks(g["m"], g["b"], device=dev, threads=threads)
-    out = str(tmp_path / "out")
+    out = os.path.join(out_dir, "out")
     n_trimmed, cov = finder.GenerateOutput(out)
     assert n_trimmed == g["blocks_found"] and "%.2f" % cov == g["coverage"]
     gff = os.path.join(out, "blocks_coords.gff")
@@ -51,3 +51,10 @@ def test_fullsize_gff_equals_reference(built, name, tmp_path):
     assert _sha256(gff) == g["gff_sha256"], "blocks_coords.gff differs from the reference's"
     print("%s: %d seeds, %.1f s phase loop, %d launches, modes %s" % (name, finder.stats["seeds"], finder.stats["wall_ms"] / 1e3,
                                                                         finder.stats["launches"], dev.mode_seeds()))
+    dev.close()
+    st.close()
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_fullsize_gff_equals_reference(built, name, tmp_path):
+    check_case(name, FULL[name], str(tmp_path))
