@@ -155,9 +155,6 @@ typedef struct {
                                 default 1 << 22; enlarged x4 when a launch fills it (its unlucky seeds run again) */
     uint32_t side_lanes;     /* asynchronous job batches that can be in flight beside the synchronous launches (own streams, buffers,
                                 workspace slots and predicted views each); default 4; 0xFFFFFFFF = none */
-    uint32_t side_cus;       /* compute units the side lanes' kernels may run on (a CU mask on their streams: the rest of the chip stays free for
-                                the synchronous launches, whose few seeds otherwise wait for a compute unit that a background job holds for
-                                up to 100 ms); default 0 = all of them (stream priorities only) */
                              /* (the stream of the synchronous launches - the results the commit waits for - has the highest HIP stream priority,
                                 the side lanes' streams the lowest: speculation that fills the machine does not delay a needed result) */
 } lcb_device_opts;

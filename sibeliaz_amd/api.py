@@ -62,7 +62,7 @@ ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max
 class DeviceOpts(C.Structure):
     """lcb_device_opts: tuning knobs of a device, 0 = default."""
     _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
-                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes", "side_cus")]
+                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")]
 
 
 class Counters(C.Structure):

@@ -582,17 +582,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->lanes.resize(nLanes);
         for (uint32_t l = 0; l < nLanes; l++) {
             SideLane& L = d->lanes[l];
-            if (o.side_cus && o.side_cus < nCu) {
-                // a CU mask instead of a low priority: the lanes' kernels leave nCu - side_cus compute units to the synchronous launches
-                // (spread over the XCDs: CU i of the mask is kept if i mod nCu/side_cus-ish pattern below says so)
-                std::vector<uint32_t> mask((nCu + 31) / 32, 0u);
-                for (uint32_t c = 0; c < nCu; c++) if ((uint64_t)(c + 1) * o.side_cus / nCu != (uint64_t)c * o.side_cus / nCu) mask[c >> 5] |= 1u << (c & 31);
-                HIP_CHECK(hipExtStreamCreateWithCUMask(&L.sw, (uint32_t)mask.size(), mask.data()));
-                HIP_CHECK(hipExtStreamCreateWithCUMask(&L.sb, (uint32_t)mask.size(), mask.data()));
-            } else {
-                HIP_CHECK(hipStreamCreateWithPriority(&L.sw, hipStreamNonBlocking, prioLow));
-                HIP_CHECK(hipStreamCreateWithPriority(&L.sb, hipStreamNonBlocking, prioLow));
-            }
+            HIP_CHECK(hipStreamCreateWithPriority(&L.sw, hipStreamNonBlocking, prioLow));
+            HIP_CHECK(hipStreamCreateWithPriority(&L.sb, hipStreamNonBlocking, prioLow));
             for (hipEvent_t* e : {&L.w0, &L.w1, &L.b0, &L.b1}) HIP_CHECK(hipEventCreate(e));
             L.cap = 2048; L.arenaCap = 1ull << 20;
             // the host polls these while the kernels run: fine-grained (coherent) pinned memory

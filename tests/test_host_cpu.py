@@ -35,12 +35,12 @@ def test_ctypes_structs_have_the_layout_of_the_header(built, tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lcb.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lcb_stats), sizeof(lcb_hooks), '
                    'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, kernel_side_ms), offsetof(lcb_hooks, host_commit), '
-                   'offsetof(lcb_device_opts, side_cus)); return 0; }\n')
+                   'offsetof(lcb_device_opts, side_lanes)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     want = [C.sizeof(api.Stats), C.sizeof(api.Hooks), C.sizeof(api.DeviceOpts), sibeliaz_amd.SEED_DTYPE.itemsize, sibeliaz_amd.BLOCK_DTYPE.itemsize,
-            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.kernel_side_ms.offset, api.Hooks.host_commit.offset, api.DeviceOpts.side_cus.offset]
+            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.kernel_side_ms.offset, api.Hooks.host_commit.offset, api.DeviceOpts.side_lanes.offset]
     assert got == want
     header = open(os.path.join(ROOT, "include", "lcb.h")).read()
     assert int(re.search(r"#define LCB_ABI_VERSION (\d+)", header).group(1)) == api.ABI_VERSION == sibeliaz_amd.load_library().lcb_abi_version()
