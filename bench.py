@@ -102,12 +102,15 @@ def ensure_workload(name):
     d = os.path.join(os.environ.get("LCB_BENCH_DIR", "/tmp/lcb_bench"), name)
     os.makedirs(d, exist_ok=True)
     fa, gr = os.path.join(d, "genomes.fa"), os.path.join(d, "graph.bin")
-    if not (os.path.exists(fa) and os.path.exists(gr) and os.path.exists(gr + ".ok")):
-        t = time.time()
-        subprocess.check_call([os.path.join(BIN, "lcb-synth"), "-o", fa] + w["synth"].split())
-        subprocess.check_call([os.path.join(BIN, "lcb-mkgraph"), "-k", str(w["k"]), "-o", gr, fa], stderr=subprocess.DEVNULL)
-        open(gr + ".ok", "w").write("ok")
-        log("bench: generated workload %s in %.1fs" % (name, time.time() - t))
+    import fcntl
+    with open(os.path.join(d, ".lock"), "w") as lock:         # (several processes may ask for the same workload: pytest-xdist workers, ranks)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not (os.path.exists(fa) and os.path.exists(gr) and os.path.exists(gr + ".ok")):
+            t = time.time()
+            subprocess.check_call([os.path.join(BIN, "lcb-synth"), "-o", fa] + w["synth"].split())
+            subprocess.check_call([os.path.join(BIN, "lcb-mkgraph"), "-k", str(w["k"]), "-o", gr, fa], stderr=subprocess.DEVNULL)
+            open(gr + ".ok", "w").write("ok")
+            log("bench: generated workload %s in %.1fs" % (name, time.time() - t))
     return dict(w, name=name, fasta=fa, graph=gr, dir=d)
 
 

@@ -62,24 +62,6 @@
 #ifndef LCB_FLIGHT_RECORDER
 #define LCB_FLIGHT_RECORDER 1
 #endif
-#ifndef LCB_SPLIT_ARGS
-#define LCB_SPLIT_ARGS 1
-#endif
-#ifndef LCB_INSERT_LATE
-#define LCB_INSERT_LATE 1          // (0: a push inserts its vertex into the path set before it looks at the instances, for the A/B)
-#endif
-#ifndef LCB_FIELDS_ONE
-#define LCB_FIELDS_ONE 1           // (0: the fields of a voter / of the origin instance are read one by one, for the A/B)
-#endif
-#ifndef LCB_PUSH_HOIST
-#define LCB_PUSH_HOIST 1           // (0: the step-by-step reads of a push in the variants whose instance pool lives in the HBM workspace, for the A/B)
-#endif
-#ifndef LCB_WALK_STAGE
-#define LCB_WALK_STAGE 0           // (1: chunks 1-2 of a voter's window are requested straight into LDS when its walk starts - wide / big / huge;
-                                   //  2: also chunk 1 in the compact variant, staged in LDS that is idle during a vote)
-#endif
-#define LCB_STAGE_CHUNKS 2u
-#define LCB_STAGE_WORDS (LCB_STAGE_CHUNKS * (64u + 64u + 16u))   // per wavefront: positions, vertex ids and `used` words of the staged chunks
 
 // Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
@@ -306,8 +288,6 @@ struct LcbStateT {
     uint32_t* vLast;
     uint16_t* vTouched;        // slots claimed in the current vote, in claim order
     uint32_t* vNClaimed;       // LDS counter: number of them
-    uint32_t* stage;           // this wavefront's LDS staging area for the chunks of a voter's window requested ahead (null: none)
-    uint32_t stageChunks;      // chunks it holds: positions [0, 64 C), vertex ids [64 C, 128 C), `used` words [128 C, 144 C)
     uint32_t* vTicket;         // LDS counter: next entry of the touch list to hand to a wavefront (votes shared by more than two wavefronts)
     uint32_t* vOvf;            // LDS flag: a walk of the current vote could not place a vertex
     uint32_t voteCap, voteShift;
@@ -384,25 +364,6 @@ __device__ __forceinline__ uint32_t lcb_uword(const LcbUsed& U, uint32_t w)
 {
     if (U.tab) w += LCB_GLOBAL_U32(U.tab)[w >> LCB_PAGE_SHIFT];
     return U.live[w];
-}
-
-// One dword per active lane from global memory straight into LDS (dst[lane], dst wave-uniform): no register is held while the load is
-// in flight, so a wavefront at its register budget can still request data ahead. The reader waits with lcb_stage_wait().
-__device__ __forceinline__ void lcb_stage_load(uint32_t* dst, const uint32_t* src, uint32_t lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
-#else
-    dst[lane] = *src;
-#endif
-}
-__device__ __forceinline__ void lcb_stage_wait()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): every load of this wavefront has landed (LDS writes included)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
 }
 
 __device__ __forceinline__ bool lcb_used_bit(const LcbUsed& U, uint32_t g)
@@ -524,37 +485,6 @@ __device__ inline void lcb_path_insert(ST& S, int32_t vid)
     LCB_SYNC_IF(PL);
 }
 
-// The same in two halves for a push whose set lives in the HBM workspace: the home slot is requested when the push starts and looked at
-// when the push is over - nothing inside a push reads the set, so the round trip (and the fence that publishes the key, which waits for
-// every load in flight: the occurrence records requested ahead, the `used` words) hides behind the work on the instances.
-template <class ST>
-__device__ __forceinline__ int32_t lcb_path_insert_begin(ST& S, int32_t vid, uint32_t& h)
-{
-    h = 0;
-    if ((S.nPath + 1) * 2 > S.pathCap) { S.status = LCB_ST_PATH_OVF; return 0; }
-    h = lcb_hash(vid, S.pathShift);
-    return S.pKeys[h];
-}
-template <class ST>
-__device__ inline void lcb_path_insert_end(ST& S, int32_t vid, uint32_t h, int32_t k)
-{
-    const uint32_t mask = S.pathCap - 1;
-    uint32_t probe = 0;
-    while (k != LCB_EMPTY_KEY && probe < S.pathCap) { h = (h + 1) & mask; probe++; k = S.pKeys[h]; }
-    if (probe == S.pathCap) { S.status = LCB_ST_PATH_OVF; return; }
-    LCB_WAVE_SYNC();
-    if (S.lane == 0) {
-        S.pKeys[h] = vid; S.pSlots[S.nPath] = h;
-        if (LcbCfg<ST::MODE>::BW) {
-            const uint32_t a = lcb_bloom1(vid, S.bloomShift), b = lcb_bloom2(vid, S.bloomShift);
-            S.bloom[a >> 5] |= 1u << (a & 31);
-            S.bloom[b >> 5] |= 1u << (b & 31);
-        }
-    }
-    S.nPath++;
-    LCB_WAVE_SYNC();
-}
-
 // Path::Clear (path.h:650-677): wave-uniform. The right-body list is kept (the replay reads it).
 template <class ST>
 __device__ inline void lcb_path_clear(ST& S)
@@ -664,7 +594,7 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // with the path set in LDS always walk exactly.
 // (Tried and measured slower on the MI355X, profiles/r03: requesting the next chunk of a voter ahead of time with unconditional,
 // straight-line loads - the main wavefront is bound by instruction issue, not by the round trips the prefetch hides.)
-struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; uint32_t pg, tabD; };
+struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
 struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 template <bool STATS, bool PROF = false, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
@@ -693,20 +623,17 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 const uint32_t i = lcb_rfl((uint32_t)S.touch[t]);
                 const uint32_t e = useGood ? lcb_rfl((uint32_t)S.goodPos[i]) : i;      // position in the voting list (its order breaks ties)
                 if (e == LCB_NONE16) continue;
-                const uint32_t f = LCB_FIELDS_ONE ? lcb_inst_fields(S, i) : 0u;
-                const uint32_t fl = LCB_FIELDS_ONE ? lcb_rl(f, LCB_F_FLAGS) : lcb_rfl(S.iFlags[i]);
-                const uint32_t fp = LCB_FIELDS_ONE ? lcb_rl(f, LCB_F_FRONTPOS) : lcb_rfl(S.iFrontPos[i]), bp = LCB_FIELDS_ONE ? lcb_rl(f, LCB_F_BACKPOS) : lcb_rfl(S.iBackPos[i]);
+                const uint32_t f = lcb_inst_fields(S, i);
+                const uint32_t fl = lcb_rl(f, LCB_F_FLAGS), fp = lcb_rl(f, LCB_F_FRONTPOS), bp = lcb_rl(f, LCB_F_BACKPOS);
                 v.e = e; v.i = i;
-                v.g0 = LCB_FIELDS_ONE ? (forward ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG)) : lcb_rfl(forward ? S.iBackG[i] : S.iFrontG[i]);
+                v.g0 = forward ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG);
                 v.pos0 = forward ? bp : fp;
-                v.lo = LCB_FIELDS_ONE ? lcb_rl(f, LCB_F_LO) : lcb_rfl(S.iLo[i]);
-                const uint32_t hi = LCB_FIELDS_ONE ? lcb_rl(f, LCB_F_HI) : lcb_rfl(S.iHi[i]);
+                v.lo = lcb_rl(f, LCB_F_LO);
+                const uint32_t hi = lcb_rl(f, LCB_F_HI);
                 v.weight = lcb_absdiff(fp, bp) + 1u;                                   // blocksfinder.h:719
                 v.positive = (fl & LCB_FLAG_POS) != 0;
                 v.dir = (forward == v.positive) ? 1 : -1;
                 v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                      // steps for which it.Valid() holds
-                v.pg = 0; v.tabD = 0;
-                if (LCB_WALK_STAGE && S.U.tab) { v.pg = (v.g0 >> 5) >> LCB_PAGE_SHIFT; v.tabD = lcb_rfl(LCB_GLOBAL_U32(S.U.tab)[v.pg]); }
                 return true;
             }
         }
@@ -743,8 +670,6 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             v.positive = (lcb_rl(fFl, b) & LCB_FLAG_POS) != 0;
             v.dir = (forward == v.positive) ? 1 : -1;
             v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
-            v.pg = 0; v.tabD = 0;
-            if (LCB_WALK_STAGE && S.U.tab) { v.pg = (v.g0 >> 5) >> LCB_PAGE_SHIFT; v.tabD = lcb_rfl(LCB_GLOBAL_U32(S.U.tab)[v.pg]); }
             return true;
         }
     };
@@ -765,58 +690,6 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
         }
         return w;
     };
-    // Staging (wide, big, huge): a window is 2.5 chunks on average and every chunk after the first used to cost a full round trip to
-    // HBM (the voters of a vote are in different genomes: nothing of a window is in a cache). When the walk of a voter starts, the table
-    // entries of its chunks 1 and 2 - and the two or three `used` words under each - are requested straight into this wavefront's LDS
-    // staging area (no registers: these variants sit at their 128-VGPR budget) and arrive while chunk 0 is worked off.
-    const bool staging = LCB_WALK_STAGE && S.stage != nullptr;
-    const uint32_t stC = S.stageChunks;
-    uint32_t stW1 = 0, stW2 = 0;                                    // first staged `used` word of chunk 1 / 2
-    auto stageIssue = [&](const LcbVoter& v) -> uint32_t {         // -> number of staged chunks (1 .. n)
-        if (v.rem <= 64u) return 0u;
-        uint32_t n = (v.rem - 1u) / 64u;                           // chunk c exists iff c * 64 + 1 <= rem
-        if (n > stC) n = stC;
-        uint32_t done = 0;
-        for (uint32_t c = 1; c <= n; c++) {
-            uint32_t wlo = 0, cnt = 0;
-            if (!tryUsed) {
-                // bits read by the valid steps of the chunk: + strand bit g, - strand bit g-1 for g > lo
-                const uint32_t dA = c * 64u + 1u, dB = (c * 64u + 64u) < v.rem ? (c * 64u + 64u) : v.rem;
-                uint32_t gmin = v.dir > 0 ? v.g0 + dA : v.g0 - dB, gmax = v.dir > 0 ? v.g0 + dB : v.g0 - dA;
-                bool any = true;
-                if (!v.positive) { if (gmin <= v.lo) gmin = v.lo + 1u; any = gmin <= gmax; gmin -= 1u; gmax -= 1u; }
-                if (any) {
-                    wlo = gmin >> 5; cnt = (gmax >> 5) - wlo + 1u;
-                    if (S.U.tab && ((wlo >> LCB_PAGE_SHIFT) != v.pg || ((wlo + cnt - 1u) >> LCB_PAGE_SHIFT) != v.pg)) break;   // (another page of the view: the plain walk)
-                }
-            }
-            const uint32_t d = c * 64u + S.lane + 1u;
-            if (d <= v.rem) {
-                const uint32_t g = v.dir > 0 ? v.g0 + d : v.g0 - d;
-                lcb_stage_load(S.stage + (c - 1u) * 64u, T.posPos + g, S.lane);
-                lcb_stage_load(S.stage + (stC + c - 1u) * 64u, (const uint32_t*)(T.posId + g), S.lane);
-            }
-            if (S.lane < cnt) lcb_stage_load(S.stage + stC * 128u + (c - 1u) * 16u, S.U.live + (wlo + v.tabD + S.lane), S.lane);
-            if (c == 1) stW1 = wlo; else stW2 = wlo;
-            done = c;
-        }
-        return done;
-    };
-    auto fromStage = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
-        LcbWalk w;
-        const uint32_t d = c * 64 + S.lane + 1;
-        w.valid = d <= v.rem;
-        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
-        w.pos = 0; w.id = 0; w.uw = 0;
-        lcb_stage_wait();
-        if (w.valid) {
-            w.pos = S.stage[(c - 1u) * 64u + S.lane];
-            w.id = (int32_t)S.stage[(stC + c - 1u) * 64u + S.lane];
-            const uint32_t ub = w.g - (v.positive ? 0u : 1u);
-            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = S.stage[stC * 128u + (c - 1u) * 16u + ((ub >> 5) - (c == 1 ? stW1 : stW2))] >> (ub & 31);
-        }
-        return w;
-    };
     LcbVoter cur, nxt;
     LcbWalk wcur, wnxt;
     bool have = nextVoter(cur);
@@ -824,9 +697,8 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     while (have) {
         const bool haveNext = nextVoter(nxt);
         if (haveNext) wnxt = issue(nxt, 0);
-        const uint32_t nStaged = staging ? stageIssue(cur) : 0u;
         for (uint32_t c = 0;; c++) {
-            const LcbWalk w = c == 0 ? wcur : ((staging && c <= nStaged) ? fromStage(cur, c) : issue(cur, c));
+            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
             if (PROF) S.pfChunks++;
             const uint32_t d = c * 64 + S.lane + 1;
             const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
@@ -873,9 +745,6 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
         if (PROF) S.pfVoters++;
         have = haveNext; cur = nxt; wcur = wnxt;
     }
-    // a window that ended early leaves requests for its later chunks in flight: they land before anybody else may use the staging area
-    // (the compact variant's is the insert scratch of the pushes / the spare half of the ordered index)
-    if (staging) lcb_stage_wait();
 }
 
 // Is one of the vertices named by the entries [s0, s1) of the touched list of the vote table in the path? (after a pass with
@@ -924,7 +793,7 @@ __device__ inline LcbBest lcb_vote_argmax(const ST& S, bool forward, bool useGoo
 }
 
 // Mailbox words through which wave 0 hands a vote to the helper wavefronts of its workgroup.
-enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_NTOUCH, LCB_MAIL_FPSPLIT, LCB_MAIL_FPSHIFT, LCB_MAIL_CUR, LCB_MAIL_WORDS = 8 };
+enum { LCB_MAIL_CMD = 0, LCB_MAIL_FLAGS, LCB_MAIL_NLIST, LCB_MAIL_FLANK, LCB_MAIL_NTOUCH, LCB_MAIL_FPSPLIT, LCB_MAIL_FPSHIFT, LCB_MAIL_WORDS = 8 };
 enum { LCB_CMD_VOTE = 1, LCB_CMD_EXIT = 2 };
 
 // Clears the vote-table slots named by the entries [s0, s1) of the touched list (blocksfinder.h:761-766).
@@ -973,7 +842,7 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
         if (S.lane == 0) {
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u) | (exact ? 16u : 0u);
             S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
-            S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift; S.mail[LCB_MAIL_CUR] = S.cur;
+            S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
             *S.vTicket = 0;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
@@ -1144,8 +1013,7 @@ template <bool BACK, bool STATS, bool PROF, class ST>
 __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
-    constexpr bool HOIST = LCB_PUSH_HOIST && !LcbCfg<ST::MODE>::INST_LDS;
-    constexpr bool LATE = LCB_INSERT_LATE && LcbCfg<ST::MODE>::PC == 0;
+    constexpr bool HOIST = !LcbCfg<ST::MODE>::INST_LDS;
     const uint64_t tq0 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
@@ -1160,10 +1028,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
     const int64_t dist64 = BACK ? (int64_t)S.rightFlank + length : (int64_t)S.leftFlank - (int64_t)length;
     if (dist64 > INT32_MAX || dist64 < -(int64_t)INT32_MAX) { S.status = LCB_ST_DIST_OVF; return false; }
     const int32_t distance = (int32_t)dist64;
-    uint32_t insH = 0;
-    int32_t insK = 0;
-    if (LATE) insK = lcb_path_insert_begin(S, vertex, insH);
-    else lcb_path_insert(S, vertex);
+    lcb_path_insert(S, vertex);
     if (S.status) return false;
 
     const int64_t B = S.P.maxBranch;
@@ -1365,7 +1230,6 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         if (m) lcb_order_merge(S, m);
         if (PROF && LCB_PROF_PUSH) S.pfTScan += wall_clock64() - tq3;
     }
-    if (LATE) { lcb_path_insert_end(S, vertex, insH, insK); if (S.status) return true; }
     if (BACK) {
         if (record) {
             if (S.nRight >= S.bodyCap) { S.status = LCB_ST_PATH_OVF; return true; }
@@ -1540,7 +1404,7 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
     if (next != 0) {
         // (pool in the HBM workspace: one load for the four fields, see lcb_inst_fields; an LDS-resident pool is read field by field -
         // there the one-load form made the register allocator of the compact instantiation spill whole 16-register tuples)
-        constexpr bool ONE = LCB_FIELDS_ONE && !LcbCfg<ST::MODE>::INST_LDS;
+        constexpr bool ONE = !LcbCfg<ST::MODE>::INST_LDS;
         const uint32_t f = ONE ? lcb_inst_fields(S, oi) : 0u;
         const bool positive = ((ONE ? lcb_rl(f, LCB_F_FLAGS) : lcb_rfl(S.iFlags[oi])) & LCB_FLAG_POS) != 0;
         uint32_t g = ONE ? (FORWARD ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG)) : lcb_rfl(FORWARD ? S.iBackG[oi] : S.iFrontG[oi]);
@@ -1707,7 +1571,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     __shared__ uint32_t sMisc[4];
     __shared__ uint32_t sMail[LCB_MAIL_WORDS];
     __shared__ uint32_t sPart[8 * NW];
-    __shared__ uint32_t sStage[(LCB_WALK_STAGE && NW > 2) ? NW * LCB_STAGE_WORDS : 1];
     __shared__ unsigned long long sMailWalk[1];
     __shared__ LcbLaunchArgs sArgs;
     if (threadIdx.x == 0) {
@@ -1718,16 +1581,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     }
 
     LcbStateT<MODE> S;
-    S.T = T; S.P = P;
-#if defined(__HIP_DEVICE_COMPILE__) && LCB_SPLIT_ARGS
-    // The kernel arguments arrive as 8- and 16-register tuples (s_load_dwordx8 / x16), and a tuple is spilled and reloaded as a whole:
-    // a reload of the `used` pointer was sixteen v_readlane instead of two. Passing every table pointer through an empty asm gives it a
-    // live range of its own.
-    asm volatile("" : "+s"(S.T.chrStart)); asm volatile("" : "+s"(S.T.posId)); asm volatile("" : "+s"(S.T.posPos)); asm volatile("" : "+s"(S.T.posCh));
-    asm volatile("" : "+s"(S.T.posRevCh)); asm volatile("" : "+s"(S.T.occStart)); asm volatile("" : "+s"(S.T.occRec)); asm volatile("" : "+s"(S.T.used));
-    asm volatile("" : "+s"(S.T.viewTab));
-#endif
-    S.U = lcb_used_of(S.T, 0);
+    S.T = T; S.P = P; S.U = lcb_used_of(T, 0);
     S.lane = threadIdx.x & 63u;
     uint8_t* slot = W.base + (uint64_t)blockIdx.x * W.slotBytes;
     const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, INST_LDS ? 0 : W.instCap, IDX_LDS ? 0 : W.voteCap);
@@ -1771,20 +1625,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1]; S.vTicket = &sMisc[2];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
-    // Staging areas of the look-ahead walks: the many-wavefront variants have LDS to spare; the compact variant (LCB_WALK_STAGE 2) stages one
-    // chunk in LDS nobody uses during a vote - wave 0 in the insert scratch of the pushes, the helper (per vote, below) in the half of the
-    // ordered index that is not the current one.
-    constexpr bool STAGE_COMPACT = LCB_WALK_STAGE >= 2 && MODE == 0 && NW == 2;
-    static_assert(!STAGE_COMPACT || (3 * 64 >= 144 && IC >= 144), "staging area of the compact variant");
-    S.stage = (LCB_WALK_STAGE && NW > 2) ? sStage + waveId * LCB_STAGE_WORDS : ((STAGE_COMPACT && waveId == 0) ? sScr : nullptr);
-    S.stageChunks = (LCB_WALK_STAGE && NW > 2) ? LCB_STAGE_CHUNKS : 1u;
     S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     S.abort = W.abort;
-#if defined(__HIP_DEVICE_COMPILE__) && LCB_SPLIT_ARGS
-    // (the same for what stays live of LcbWork: its sixteen-register tuple otherwise comes back whole for the abort pointer of every step)
-    asm volatile("" : "+s"(S.abort)); asm volatile("" : "+s"(S.dbg)); asm volatile("" : "+s"(S.pathCap)); asm volatile("" : "+s"(S.bodyCap));
-    asm volatile("" : "+s"(S.bestCap)); asm volatile("" : "+s"(slot));
-#endif
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
     S.nInst = S.nGood = S.cur = S.nPath = S.nRight = S.nLeft = S.nBest = 0; S.status = 0; S.nTouch = S.nInit = 0;
@@ -1805,7 +1647,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 const uint32_t flags = lcb_rfl(S.mail[LCB_MAIL_FLAGS]);
                 S.nTouch = lcb_rfl(S.mail[LCB_MAIL_NTOUCH]);
                 S.fpSplit = lcb_rfl(S.mail[LCB_MAIL_FPSPLIT]); S.fpShift = lcb_rfl(S.mail[LCB_MAIL_FPSHIFT]);
-                if (STAGE_COMPACT) S.stage = sOrdKey + (lcb_rfl(S.mail[LCB_MAIL_CUR]) ^ 1u) * IC;
                 S.cWalk = 0;
                 lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
                                      (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW, (flags & 16u) != 0);

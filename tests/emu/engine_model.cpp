@@ -267,6 +267,19 @@ int main(int argc, char** argv)
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
                 (tRound + tJobs + tBig) / 1000);
+        // N ranks: every launch is dealt to the ranks, so the throughput-bound part of a launch divides by N and its longest seed
+        // does not; every launch ends with two all-gathers (headers, then instances + footprints) priced at 2 x 60 us for N > 1 (8 ranks on
+        // xGMI: latency-bound messages). Background batches are not priced: they fill otherwise idle slots on every rank.
+        for (int N : {1, 2, 4, 8}) {
+            double t = 0;
+            for (const Launch& L : proc.launches) {
+                const bool wide = L.n <= 512;
+                const double c = wide ? 8.0 : 10.0, slots = (wide ? 256.0 : 1280.0) * N;
+                t += std::max((double)L.maxPush * c, (double)L.sumPush * c / slots) + 50.0 + (N > 1 ? 120.0 : 0.0);
+                if (L.nBig) t += (double)L.maxPushBig * 20.0 + 50.0 + (N > 1 ? 120.0 : 0.0);
+            }
+            fprintf(stderr, "model: %d rank%s: %.0f ms of launches (x %.2f)\n", N, N > 1 ? "s" : "", t / 1000, (tRound + tJobs + tBig) / t);
+        }
         fprintf(stderr, "model: virtual clock (pushes; a synchronous launch = its longest seed, a background job is ready its own pushes after its batch began): %lld | side lanes %zu: "
                         "%lld batches, %lld jobs (%lld taken, %lld dropped), %lld pushes of background work, the commit waited %lld pushes for background jobs\n",
                 (long long)proc.now, proc.lanes.size(), (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.sideVoid, (long long)proc.sidePushes, (long long)proc.sideWaited);
