@@ -6,7 +6,8 @@ MODE=${1:-all}
 mkdir -p gpurun_out/r4ev
 R=$PWD; O=$R/gpurun_out/r4ev
 export LCB_WATCHDOG_S=600
-git -C $R rev-parse HEAD > $O/evidence_head.txt 2>/dev/null || true
+# (the snapshot on the GPU box has no .git: the commit is written into .evidence_head right before the call)
+git -C $R rev-parse HEAD > $O/evidence_head.txt 2>/dev/null || cp $R/.evidence_head $O/evidence_head.txt
 cat $O/evidence_head.txt
 if [ "$MODE" = all ] || [ "$MODE" = tests ]; then
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -x -s > $O/pytest_gpu.log 2>&1; grep -E "seeds,|passed|failed|skipped" $O/pytest_gpu.log | tail -8
