@@ -1616,6 +1616,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.bloomShift = BW ? 32u - (uint32_t)__ffs((int)(BW * 32u)) + 1u : 0u;
     for (uint32_t h = threadIdx.x; h < BW; h += 64 * NW) sBloom[h] = 0;
     S.voteShift = 32u - (uint32_t)__ffs((int)S.voteCap) + 1u;
+    // (field f of the pool lives at instBase + f * instStride, in the order of the LCB_F_* enumeration: lcb_inst_fields relies on it)
     S.iFrontG = instBase; S.iBackG = instBase + instStride;
     S.iFrontPos = instBase + 2 * instStride; S.iBackPos = instBase + 3 * instStride;
     S.iLo = instBase + 4 * instStride; S.iHi = instBase + 5 * instStride;
