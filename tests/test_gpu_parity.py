@@ -298,6 +298,52 @@ def test_footprints_cover_every_read_on_gpu(built, case, mode):
     dev.reset_used()
 
 
+@pytest.mark.parametrize("synth_seed", [7101, 7102, 7103])
+def test_footprints_cover_every_read_on_random_inputs(built, tmp_path, synth_seed):
+    """The same property on RANDOM inputs (the bug class it guards - a read outside the footprint - showed on 6 of 11 random inputs under
+    the emulator in round 2 and on none of the goldens), for the compact and the wide variant, in three `used` states - all unused,
+    random runs of used positions (any bitmap is a legal state for the kernels), the final state of a whole FindBlocks - and for up to
+    120 seeds that yield a block per state (the heavy head of the seed order and a sample of the rest)."""
+    import bench
+    fa, gr = str(tmp_path / "g.fa"), str(tmp_path / "g.bin")
+    subprocess.check_call([os.path.join(bench.BIN, "lcb-synth"), "-o", fa] + ("--strains 7 --segments 50 --keep 0.8 --swap 0.08 --invert 0.15 --sub 0.03 --indel 0.004 "
+                          "--filler-frac 0.3 --filler-min 100 --filler-max 1500 --repeat-families 4 --repeat-copies 6 --repeat-len 500 --seg-min 300 --seg-max 4000 --seed %d" % synth_seed).split())
+    subprocess.check_call([os.path.join(bench.BIN, "lcb-mkgraph"), "-k", "15", "-o", gr, fa], stderr=subprocess.DEVNULL)
+    k, b, m, a = 15, 200, 50, 150
+    st = sibeliaz_amd.JunctionStorage(gr, [fa], k, threads=4, abundance=a)
+    p = sibeliaz_amd.Params.make(k, b=b, m=m)
+    orc = Oracle(gr, [fa], k, a)
+    orc.find_blocks(k, b, m)
+    final = np.array(orc.used_bitmap(st.chr_start()), dtype="<u4")
+    n_pos = st.n_positions()
+    words = (n_pos + 31) // 32 + 1
+    rng = np.random.default_rng(synth_seed)
+    rnd = np.zeros(words * 32, dtype=bool)
+    for _ in range(max(1, n_pos // 2000)):
+        q = int(rng.integers(0, n_pos)); rnd[q:q + int(rng.integers(20, 300))] = True
+    rnd[n_pos:] = False
+    states = {"unused": np.zeros(words * 32, dtype=bool), "random": rnd, "final": np.unpackbits(np.resize(final, words).view(np.uint8), bitorder="little").astype(bool)}
+    checked = 0
+    for mode in (1, 2):
+        dev = sibeliaz_amd.Device(st, p, 0, start_mode=mode)
+        seeds = st.seeds(4)
+        for name, base in states.items():
+            dev.set_used(np.packbits(base, bitorder="little").view("<u4")[:words])
+            off, inst, fp_off, fp = dev.process_seeds_fp(seeds)
+            good = [i for i in range(len(seeds)) if off[i + 1] - off[i] > 1]
+            picked = sorted(set(good[:50] + good[50:: max(1, len(good) // 70)][:70]))       # the heavy head of the seed order and a sample of the rest
+            for i in picked:
+                bits = np.ones(words * 32, dtype=bool)
+                for lo, hi in fp[int(fp_off[i]):int(fp_off[i + 1])]:
+                    bits[int(lo):int(hi) + 1] = base[int(lo):int(hi) + 1]            # inside the footprint: the state the seed saw
+                dev.set_used(np.packbits(bits, bitorder="little").view("<u4")[:words])
+                off2, inst2, _, _ = dev.process_seeds_fp(seeds[i:i + 1])
+                assert inst2.tobytes() == inst[int(off[i]):int(off[i + 1])].tobytes(), "input %d, %s state, seed %d: a read outside its footprint changed the result (variant %d)" % (synth_seed, name, i, mode)
+                checked += 1
+        dev.close()
+    assert checked >= 20, "too few block-producing seeds (%d) - the generator parameters no longer fit" % checked
+
+
 def test_persistent_gpu_set(built, case):
     """lcb_gpus_create / lcb_gpus_find_blocks / lcb_gpus_destroy: devices, tables and the RCCL communicator live across passes (the handle
     bench.py --gpus N and sibeliaz-lcb LCB_GPUS=N use) - with the one GPU of the test box, forced through the exchange path; two passes."""
