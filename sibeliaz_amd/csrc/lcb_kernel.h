@@ -56,12 +56,6 @@
 #ifndef LCB_PROF_PUSH
 #define LCB_PROF_PUSH 0
 #endif
-#ifndef LCB_VOTE_TICKETS
-#define LCB_VOTE_TICKETS 1         // (0: the static deal of voters to wavefronts, for the A/B)
-#endif
-#ifndef LCB_FLIGHT_RECORDER
-#define LCB_FLIGHT_RECORDER 1
-#endif
 
 // Four kernel variants by where the per-path state lives and how many seeds share a CU. Seeds that overflow one are
 // re-run by the host in the next:
@@ -215,7 +209,7 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
 // Flight recorder: lane 0 stores progress words the host watchdog can read while the kernel is running.
 #define LCB_MARK(S, slot, value)                                                         \
     do {                                                                                 \
-        if (LCB_FLIGHT_RECORDER && (S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+        if ((S).dbg && (S).lane == 0) __hip_atomic_store(&(S).dbg[(slot)], (uint32_t)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
     } while (0)
 
 // wave-uniform value -> scalar register (every lane must hold the same value; uniform control flow only)
@@ -610,7 +604,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
     unsigned long long pend = 0;
     uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
     bool scanned = false;
-    const bool tickets = LCB_VOTE_TICKETS && nWaves > 2;
+    const bool tickets = nWaves > 2;
     auto nextVoter = [&](LcbVoter& v) -> bool {
         if (tickets) {
             // one entry of the touch list per draw; its fields are wave-uniform loads (the next voter is drawn while the current one
@@ -1626,7 +1620,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     S.scr = sScr; S.vNClaimed = &sMisc[0]; S.vOvf = &sMisc[1]; S.vTicket = &sMisc[2];
     S.mail = sMail; S.mailWalk = sMailWalk; S.part = sPart;
     const uint32_t waveId = lcb_rfl(threadIdx.x >> 6);
-    S.dbg = (LCB_FLIGHT_RECORDER && W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
+    S.dbg = (W.dbg && waveId == 0) ? W.dbg + 16u * blockIdx.x : nullptr;
     S.abort = W.abort;
     LCB_MARK(S, 0, 1);
     if (threadIdx.x == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; sMail[LCB_MAIL_CMD] = 0; sMailWalk[0] = 0; }
