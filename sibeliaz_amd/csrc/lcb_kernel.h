@@ -1209,6 +1209,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             {   // the creating read (the occurrence's own `used` bit was 0)
                 const uint32_t fs = lcb_fp_slot(S, i);
                 if (fs >= S.nFp) { S.fpLo[fs] = g; S.fpHi[fs] = g; }
+                else if (HOIST) { atomicMin(&S.fpLo[fs], g); atomicMax(&S.fpHi[fs], g); }     // (slots in the HBM workspace are only ever UPDATED with atomics: the walks of the other wavefronts update them at the L2)
                 else { if (g < S.fpLo[fs]) S.fpLo[fs] = g; if (g > S.fpHi[fs]) S.fpHi[fs] = g; }
             }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
@@ -1709,7 +1710,13 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             olo = lcb_rfl(olo); ohi = lcb_rfl(ohi);
             fpo = ((unsigned long long)ohi << 32) | olo;
             if (fpo + nfp > sArgs.fpCap) S.status = LCB_ST_ARENA_OVF;
-            else for (uint32_t e = S.lane; e < nfp; e += 64) { uint2 r; r.x = S.fpLo[e] ? S.fpLo[e] - 1 : 0u; r.y = S.fpHi[e]; fpa[fpo + e] = r; }
+            else for (uint32_t e = S.lane; e < nfp; e += 64) {
+                // (slots in the HBM workspace were updated with atomics at the L2 by every wavefront of the workgroup: read them there, not
+                // through a line this wavefront's L1 may still hold from an earlier plain read)
+                const uint32_t lo = INST_LDS ? S.fpLo[e] : __hip_atomic_load(&S.fpLo[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t hi = INST_LDS ? S.fpHi[e] : __hip_atomic_load(&S.fpHi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint2 r; r.x = lo ? lo - 1 : 0u; r.y = hi; fpa[fpo + e] = r;
+            }
         }
         // (no local arrays here: the compiler would move them to LDS, 48 B x every lane of the workgroup)
         uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
