@@ -68,6 +68,11 @@ WORKLOADS = {
     "mice16_scaled": dict(synth="--strains 16 --chromosomes 20 --segments 600 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.005 "
                                 "--indel 0.0005 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1004",
                           k=25, b=200, m=50, a=150, desc="16 synthetic strains x 20 chromosomes (1.0 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 5, scaled]"),
+    # config 4's shape at the largest size the build container can run the unmodified reference on (its hash: tests/golden/fullsize_scaled.json):
+    # 8 x 24 chromosomes x ~21.5 Mbp = 4.1 Gbp (5 600 segments)
+    "primates8_4g": dict(synth="--strains 8 --chromosomes 24 --segments 5600 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "
+                               "--indel 0.001 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1003",
+                         k=25, b=200, m=50, a=150, desc="8 synthetic strains x 24 chromosomes (4.1 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 4, scaled]"),
     # the same two shapes at the size of a parity test (tests/test_gpu_fullsize.py; the reference needs ~20 s for each on 8 cores):
     # 8 x 24 chromosomes = 186 Mbp at 1 % divergence, 16 x 20 chromosomes = 217 Mbp at 0.5 %
     "primates8_test": dict(synth="--strains 8 --chromosomes 24 --segments 240 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "

@@ -104,6 +104,7 @@ typedef struct {
     double kernel_busy_ms;      /* UNION of the hipEvent-timed kernel intervals of all streams: the time the GPU was busy with process kernels
                                    (kernel_ms is their SUM; the side lanes' kernels run beside the synchronous ones, so the sum can exceed the pass) */
     double kernel_side_ms;      /* the part of kernel_ms that ran on the side lanes' streams */
+    int64_t lazy_seeds;         /* seeds in the lazy tails of the rounds: no speculative launch, their phase-start results are background jobs (lcb_hooks.lazy_span) */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -112,7 +113,7 @@ const char* lcb_last_error(void);
 const char* lcb_version(void);
 /* Layout version of the structs of this header (lcb_stats, lcb_hooks, lcb_device_opts): they are allocated by the caller, so a caller
  * built against another LCB_ABI_VERSION must not call in. lcb_abi_version() returns the library's. */
-#define LCB_ABI_VERSION 4
+#define LCB_ABI_VERSION 5
 int lcb_abi_version(void);
 
 /* ---- graph: JunctionStorage::Init (junctionstorage.h:572-650), junctionapi.h:80-98, streamfastaparser.cpp:28-92 */
@@ -136,8 +137,10 @@ void lcb_free(void* p);
 
 /* ---- device: one MI355X. device_ordinal is the HIP device index. */
 lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int device_ordinal);
-/* Tuning knobs of a device; a zero field means "default". Results never depend on them (tests sweep them). */
+/* Tuning knobs of a device; a zero field means "default". Results never depend on them (tests sweep them). The struct is allocated by
+ * the caller: `abi` must hold the LCB_ABI_VERSION of the header it was compiled against (a mismatch is rejected, not misread). */
 typedef struct {
+    uint32_t abi;            /* = LCB_ABI_VERSION */
     uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 5 per CU */
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
     uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
@@ -157,6 +160,12 @@ typedef struct {
                                 workspace slots and predicted views each); default 4; 0xFFFFFFFF = none */
                              /* (the stream of the synchronous launches - the results the commit waits for - has the highest HIP stream priority,
                                 the side lanes' streams the lowest: speculation that fills the machine does not delay a needed result) */
+    /* Positions on the device are (segment, 32-bit offset) pairs; a segment is a run of whole chromosomes (the reference bounds a
+     * chromosome by 2^32, junctionstorage.h:120-151, not the input). Test hooks - results never depend on them: */
+    uint64_t seg_cap;        /* most junction occurrences per segment; default 2^32 - 2^20. Non-zero: the segment-aware kernels run even
+                                if everything fits one segment (small values cut a small input into many segments) */
+    uint64_t seg_gap;        /* unused positions between two segments of the device tables (0 = none): with 2^32 the flat indices of a
+                                small input exceed 32 bits, i.e. every 64-bit address computation of the kernels is exercised */
 } lcb_device_opts;
 lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int device_ordinal, const lcb_device_opts* opts);
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows
@@ -178,12 +187,12 @@ int lcb_device_set_stats_mode(lcb_device* d, int on);
  * capacity is then in offsets[n]). best_score and ctr may be NULL. */
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets,
                       lcb_instance* inst, uint64_t inst_cap, int64_t* best_score, lcb_counters* ctr);
-/* The same, also returning every seed's FOOTPRINT: intervals [lo, hi] of flat positions (pairs of uint32) that cover every position
+/* The same, also returning every seed's FOOTPRINT: intervals [lo, hi] of flat positions (pairs of uint64) that cover every position
  * whose `used` bit the seed's computation read as 0 - what makes the engine's speculation exact (a result stays valid as long as
  * no bit inside its footprint has been set since). fp_offsets has n+1 entries; interval j of seed i is fp[2*j], fp[2*j+1] for j in
  * fp_offsets[i] .. fp_offsets[i+1]. On LCB_ERR for lack of room the needed capacities are in offsets[n] / fp_offsets[n]. */
 int lcb_process_seeds_fp(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
-                         uint64_t* fp_offsets, uint32_t* fp, uint64_t fp_cap);
+                         uint64_t* fp_offsets, uint64_t* fp, uint64_t fp_cap);
 /* Measured HBM rate of this GPU: STREAM triad over three arrays of `bytes` each, GB/s (the roofline's measured peak). */
 int lcb_device_hbm_triad(lcb_device* d, uint64_t bytes, int reps, double* gb_per_s);
 /* hipEvent-timed duration (ms) and launch count of kernels since the last call (reset on read). */
@@ -222,6 +231,7 @@ typedef int (*lcb_process_cb)(void* user, const lcb_seed* seeds, int64_t n, uint
 typedef int (*lcb_mark_cb)(void* user, const uint64_t* ranges, int64_t n);
 typedef int (*lcb_reset_cb)(void* user);
 typedef struct {
+    int32_t abi;                /* = LCB_ABI_VERSION (the struct is allocated by the caller: a mismatch is rejected, not misread) */
     int32_t rank, world;
     lcb_allgather_cb allgather;
     void* allgather_user;
@@ -246,6 +256,9 @@ typedef struct {
     int32_t host_commit;        /* 1: the ordered commit of a round runs on the host only (for A/B runs and tests). Default: the clean prefix of
                                    every round is validated, conflict-checked and marked used by lcb_commit_kernel on the device, chained behind
                                    the round's kernels; the host mirrors those commits and takes over at the first seed that needs a new result */
+    int32_t lazy_span;          /* a round spans at least this many phases: the phases beyond the (adaptive) size of its speculative launch get their
+                                   phase-start results as background jobs against predicted views, planned while the commit works through the stops of the
+                                   phases in front of them. Default 8; -1 = off (a round is exactly its speculative launch) */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

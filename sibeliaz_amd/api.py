@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
                 ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [
                     (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "device_commits", "device_rounds", "early_critical")] + [
-                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double)]
+                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -47,22 +47,36 @@ MARK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 RESET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
+ABI_VERSION = 5        # LCB_ABI_VERSION of include/lcb.h: layout of Stats, Hooks, DeviceOpts (Hooks / DeviceOpts carry it in their first field)
+
+
 class Hooks(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allgather", ALLGATHER_CB), ("allgather_user", C.c_void_p),
+    _fields_ = [("abi", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("allgather", ALLGATHER_CB), ("allgather_user", C.c_void_p),
                 ("process", PROCESS_CB), ("mark", MARK_CB), ("reset", RESET_CB), ("engine_user", C.c_void_p),
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("host_commit", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("host_commit", C.c_int32),
+                ("lazy_span", C.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.abi = ABI_VERSION
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "host_commit")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "host_commit", "lazy_span")
 
 
 class DeviceOpts(C.Structure):
     """lcb_device_opts: tuning knobs of a device, 0 = default."""
-    _fields_ = [(n, C.c_uint32) for n in ("compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
-                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")]
+    _fields_ = [(n, C.c_uint32) for n in ("abi", "compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
+                                          "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")] + [
+                    # test hooks of the (segment, offset) positions: small segments on small inputs, flat indices beyond 2^32 (lcb.h)
+                    ("seg_cap", C.c_uint64), ("seg_gap", C.c_uint64)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.abi = ABI_VERSION
 
 
 class Counters(C.Structure):
@@ -71,8 +85,6 @@ class Counters(C.Structure):
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
-
-ABI_VERSION = 4        # LCB_ABI_VERSION of include/lcb.h: layout of Stats, Hooks, DeviceOpts
 
 REPROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
 
@@ -315,7 +327,7 @@ class Device:
         cap, fcap = max(1024, 64 * n), max(4096, 256 * n)
         while True:
             inst = np.zeros(cap, dtype=INSTANCE_DTYPE)
-            fp = np.zeros((fcap, 2), dtype="<u4")
+            fp = np.zeros((fcap, 2), dtype="<u8")
             rc = self.L.lcb_process_seeds_fp(self.h, s.ctypes.data, n, offsets.ctypes.data, inst.ctypes.data, cap, fp_off.ctypes.data, fp.ctypes.data, fcap)
             if rc == 0:
                 break

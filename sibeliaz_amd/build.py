@@ -22,7 +22,7 @@ LIB = os.path.join(PKG, "libsibeliaz_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 LIB_SRC = ["graph.cpp", "bundles.cpp", "commit.cpp", "engine.cpp", "output.cpp", "capi.cpp", "comm.hip", "device.hip"]
-LIB_HDR = ["lcb_host.h", "lcb_kernel.h", "lcb_device.h"]
+LIB_HDR = ["lcb_host.h", "lcb_kernel.h", "lcb_device.h", "lcb_segments.h", "lcb_kernel_limits.h"]
 
 
 def _newer(srcs, out):

@@ -36,14 +36,14 @@ void lcb_enumerate_seeds_impl(const lcb_graph& g, int threads, std::vector<lcb_s
 #pragma omp for schedule(dynamic, 4096)
         for (int64_t v = -V + 1; v < V; v++) {
             const uint32_t av = (uint32_t)(v < 0 ? -v : v);
-            const uint32_t o0 = g.occStart[av], o1 = g.occStart[av + 1];
+            const uint64_t o0 = g.occStart[av], o1 = g.occStart[av + 1];
             if (o1 - o0 < 2) continue;                                   // count > 1 needs two occurrences
             uint32_t count[256] = {0};
             bool good[256] = {false};
             unsigned char seen[8]; int nSeen = 0;                        // distinct characters, tiny
             unsigned char overflow[256]; int nOver = 0;
-            for (uint32_t j = o0; j < o1; j++) {
-                const uint32_t p = g.occG[j];
+            for (uint64_t j = o0; j < o1; j++) {
+                const uint64_t p = g.occG[j];
                 const bool positive = g.posId[p] == (int32_t)v;          // JunctionIterator::IsPositiveStrand
                 const unsigned char ch = positive ? g.posCh[p] : g.posRevCh[p];
                 if (count[ch]++ == 0) { if (nSeen < 8) seen[nSeen++] = ch; else overflow[nOver++] = ch; }
@@ -56,8 +56,8 @@ void lcb_enumerate_seeds_impl(const lcb_graph& g, int threads, std::vector<lcb_s
                     b.vid = (int32_t)v; b.ch = (int32_t)(signed char)ch; b.count = count[ch];
                     b.rank = 0; b.resolve_pos = UINT64_MAX; b.resolve_chr = UINT64_MAX;
                     uint64_t base = 1;
-                    for (uint32_t j = o0; j < o1; j++) {
-                        const uint32_t p = g.occG[j];
+                    for (uint64_t j = o0; j < o1; j++) {
+                        const uint64_t p = g.occG[j];
                         const bool positive = g.posId[p] == (int32_t)v;
                         const unsigned char c2 = positive ? g.posCh[p] : g.posRevCh[p];
                         if (c2 != ch) continue;

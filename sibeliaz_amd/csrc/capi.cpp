@@ -21,13 +21,21 @@ void lcb_set_error(const std::string& msg) { g_error = msg; }
     catch (...) { g_error = "unknown error"; return ret; }
 
 namespace {
+// The structs of the ABI are allocated by the caller: one built against another header would be misread field by field.
+void checkAbi(const lcb_hooks* hooks, const lcb_device_opts* opts)
+{
+    if (hooks && hooks->abi != LCB_ABI_VERSION) throw LcbError("lcb_hooks.abi is " + std::to_string(hooks->abi) + ", this library has LCB_ABI_VERSION " + std::to_string(LCB_ABI_VERSION));
+    if (opts && opts->abi != (uint32_t)LCB_ABI_VERSION) throw LcbError("lcb_device_opts.abi is " + std::to_string(opts->abi) + ", this library has LCB_ABI_VERSION " + std::to_string(LCB_ABI_VERSION));
+}
+
 LcbEngineConfig tuningOf(const lcb_hooks* hooks)
 {
+    checkAbi(hooks, nullptr);
     LcbEngineConfig cfg;
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0; cfg.lazySpan = hooks->lazy_span;
     }
     return cfg;
 }
@@ -94,6 +102,7 @@ lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int de
 {
     LCB_TRY
     if (!g || !p) throw LcbError("lcb_device_create_ex: null argument");
+    checkAbi(nullptr, opts);
     return lcb_device_create_impl(g, p, device_ordinal, opts);
     LCB_CATCH(nullptr)
 }
@@ -136,7 +145,7 @@ int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t*
 }
 
 int lcb_process_seeds_fp(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets, lcb_instance* inst, uint64_t inst_cap,
-                         uint64_t* fp_offsets, uint32_t* fp, uint64_t fp_cap)
+                         uint64_t* fp_offsets, uint64_t* fp, uint64_t fp_cap)
 {
     LCB_TRY
     LCB_NEED(d && (seeds || n == 0) && offsets && fp_offsets && (inst || inst_cap == 0) && (fp || fp_cap == 0), "lcb_process_seeds_fp");
@@ -148,7 +157,7 @@ int lcb_process_seeds_fp(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64
     memcpy(fp_offsets, fpOff.data(), fpOff.size() * sizeof(uint64_t));
     if (res.size() > inst_cap || fps.size() > fp_cap) throw LcbError("lcb_process_seeds_fp: inst_cap / fp_cap too small (needed counts are in offsets[n] / fp_offsets[n])");
     if (!res.empty()) memcpy(inst, res.data(), res.size() * sizeof(lcb_instance));
-    static_assert(sizeof(lcb_fp) == 8, "footprint intervals are pairs of uint32");
+    static_assert(sizeof(lcb_fp) == 16, "footprint intervals are pairs of uint64");
     if (!fps.empty()) memcpy(fp, fps.data(), fps.size() * sizeof(lcb_fp));
     return LCB_OK;
     LCB_CATCH(LCB_ERR)
@@ -207,7 +216,7 @@ struct CallbackProcessor : LcbProcessor {
         }
         inst.resize(off[(size_t)n]);
         fpOff.resize((size_t)n + 1);
-        fp.assign((size_t)n, lcb_fp{0u, UINT32_MAX});
+        fp.assign((size_t)n, lcb_fp{0u, UINT64_MAX});
         for (int64_t i = 0; i <= n; i++) fpOff[(size_t)i] = (uint64_t)i;
     }
     void mark(const uint64_t* ranges, int64_t n) override { if (h->mark(h->engine_user, ranges, n)) throw LcbError("mark callback failed"); }
@@ -221,12 +230,13 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
     LCB_TRY
     LCB_NEED(g && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks_ex");
     LcbEngineConfig cfg;
+    checkAbi(hooks, nullptr);
     if (hooks) {
         cfg.rank = hooks->rank; cfg.world = hooks->world > 0 ? hooks->world : 1;
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0; cfg.lazySpan = hooks->lazy_span;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -298,6 +308,7 @@ int lcb_find_blocks_gpus(const lcb_graph* g, const int* device_ordinals, int n_d
     LCB_TRY
     LCB_NEED(g && device_ordinals && p && (seeds || n_seeds == 0) && blocks && n_blocks, "lcb_find_blocks_gpus");
     std::vector<lcb_block> v;
+    checkAbi(nullptr, opts);
     lcb_find_blocks_gpus_impl(g, device_ordinals, n_devices, p, opts, seeds, n_seeds, tuningOf(hooks), v, stats);
     return giveBlocks(v, blocks, n_blocks);
     LCB_CATCH(LCB_ERR)
@@ -308,6 +319,7 @@ lcb_gpus* lcb_gpus_create(const lcb_graph* g, const int* device_ordinals, int n_
 {
     LCB_TRY
     if (!g || !device_ordinals || !p) throw LcbError("lcb_gpus_create: null argument");
+    checkAbi(nullptr, opts);
     return new lcb_gpus{lcb_gpus_create_impl(g, device_ordinals, n_devices, p, opts, always_comm != 0)};
     LCB_CATCH(nullptr)
 }

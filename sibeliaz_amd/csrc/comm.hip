@@ -83,6 +83,8 @@ Rccl& rccl()
 struct lcb_comm {
     ncclComm_t comm = nullptr;
     std::atomic<bool> aborted{false};    // set (never cleared) when another rank thread of the set failed: no further collective is issued
+    std::mutex issue;                    // held while a collective is ISSUED on `comm` and while the communicator is aborted: the check of `aborted` and
+                                         // the call into RCCL are one step for the aborting thread (a thread that waits for a collective holds nothing)
     int rank = 0, world = 1, ordinal = 0;
     hipStream_t stream = nullptr;
     void* dSend = nullptr; void* dRecv = nullptr;
@@ -106,7 +108,11 @@ struct lcb_comm {
         use();
         reserve((size_t)n);
         HIP_CHECK(hipMemcpyAsync(dSend, send, (size_t)n, hipMemcpyHostToDevice, stream));
-        RCCL_CHECK(rccl().AllGather(dSend, dRecv, (size_t)n, ncclChar, comm, stream));
+        {
+            std::lock_guard<std::mutex> lock(issue);
+            if (aborted.load(std::memory_order_acquire)) throw LcbError("the communicator was aborted (another rank failed)");
+            RCCL_CHECK(rccl().AllGather(dSend, dRecv, (size_t)n, ncclChar, comm, stream));
+        }
         HIP_CHECK(hipMemcpyAsync(recv, dRecv, (size_t)n * (size_t)world, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         gathers++; bytes += n * (uint64_t)world;
@@ -228,7 +234,7 @@ void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t 
                 if (!m->broken && n > 1) {
                     m->broken = true;
                     for (auto c : m->comm) if (c) c->aborted.store(true, std::memory_order_release);
-                    for (auto c : m->comm) if (c && c->comm) (void)rccl().CommAbort(c->comm);
+                    for (auto c : m->comm) if (c && c->comm) { std::lock_guard<std::mutex> issuing(c->issue); (void)rccl().CommAbort(c->comm); }
                 }
             }
         });

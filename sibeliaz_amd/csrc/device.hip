@@ -2,8 +2,9 @@
 // single-GPU phase loop (BlocksFinder::FindBlocks, blocksfinder.h:453-530).
 //
 // Data layout in HBM (one copy per GPU, read-only except `used`):
-//   chrStart u32[C+1] | posId i32[P] | posPos u32[P] | posCh u8[P] | posRevCh u8[P]
-//   occStart u32[V+1] | occRec uint4[P] = {g, chr, pos, id} | used u32[ceil(P/32)+1] x (1 + views)      ~ 30 B per occurrence
+//   chrLoHi uint2[C] | segBase u64[32] | posId i32[P] | posPos u32[P] | posCh u8[P] | posRevCh u8[P]
+//   occStart u64[V+1] | occRec uint4[P] = {g, segment | chr, pos, id} | used u32[ceil(P/32)+1] + private pages of the views      ~ 30 B per occurrence
+// A position is (segment, 32-bit g), flat index segBase[segment] + g (lcb_segments.h): inputs below 2^32 occurrences are one segment.
 // Seeds and results travel through pinned, device-mapped host memory (the kernels read 16 B per seed and write a 40-B
 // header + 16 B per result instance + 8 B per footprint interval), so a launch needs no explicit copies.
 //
@@ -31,6 +32,7 @@
 
 #include "lcb_device.h"
 #include "lcb_kernel.h"
+#include "lcb_segments.h"
 
 #define HIP_CHECK(x)                                                                              \
     do {                                                                                          \
@@ -51,12 +53,13 @@
 #endif
 #define LCB_NW_HUGE 8
 // PROF adds the in-kernel section timers (LCB_DEBUG / LCB_TRACE_SEEDS); compiled out otherwise.
-template <int MODE, bool STATS, int NW, bool PROF>
+// SEG: the input has several segments (2^32 positions or more; lcb_kernel.h) - inputs of one segment run kernels without any segment code.
+template <int MODE, bool STATS, int NW, bool PROF, bool SEG>
 __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKParams P, const LcbKSeed* seeds, uint32_t nSeeds,
                                                          LcbWork W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
-                                                         uint2* fpArena, unsigned long long fpCap)
+                                                         LcbFpOut* fpArena, unsigned long long fpCap)
 {
-    lcb_process_body<MODE, STATS, NW, PROF>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
+    lcb_process_body<MODE, STATS, NW, PROF, SEG>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
 __global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive,
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void lcb_init_slots_kernel(uint8_t* base, uint
     for (uint32_t i = threadIdx.x; i < pathCap; i += blockDim.x) pKeys[i] = LCB_EMPTY_KEY;
     int32_t* vKey = (int32_t*)(slot + L.vKey);
     uint32_t* vCount = (uint32_t*)(slot + L.vCount);
-    uint32_t* vLast = (uint32_t*)(slot + L.vLast);
+    unsigned long long* vLast = (unsigned long long*)(slot + L.vLast);      // (slots with a vote table are the huge variant's: LcbCfg<3>::VLast)
     for (uint32_t i = threadIdx.x; i < voteCap; i += blockDim.x) { vKey[i] = LCB_EMPTY_KEY; vCount[i] = 0; vLast[i] = 0; }
 }
 
@@ -182,7 +185,7 @@ struct ViewSpace {
 struct SideLane {
     hipStream_t sw = nullptr, sb = nullptr;      // the wide and the big kernel of a batch run side by side
     hipEvent_t w0 = nullptr, w1 = nullptr, b0 = nullptr, b1 = nullptr;
-    LcbKSeed* hSeeds = nullptr; LcbSeedOut* hOut = nullptr; uint4* hArena = nullptr; uint2* hFp = nullptr;
+    LcbKSeed* hSeeds = nullptr; LcbSeedOut* hOut = nullptr; uint4* hArena = nullptr; LcbFpOut* hFp = nullptr;
     uint32_t* hList = nullptr;                   // pinned: ticket -> job index, [cap] for the wide kernel then [cap] for the big one
     uint32_t* hCtl = nullptr;                    // pinned staging of the control words
     uint32_t* dCtl = nullptr;                    // device: [0] wide tickets [1] big tickets [2..3] arena [4..5] footprints [6] wide jobs [7] big jobs [8] stop flag
@@ -204,6 +207,9 @@ struct lcb_device_impl {
     lcb_device_opts o{};
     LcbTables T{};
     LcbKParams KP{};
+    LcbSegPlan plan;                             // host positions <-> (segment, g) of the device tables
+    bool seg = false;                            // the SEG instantiations of the kernels run (several segments)
+    uint64_t* dChrBase = nullptr;                // [C] flat index of every chromosome's first position (commit kernel)
     std::vector<void*> owned;
     uint32_t* dUsed = nullptr;                   // the live bitmap
     size_t usedWords = 0;                        // its words (a multiple of the page size)
@@ -221,7 +227,7 @@ struct lcb_device_impl {
         uint32_t n = 0, phase = 0;
         LcbSeedOut* dOut = nullptr; uint32_t* dState = nullptr; size_t cap = 0;      // [cap] seeds of a round
         uint32_t* dChrStamp = nullptr;
-        uint2* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 16;      // ranges marked by the current round's commits
+        LcbFpOut* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 16;      // ranges marked by the current round's commits
         uint32_t* hIdx = nullptr;                // pinned: launch-local seed index -> index in the round
         uint32_t* hState = nullptr;              // pinned: LCB_CS_* words
         uint32_t* hCommitted = nullptr; size_t committedCap = 0;                   // pinned
@@ -238,11 +244,11 @@ struct lcb_device_impl {
     LcbSeedOut* hOut = nullptr;
     LcbSeedCtr* hCtr = nullptr;                  // stats / instrumented variants only
     uint4* hArena = nullptr;
-    uint2* hFp = nullptr;                        // footprint arena (pinned)
+    LcbFpOut* hFp = nullptr;                     // footprint arena (pinned)
     unsigned long long fpCap = 0;
     LcbMarkRange* hRanges = nullptr;
     // second set of the host buffers, for the launch that runs while the host still commits the previous round (processBegin/End)
-    LcbKSeed* hSeedsB = nullptr; LcbSeedOut* hOutB = nullptr; uint4* hArenaB = nullptr; uint2* hFpB = nullptr; uint32_t* hLiveB = nullptr;
+    LcbKSeed* hSeedsB = nullptr; LcbSeedOut* hOutB = nullptr; uint4* hArenaB = nullptr; LcbFpOut* hFpB = nullptr; uint32_t* hLiveB = nullptr;
     unsigned long long arenaCapB = 0, fpCapB = 0;
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     void swapBufs()
@@ -311,6 +317,21 @@ struct lcb_device_impl {
         return (T_*)d;
     }
 
+    // a per-position table: the segments of the host array go to their places in the device's flat index space (contiguous unless a
+    // test put gaps between them)
+    template <class T_>
+    T_* uploadSeg(const T_* src, const LcbSegPlan& pl)
+    {
+        void* dv = nullptr;
+        HIP_CHECK(hipMalloc(&dv, (size_t)(pl.devPositions ? pl.devPositions : 1) * sizeof(T_)));
+        owned.push_back(dv);
+        for (uint32_t sg = 0; sg < pl.nSeg(); sg++) {
+            const uint64_t a = pl.segStart[sg], b = pl.segStart[sg + 1];
+            if (b > a) HIP_CHECK(hipMemcpy((T_*)dv + pl.segDev[sg], src + a, (size_t)(b - a) * sizeof(T_), hipMemcpyHostToDevice));
+        }
+        return (T_*)dv;
+    }
+
     void allocWork(WorkSet& w)
     {
         if (w.base) { HIP_CHECK(hipFree(w.base)); w.base = nullptr; }
@@ -329,7 +350,7 @@ struct lcb_device_impl {
         if (hFp) HIP_CHECK(hipHostFree(hFp));
         arenaCap = cap; fpCap = cap;
         HIP_CHECK(hipHostMalloc((void**)&hArena, (size_t)cap * sizeof(uint4), hipHostMallocDefault));
-        HIP_CHECK(hipHostMalloc((void**)&hFp, (size_t)cap * sizeof(uint2), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&hFp, (size_t)cap * sizeof(LcbFpOut), hipHostMallocDefault));
     }
 
     // One launch over hSeeds[0..m): optional screening, then the process kernel of w's variant. Returns after the stream
@@ -365,29 +386,31 @@ struct lcb_device_impl {
             HIP_CHECK(hipGetLastError());
         }
 #define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))
-#define LCB_LAUNCH(MODE, ST, PF) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
+#define LCB_LAUNCH(MODE, ST, PF, SG) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF, SG>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
                                                   T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
-#define LCB_LAUNCH_MODE(MODE) do { if (stats) LCB_LAUNCH(MODE, true, false); else if (prof) LCB_LAUNCH(MODE, false, true); else LCB_LAUNCH(MODE, false, false); } while (0)
+#define LCB_LAUNCH_SEG(MODE, ST, PF) do { if (seg) LCB_LAUNCH(MODE, ST, PF, true); else LCB_LAUNCH(MODE, ST, PF, false); } while (0)
+#define LCB_LAUNCH_MODE(MODE) do { if (stats) LCB_LAUNCH_SEG(MODE, true, false); else if (prof) LCB_LAUNCH_SEG(MODE, false, true); else LCB_LAUNCH_SEG(MODE, false, false); } while (0)
         if (w.mode == 3) LCB_LAUNCH_MODE(3);
         else if (w.mode == 2) LCB_LAUNCH_MODE(2);
         else if (w.mode == 1) LCB_LAUNCH_MODE(1);
         else LCB_LAUNCH_MODE(0);
 #undef LCB_LAUNCH_MODE
+#undef LCB_LAUNCH_SEG
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(evB, stream));       // [evA, evB]: screening + process kernel (the commit kernel behind them is not part of kernel_ms)
         if (round) {
             // the ordered commit of the round goes on as far as the results reach, behind the kernels that produced them
             LcbCommitArgs A;
-            A.chrStart = T.chrStart; A.used = dUsed; A.chrStamp = rc.dChrStamp;
+            A.chrBase = dChrBase; A.used = dUsed; A.chrStamp = rc.dChrStamp;
             A.roundState = rc.dState; A.roundOut = rc.dOut; A.arena = hArena; A.fpArena = hFp;
             A.n = rc.n; A.phase = rc.phase; A.nPos = T.nPos;
             A.state = rc.hState; A.committed = rc.hCommitted; A.deltaList = rc.dDeltaList; A.deltaCount = rc.dDeltaCount; A.deltaCap = rc.deltaCap;
-            A.pageShift = 10; while ((T.nPos >> A.pageShift) >= LCB_COMMIT_PAGES) A.pageShift++;
+            A.pageShift = 10; while ((T.nPos >> A.pageShift) >= (uint64_t)LCB_COMMIT_PAGES) A.pageShift++;
             hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, stream, A);
             HIP_CHECK(hipGetLastError());
             rc.kernels++;
         }
-        HIP_CHECK(hipEventRecord(evB, stream));
         if (screen) {      // the host only looks at the seeds that survived the screening
             HIP_CHECK(hipMemcpyAsync(hLive + batchCap, dCursor + 1, 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(hLive, dLive, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
@@ -470,8 +493,12 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, ordinal));
         const uint32_t nCu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        // defaults: compact 5 workgroups per CU (LDS-bound), wide 1 per CU, big 1 per CU
-        if (!o.compact_slots) o.compact_slots = 5 * nCu;
+        // positions: (segment, g) pairs (lcb_segments.h); seg_cap / seg_gap are test hooks (small segments on small inputs, flat indices
+        // beyond 2^32 through unused table space between the segments)
+        d->plan = lcb_plan_segments(*g, o.seg_cap, o.seg_gap);
+        d->seg = d->plan.nSeg() > 1 || o.seg_cap != 0;
+        // defaults: compact 5 workgroups per CU (LDS-bound; 4 with the segment tables of the SEG kernels), wide 1 per CU, big 1 per CU
+        if (!o.compact_slots) o.compact_slots = (d->seg ? 4 : 5) * nCu;
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
@@ -494,21 +521,31 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipEventCreate(&d->ev1));
         HIP_CHECK(hipEventCreate(&d->ev2));
         HIP_CHECK(hipEventCreate(&d->ev3));
-        const uint64_t P = g->nPos();
-        if (P >= (1ull << 32) - (1ull << 20)) throw LcbError("more than 2^32 - 2^20 junction occurrences are not supported by the device tables");
-        std::vector<uint32_t> cs(g->chrStart.begin(), g->chrStart.end());
-        d->T.chrStart = d->upload(cs.data(), cs.size());
-        d->T.posId = d->upload(g->posId.data(), P);
-        d->T.posPos = d->upload(g->posPos.data(), P);
-        d->T.posCh = d->upload(g->posCh.data(), P);
-        d->T.posRevCh = d->upload(g->posRevCh.data(), P);
-        d->T.occStart = d->upload(g->occStart.data(), g->occStart.size());
+        const LcbSegPlan& plan = d->plan;
+        const uint64_t nOcc = g->nPos(), P = plan.devPositions;      // P: length of the device tables (the occurrences + the test gaps)
         {
-            std::vector<uint4> rec((size_t)P);
+            std::vector<uint2> lh(g->nChr());
+            for (size_t c = 0; c < lh.size(); c++) lh[c] = uint2{plan.chrLo[c], plan.chrHi[c]};
+            d->T.chrLoHi = d->upload(lh.data(), lh.size());
+            d->T.segBase = d->upload(plan.segDev.data(), plan.segDev.size());
+            d->dChrBase = d->upload(plan.chrDev.data(), plan.chrDev.size());
+        }
+        d->T.posId = d->uploadSeg(g->posId.data(), plan);
+        d->T.posPos = d->uploadSeg(g->posPos.data(), plan);
+        d->T.posCh = d->uploadSeg(g->posCh.data(), plan);
+        d->T.posRevCh = d->uploadSeg(g->posRevCh.data(), plan);
+        if (d->seg) { d->T.occStart64 = d->upload(g->occStart.data(), g->occStart.size()); d->T.occStart32 = nullptr; }
+        else {      // one segment: fewer than 2^32 occurrences
+            std::vector<uint32_t> os(g->occStart.begin(), g->occStart.end());
+            d->T.occStart32 = d->upload(os.data(), os.size()); d->T.occStart64 = nullptr;
+        }
+        {
+            std::vector<uint4> rec((size_t)nOcc);
             #pragma omp parallel for schedule(static)
-            for (int64_t j = 0; j < (int64_t)P; j++) {
-                const uint32_t q = g->occG[j];
-                rec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]};
+            for (int64_t j = 0; j < (int64_t)nOcc; j++) {
+                const uint64_t q = g->occG[j];
+                const uint32_t cw = plan.chrWord[g->occChr[j]];
+                rec[j] = uint4{(uint32_t)(q - plan.segStart[cw >> LCB_SEG_SHIFT]), cw, g->posPos[q], (uint32_t)g->posId[q]};
             }
             d->T.occRec = d->upload(rec.data(), rec.size());
         }
@@ -527,7 +564,8 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         HIP_CHECK(hipMalloc((void**)&d->views.tab, (size_t)(d->maxViews + 1) * d->nPages * 4));
         HIP_CHECK(hipMemset(d->views.tab, 0, (size_t)(d->maxViews + 1) * d->nPages * 4));
         d->T.used = d->dUsed; d->T.viewTab = d->views.tab; d->T.nPages = d->nPages;
-        d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = (uint32_t)P;
+        d->T.nChr = g->nChr(); d->T.nVertex = g->nVertex; d->T.nPos = P; d->T.nSeg = plan.nSeg();
+        if (d->usedWords + (((uint64_t)d->views.poolBasePage + d->views.poolPages + 1) << LCB_PAGE_SHIFT) >= (1ull << 32)) throw LcbError("the `used` bitmap and its view pages need more than 2^32 words");
         d->KP.k = p->k; d->KP.minBlock = p->min_block; d->KP.maxBranch = p->max_branch; d->KP.maxFlank = p->max_flank;
         d->KP.depth = p->looking_depth;
         HIP_CHECK(hipMalloc((void**)&d->dCursor, 32));
@@ -590,7 +628,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             HIP_CHECK(hipHostMalloc((void**)&L.hSeeds, (size_t)L.cap * sizeof(LcbKSeed), hipHostMallocCoherent));
             HIP_CHECK(hipHostMalloc((void**)&L.hOut, (size_t)L.cap * sizeof(LcbSeedOut), hipHostMallocCoherent));
             HIP_CHECK(hipHostMalloc((void**)&L.hArena, (size_t)L.arenaCap * sizeof(uint4), hipHostMallocCoherent));
-            HIP_CHECK(hipHostMalloc((void**)&L.hFp, (size_t)L.arenaCap * sizeof(uint2), hipHostMallocCoherent));
+            HIP_CHECK(hipHostMalloc((void**)&L.hFp, (size_t)L.arenaCap * sizeof(LcbFpOut), hipHostMallocCoherent));
             HIP_CHECK(hipHostMalloc((void**)&L.hList, (size_t)2 * L.cap * sizeof(uint32_t), hipHostMallocCoherent));
             HIP_CHECK(hipHostMalloc((void**)&L.hCtl, 64, hipHostMallocCoherent));
             HIP_CHECK(hipMalloc((void**)&L.dCtl, 64));
@@ -691,8 +729,17 @@ void lcb_device_set_used_impl(lcb_device* h, const uint32_t* words, int64_t nWor
 {
     lcb_device_impl* d = h->impl;
     d->use();
-    if ((size_t)nWords > d->usedWords) throw LcbError("used bitmap has too many words");
-    HIP_CHECK(hipMemcpy(d->dUsed, words, (size_t)nWords * 4, hipMemcpyHostToDevice));
+    if ((uint64_t)nWords > d->g->nPos() / 32 + 2) throw LcbError("used bitmap has too many words");
+    if (!d->plan.gap) { HIP_CHECK(hipMemcpy(d->dUsed, words, (size_t)nWords * 4, hipMemcpyHostToDevice)); return; }
+    // (tests) unused table space between the segments: every segment's bits go to their place, shifted where the gap is not a multiple of 32
+    HIP_CHECK(hipMemset(d->dUsed, 0, d->usedWords * 4));
+    for (uint32_t sg = 0; sg < d->plan.nSeg(); sg++) {
+        const uint64_t a = d->plan.segStart[sg], b = std::min<uint64_t>(d->plan.segStart[sg + 1], (uint64_t)nWords * 32), da = d->plan.segDev[sg];
+        if (b <= a) continue;
+        std::vector<uint32_t> buf((size_t)(((da & 31) + (b - a) + 31) / 32), 0u);
+        for (uint64_t q = a; q < b; q++) if ((words[q >> 5] >> (q & 31)) & 1u) { const uint64_t t = (da & 31) + (q - a); buf[(size_t)(t >> 5)] |= 1u << (t & 31); }
+        HIP_CHECK(hipMemcpy(d->dUsed + (da >> 5), buf.data(), buf.size() * 4, hipMemcpyHostToDevice));     // (the neighbouring segments are a gap away: whole words)
+    }
 }
 
 void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
@@ -703,7 +750,7 @@ void lcb_device_mark_used_impl(lcb_device* h, const uint64_t* ranges, int64_t n)
     for (int64_t i = 0; i < n; i++) if (ranges[2 * i + 1] > P) throw LcbError("used range beyond the position table");
     for (int64_t done = 0; done < n;) {
         const uint32_t m = (uint32_t)((n - done) < (int64_t)d->rangeCap ? (n - done) : d->rangeCap);
-        for (uint32_t i = 0; i < m; i++) d->hRanges[i] = LcbMarkRange{ranges[2 * (done + i)], ranges[2 * (done + i) + 1]};
+        for (uint32_t i = 0; i < m; i++) { LcbMarkRange r; d->plan.rangeToDev(ranges[2 * (done + i)], ranges[2 * (done + i) + 1], r.lo, r.hi); d->hRanges[i] = r; }   // (a range lies inside one chromosome)
         hipLaunchKernelGGL(lcb_mark_kernel, dim3(m), dim3(256), 0, d->stream, d->dUsed, d->hRanges, m);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(d->stream));   // the pinned staging buffer is reused
@@ -726,9 +773,11 @@ static bool lcb_build_views_into(lcb_device_impl* d, ViewSpace& V, hipStream_t s
     std::vector<Piece> pc;
     for (int64_t k = 0; k < nMarks; k++) {
         if (marks[k].hi > P || marks[k].firstView < 1 || marks[k].hi <= marks[k].lo) throw LcbError("bad predicted mark");
-        for (uint64_t a = marks[k].lo; a < marks[k].hi;) {
+        uint64_t mlo, mhi;
+        d->plan.rangeToDev(marks[k].lo, marks[k].hi, mlo, mhi);
+        for (uint64_t a = mlo; a < mhi;) {
             const uint32_t page = (uint32_t)(a / pageBits);
-            const uint64_t end = std::min<uint64_t>(marks[k].hi, (uint64_t)(page + 1) * pageBits);
+            const uint64_t end = std::min<uint64_t>(mhi, (uint64_t)(page + 1) * pageBits);
             pc.push_back(Piece{page, marks[k].firstView, (uint32_t)(a - (uint64_t)page * pageBits), (uint32_t)(end - (uint64_t)page * pageBits)});
             a = end;
         }
@@ -936,10 +985,10 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
             if (A.bestScore) A.bestScore[s] = o.bestScore;
             if (A.wantFp) {
                 A.fpAt[(size_t)s] = A.fpFlat.size(); A.fpCnt[(size_t)s] = o.nFp;
-                const uint2* src = d->hFp + o.fpOff;
+                const LcbFpOut* src = d->hFp + o.fpOff;
                 const size_t f0 = A.fpFlat.size();
                 A.fpFlat.resize(f0 + o.nFp);
-                for (uint32_t e = 0; e < o.nFp; e++) A.fpFlat[f0 + e] = lcb_fp{src[e].x, src[e].y};
+                for (uint32_t e = 0; e < o.nFp; e++) A.fpFlat[f0 + e] = lcb_fp{d->plan.toHost(src[e].lo), d->plan.toHost(src[e].hi)};
             }
             if (A.perSeedCtr && d->stats) {
                 const LcbSeedCtr& k = d->hCtr[i];
@@ -1005,10 +1054,11 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
+            // (a round whose launches fill the shared result arenas: the arenas are emptied between launches again - from the NEXT batch on,
+            // which would otherwise find the allocator past the end and compute its seeds for nothing -, so the commit kernel can no longer
+            // find earlier results in place: what it has committed so far stands, the host commits the rest)
+            if (d->rc.active && (A.arenaOvf || hugeOverflow)) { d->rc.active = false; d->rc.abandoned++; }
         }
-        // (a round whose launches fill the shared result arenas: the arenas are emptied between launches again, so the commit kernel
-        // can no longer find earlier results in place - what it has committed so far stands, the host commits the rest)
-        if (d->rc.active && (A.arenaOvf || hugeOverflow)) { d->rc.active = false; d->rc.abandoned++; }
         if (A.growCompactPath) {
             // The compact path set starts small on purpose (the sets of all slots together stay cache-resident: 1280 x 128 KB)
             // and grows only for workloads whose paths need it (k = 25, long blocks of few genomes)
@@ -1028,9 +1078,12 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
             WorkSet& b = d->ws[3];
-            if (b.instCap >= 32768) throw LcbError("a seed needs more than 32768 path instances: not supported by the device");
-            d->allocArena(d->arenaCap * 4);
+            // (the reference's vectors are unbounded, path.h:683-685: the huge variant's capacities double until the memory is gone -
+            // pool indices are 32-bit there; from 2^16 instances on the number of slots halves with every doubling)
+            if (b.instCap >= (1u << 26)) throw LcbError("a seed needs more than 2^26 path instances: not supported by the device");
+            if (d->arenaCap < (1ull << 30)) d->allocArena(d->arenaCap * 4);
             b.pathCap *= 2; b.bodyCap *= 2; b.instCap *= 2; b.voteCap *= 2; b.bestCap *= 2;
+            if (b.instCap > 65536 && b.nSlots > 4) b.nSlots /= 2;
             d->allocWork(b);
         } else if (mode == 3 && !A.todo[3].empty()) d->allocArena(d->arenaCap * 4);
     }
@@ -1155,7 +1208,7 @@ bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t
     if (d->stats || n <= 0 || phase <= 0 || n > (int64_t)(1u << 30) || d->hDbg || d->seedTrace || d->forceProf) return false;
     d->use();
     auto& R = d->rc;
-    static_assert(sizeof(lcb_instance) == 16 && sizeof(lcb_fp) == 8, "layouts the commit kernel reads");
+    static_assert(sizeof(lcb_instance) == 16 && sizeof(LcbFpOut) == 16, "layouts the commit kernel reads");
     if ((size_t)n > R.cap) {
         for (void* q : {(void*)R.dOut, (void*)R.dState}) if (q) HIP_CHECK(hipFree(q));
         R.cap = std::max<size_t>((size_t)n, d->batchCap);
@@ -1169,7 +1222,7 @@ bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t
     }
     if (!R.dChrStamp) {
         HIP_CHECK(hipMalloc((void**)&R.dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
-        HIP_CHECK(hipMalloc((void**)&R.dDeltaList, (size_t)R.deltaCap * sizeof(uint2)));
+        HIP_CHECK(hipMalloc((void**)&R.dDeltaList, (size_t)R.deltaCap * sizeof(LcbFpOut)));
         HIP_CHECK(hipMalloc((void**)&R.dDeltaCount, 4));
         HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
         HIP_CHECK(hipHostMalloc((void**)&R.hIdx, (size_t)d->batchCap * 4, hipHostMallocDefault));
@@ -1284,8 +1337,10 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
         W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8; W.roundIdx = nullptr; W.roundOut = nullptr; W.roundState = nullptr;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         HIP_CHECK(hipEventRecord(e0, q));
-        if (w.mode == 2) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
-        else hipLaunchKernelGGL((lcb_process_kernel<1, false, LCB_NW_WIDE, false>), dim3(grid), dim3(64 * LCB_NW_WIDE), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        if (w.mode == 2 && d->seg) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false, true>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        else if (w.mode == 2) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false, false>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        else if (d->seg) hipLaunchKernelGGL((lcb_process_kernel<1, false, LCB_NW_WIDE, false, true>), dim3(grid), dim3(64 * LCB_NW_WIDE), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
+        else hipLaunchKernelGGL((lcb_process_kernel<1, false, LCB_NW_WIDE, false, false>), dim3(grid), dim3(64 * LCB_NW_WIDE), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(e1, q));
         d->modeSeeds[w.mode] += m;
@@ -1320,8 +1375,8 @@ int lcb_device_side_poll_impl(lcb_device* h, int lane, int64_t k, bool wait, std
     if (o.status == LCB_ST_OK) {
         const uint4* src = L.hArena + o.arenaOff;
         for (uint32_t e = 0; e < o.nInst; e++) inst.push_back(lcb_instance{src[e].x, src[e].y, src[e].z, src[e].w});
-        const uint2* fs = L.hFp + o.fpOff;
-        for (uint32_t e = 0; e < o.nFp; e++) fp.push_back(lcb_fp{fs[e].x, fs[e].y});
+        const LcbFpOut* fs = L.hFp + o.fpOff;
+        for (uint32_t e = 0; e < o.nFp; e++) fp.push_back(lcb_fp{d->plan.toHost(fs[e].lo), d->plan.toHost(fs[e].hi)});
         return 1;
     }
     if (o.status == LCB_ST_DIST_OVF) throw LcbError("a path longer than 2^31 bp is not supported");
@@ -1408,5 +1463,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
         stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
+        stats->lazy_seeds = es.lazySeeds;
     }
 }

@@ -362,8 +362,17 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         }
     };
 
+    // Lazy tail of a round. Where many results are void (the dense stretches: the head of the seed order) the adaptive size shrinks
+    // towards one phase per round - and with it the horizon of the dry runs, which plan the E's of LATER phases of the round against
+    // predicted views while the commit is still busy with the F chain of the current phase. A round therefore spans at least
+    // `lazySpan` phases; its speculative launch covers the first roundPhases of them (what the adaptation decided is worth computing
+    // against the round-start state), the others have no phase-start result until a dry run asks for one as a job - in the
+    // background, against the state predicted for their turn.
+    const int lazySpan = cfg.lazySpan < 0 ? 0 : (cfg.lazySpan ? cfg.lazySpan : 8);
     for (int64_t pos = 0; pos < nSeeds;) {
-        const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)roundPhases * phase);
+        const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)std::max(roundPhases, std::min(lazySpan, maxRound)) * phase);
+        const int64_t nEager = std::min<int64_t>(nRound, (int64_t)roundPhases * phase);     // seeds [nEager, nRound) are lazy
+        int64_t eagerRecomputed = 0;
         st.rounds++;
         flush();                                    // processor state == live state at the start of phase `pos`
         epochMarks.assign(1, RangeSet());
@@ -374,19 +383,24 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         if (useDevCommit) {
             const auto tp = std::chrono::steady_clock::now();
             dcCommitted.clear();
-            devCommit = proc.processRound(seeds + pos, nRound, phase, round.off, round.inst, round.fpOff, round.fp, dcCommitted, dcStopAt, dcStopKind);
+            devCommit = proc.processRound(seeds + pos, nEager, phase, round.off, round.inst, round.fpOff, round.fp, dcCommitted, dcStopAt, dcStopKind);
             st.processMs += msSince(tp);
             if (devCommit) launchOrdinal++;
         }
-        if (!devCommit) processSharded(seeds + pos, nullptr, nRound, round, (uint64_t)pos);
+        if (!devCommit) processSharded(seeds + pos, nullptr, nEager, round, (uint64_t)pos);
         const auto tSetup = std::chrono::steady_clock::now();
+        if (nEager < nRound) {                      // the lazy seeds: no result, nothing known
+            round.off.resize((size_t)nRound + 1, round.off[(size_t)nEager]); round.fpOff.resize((size_t)nRound + 1, round.fpOff[(size_t)nEager]);
+            if (cfg.countEvents) round.ctr.resize((size_t)nRound, lcb_counters{});
+            st.lazySeeds += nRound - nEager;
+        }
         cands.clear(); viewSets.clear();
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
         liveIdx.clear();
-        for (int64_t i = 0; i < nRound; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
+        for (int64_t i = 0; i < nEager; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
+        for (int64_t i = nEager; i < nRound; i++) liveIdx.push_back((int32_t)i);
         if (useSide) { sideJobs.clear(); sideSent.clear(); batches.clear(); laneOrder.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
-        const int64_t recomputedBefore = st.recomputedSeeds;
         st.sectionMs[LCB_SEC_SETUP] += msSince(tSetup);
 
         // the newest E result of seed i: instances / footprint / provenance
@@ -413,6 +427,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         };
         auto eValidNow = [&](int64_t i) -> bool {
             if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
+            if (i >= nEager) return false;          // a lazy seed: nothing has been computed for it yet
             return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
         };
 
@@ -621,6 +636,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                         const int64_t j = liveIdx[q];
                         bool ok;
                         if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
+                        else if (j >= nEager) ok = false;
                         else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
                         if (!ok && !onItsWay(j, false)) {
                             if (!any) { currentView(); any = true; }
@@ -751,6 +767,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 for (size_t k = 1; k <= nSync - nCrit; k++) { tmp.off.push_back(i0 + tmp2.off[k]); tmp.fpOff.push_back(f0 + tmp2.fpOff[k]); }
             }
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
+            for (auto& jb : jobs) if (jb.seed < nEager) eagerRecomputed++;
             if (midPhase) st.conflictLaunches++;
             if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views" << (lane >= 0 ? ", all but the first on side lane " + std::to_string(lane) : std::string()) << "\n";
             epochMarks.emplace_back();              // marks from here on belong to the new epoch
@@ -795,7 +812,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 takeMarks(true);
                 st.deviceCommits++;
             }
-            if (dcStopKind == 0) { donePh = nRound; if (curPh >= 0) com.endPhase(); st.deviceRounds++; }
+            if (dcStopKind == 0) { donePh = nEager; if (curPh >= 0) com.endPhase(); if (nEager == nRound) st.deviceRounds++; }
             else {
                 donePh = ((int64_t)dcStopAt / phase) * phase;
                 if (curPh >= 0 && curPh * phase < donePh) com.endPhase();                 // (a stop at a phase start: the previous phase is closed)
@@ -881,7 +898,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         }
         if (useSide) for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].state == 0) dropSide((int32_t)q);   // speculation beyond the round is void
         pos += nRound;
-        lastInvalid = (double)(st.recomputedSeeds - recomputedBefore) / (double)nRound;
+        lastInvalid = (double)eagerRecomputed / (double)nEager;       // (what the adaptation judges: the speculative launch)
         if (!fixedRound) {
             if (lastInvalid > 0.25) roundPhases = std::max(1, roundPhases / 2);
             else if (lastInvalid < 0.05) roundPhases = std::min(maxRound, roundPhases * 2);

@@ -203,7 +203,10 @@ lcb_graph* lcb_graph_load_impl(const char* junctionFile, const std::vector<std::
         for (size_t bI = 0; bI < blocks.size(); bI++) { blockAt[bI + 1] = blockAt[bI] + blocks[bI].kept; g->chrStart[blocks[bI].chr + 1] = blockAt[bI + 1]; }
         for (size_t c = 0; c < C; c++) if (g->chrStart[c + 1] < g->chrStart[c]) g->chrStart[c + 1] = g->chrStart[c];   // (a chromosome whose junctions were all filtered)
         const uint64_t P = blockAt[blocks.size()];
-        if (P >= 0xFFFFFF00ull) throw LcbError("more than 2^32 junction occurrences are not supported");
+        // The reference's limit is per chromosome (uint32_t idx / pos, junctionstorage.h:120-151; README.md:25-26), not on the input:
+        // positions are (segment, 32-bit offset) pairs on the device (lcb_segments.h), the host tables are 64-bit
+        for (size_t c = 0; c < C; c++)
+            if (g->chrStart[c + 1] - g->chrStart[c] >= LCB_SEG_POSITIONS) throw LcbError("a chromosome with 2^32 or more junctions is not supported");
         g->posId.resize(P); g->posPos.resize(P);
         bool unordered = false;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
@@ -255,22 +258,22 @@ lcb_graph* lcb_graph_load_impl(const char* junctionFile, const std::vector<std::
         for (size_t v = 0; v < g->nVertex; v++) g->occStart[v + 1] += g->occStart[v];
         g->occG.resize(P); g->occChr.resize(P);
         {
-            std::vector<uint32_t> cursor(g->occStart.begin(), g->occStart.end() - 1);
+            std::vector<uint64_t> cursor(g->occStart.begin(), g->occStart.end() - 1);
 #pragma omp parallel for num_threads(threads) schedule(static)
             for (int64_t i = 0; i < (int64_t)P; i++) {
                 const int32_t id = g->posId[i];
-                uint32_t at;
+                uint64_t at;
 #pragma omp atomic capture
                 at = cursor[(size_t)(id < 0 ? -(int64_t)id : id)]++;
-                g->occG[at] = (uint32_t)i;
+                g->occG[at] = (uint64_t)i;
             }
         }
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 4096)
         for (int64_t v = 0; v < (int64_t)g->nVertex; v++) {
-            const uint32_t a = g->occStart[(size_t)v], b2 = g->occStart[(size_t)v + 1];
-            if (b2 - a > 1) std::sort(g->occG.begin() + a, g->occG.begin() + b2);
-            for (uint32_t j = a; j < b2; j++)
-                g->occChr[j] = (uint32_t)(std::upper_bound(g->chrStart.begin(), g->chrStart.end(), (uint64_t)g->occG[j]) - g->chrStart.begin() - 1);
+            const uint64_t a = g->occStart[(size_t)v], b2 = g->occStart[(size_t)v + 1];
+            if (b2 - a > 1) std::sort(g->occG.begin() + (ptrdiff_t)a, g->occG.begin() + (ptrdiff_t)b2);
+            for (uint64_t j = a; j < b2; j++)
+                g->occChr[j] = (uint32_t)(std::upper_bound(g->chrStart.begin(), g->chrStart.end(), g->occG[j]) - g->chrStart.begin() - 1);
         }
     } catch (...) {
         delete g;

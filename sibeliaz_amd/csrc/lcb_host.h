@@ -10,7 +10,9 @@
 #include "lcb.h"
 
 // Structure-of-arrays replacement of Sibelia::JunctionStorage (junctionstorage.h:116-698).
-// Every junction occurrence kept by the abundance filter has a FLAT index g = chrStart[chr] + idx.
+// Every junction occurrence kept by the abundance filter has a FLAT index g = chrStart[chr] + idx (64-bit: the reference bounds a
+// chromosome by 2^32, junctionstorage.h:120-151, not the input).
+#define LCB_SEG_POSITIONS ((1ull << 32) - (1ull << 20))    // most positions of one device segment (lcb_segments.h), hence of one chromosome
 struct lcb_graph {
     int k = 0;
     std::vector<uint64_t> chrStart;        // [C+1]
@@ -19,8 +21,8 @@ struct lcb_graph {
     std::vector<uint8_t> posCh;            // [P]  Vertex::ch    = seq[pos+k]                     (junctionstorage.h:641)
     std::vector<uint8_t> posRevCh;         // [P]  Vertex::revCh = ReverseChar(seq[pos-1]) or 'N' (junctionstorage.h:642)
     uint32_t nVertex = 0;                  // vertex_.size() = max|id| + 1
-    std::vector<uint32_t> occStart;        // [V+1] CSR over |id|, replaces vertex_ (junctionstorage.h:695)
-    std::vector<uint32_t> occG;            // [P]  flat position of each occurrence, sorted by (chr, idx)
+    std::vector<uint64_t> occStart;        // [V+1] CSR over |id|, replaces vertex_ (junctionstorage.h:695)
+    std::vector<uint64_t> occG;            // [P]  flat position of each occurrence, sorted by (chr, idx)
     std::vector<uint32_t> occChr;          // [P]
     std::vector<std::string> chrName;      // sequenceDescription_
     std::vector<std::string> seq;          // sequence_ (host only: chars above + block sequences for output)
@@ -63,7 +65,7 @@ struct lcb_committer {
 };
 
 // A footprint interval: flat positions [lo, hi] whose `used` bit a per-seed computation read as 0 (lcb_kernel.h).
-struct lcb_fp { uint32_t lo, hi; };
+struct lcb_fp { uint64_t lo, hi; };
 
 // engine.cpp — the per-rank engine behind the phase loop: something that runs ProcessVertex::Process for a batch of
 // seeds against ITS current `used` state. The product's implementation is the HIP device (device.hip); tests plug in
@@ -203,6 +205,7 @@ struct LcbEngineConfig {
     bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
     bool hostCommit = false;  // never use the processor's commitRound: the ordered commit of a round runs on the host only (A/B runs, tests)
+    int lazySpan = 0;         // a round spans at least this many phases: those beyond the adaptive launch size get their phase-start results as jobs (0 = 8, -1 = off)
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
 
@@ -222,6 +225,7 @@ struct LcbEngineStats {
     int64_t deviceCommits = 0;    // results committed by the processor itself (commitRound), and ...
     int64_t deviceRounds = 0;     // ... rounds it committed completely
     int64_t earlyCritical = 0;    // stops whose own jobs ran while the rest was planned
+    int64_t lazySeeds = 0;        // seeds of the lazy tails of the rounds (no speculative launch: their phase-start results are jobs)
     int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)
     int64_t sideTaken = 0;        // ... results taken when the commit reached their seed (view came true)
     int64_t sideVoid = 0;         // ... jobs dropped because a mark of their view did not come true, or superseded by a newer plan

@@ -7,8 +7,12 @@
 // PointPushBack/Front + workers, Compatible, Score, Clear (path.h:33-46,380-677) and
 // DistanceKeeper (distancekeeper.h:9-41). It is a new design, not a translation:
 //
-//  * tables are structure-of-arrays over a FLAT position index g = chrStart[chr] + idx, so a
-//    look-ahead walk is a coalesced read of consecutive posId/posPos words (lanes = walk steps);
+//  * tables are structure-of-arrays over a FLAT position index (chromosome after chromosome), so a
+//    look-ahead walk is a coalesced read of consecutive posId/posPos words (lanes = walk steps). A position is a pair
+//    (segment, g): a segment is a run of whole chromosomes with fewer than 2^32 positions, g a 32-bit offset inside it, and the
+//    flat index is segBase[segment] + g. A chromosome never leaves its segment, so everything a path instance does - walks,
+//    gaps, ordering inside a chromosome - is 32-bit arithmetic on g; 64 bits appear where a table or the bitmap is addressed.
+//    Inputs of fewer than 2^32 positions are ONE segment with base 0: their kernels (SEG = false) have no segment code at all;
 //  * the per-chromosome std::multiset<Instance> becomes one key-sorted index array over an
 //    insertion-ordered instance pool (pool order IS allInstance_ order) in LDS;
 //  * the dense per-thread vote array count[2V+1] becomes an LDS hash table filled with
@@ -40,6 +44,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lcb_kernel_limits.h"
+
 #define LCB_EMPTY_KEY INT32_MIN
 // A pointer the compiler cannot prove to be a global one (it was merged with a null) is dereferenced with FLAT loads, which wait on
 // two counters and are slower; this says what it is. (Device compiler only: the CPU emulator of the tests sees a plain pointer.)
@@ -68,11 +74,13 @@
 //   mode 3 "huge":    everything in the global workspace, capacities chosen (and grown) by the host
 // IC instances, VC vote slots, BW Bloom words (0 = none), PC path-set slots in LDS (0 = global workspace)
 template <int MODE> struct LcbCfg;
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; };
-template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; };
-template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; };
-template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; };
-#define LCB_NONE16 0xFFFFu
+// Idx: a pool index / a vote-table slot (16 bits where the capacities are compile-time constants of a few thousand; 32 bits in the huge
+// variant, whose capacities grow with the path - the reference's vectors are unbounded, path.h:683-685); VLast: (ordinal of the last
+// contributing instance in the voting list, step) of a vote-table entry - 16 + 16 bits, or 32 + 32.
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; typedef uint32_t Idx; typedef unsigned long long VLast; };
 
 enum LcbStatus : uint32_t {
     LCB_ST_OK = 0,
@@ -86,22 +94,29 @@ enum LcbStatus : uint32_t {
     LCB_ST_PENDING = 0xFFFFFFFFu,   // header written by the screening kernel for a live seed (the process kernel overwrites it)
 };
 
+// Positions: a segment is a run of whole chromosomes with fewer than 2^32 junction occurrences in total; (segment, g) names the
+// occurrence segBase[segment] + g of the flat tables. The reference bounds a CHROMOSOME by 2^32 (junctionstorage.h:120-151: uint32_t
+// idx / pos per chromosome) and the number of chromosomes not at all; so do the tables here (up to LCB_MAX_SEG segments).
+// A "chromosome word" cw = (segment << LCB_SEG_SHIFT) | chromosome travels with every occurrence record and every instance.
 struct LcbTables {
-    const uint32_t* chrStart;   // [nChr+1]
-    const int32_t* posId;       // [nPos]  Position::id
+    const uint2* chrLoHi;       // [nChr]  the chromosome's positions inside its segment: g in [x, y)
+    const int32_t* posId;       // [nPos]  Position::id                  (flat index = segBase[segment] + g)
     const uint32_t* posPos;     // [nPos]  Position::pos
     const uint8_t* posCh;       // [nPos]  seq[pos + k]              (JunctionSequentialIterator::GetChar, + strand)
     const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
-    const uint32_t* occStart;   // [nVertex+1] CSR over |vertex id|
-    const uint4* occRec;        // [nPos]  per occurrence, ascending in g: {g, chr, Position::pos, Position::id} (one 16-B load)
-    const uint32_t* used;       // bitmap over g: bit g = Position::used of (chr, idx) — the LIVE state (view 0)
+    const uint32_t* occStart32; // [nVertex+1] CSR over |vertex id| (one segment: fewer than 2^32 occurrences) ...
+    const uint64_t* occStart64; // ... or 64-bit (SEG kernels); the other pointer is null
+    const uint4* occRec;        // [occurrences]  per occurrence, ascending in (segment, g): {g, cw, Position::pos, Position::id} (one 16-B load)
+    const uint64_t* segBase;    // [LCB_MAX_SEG] flat index of g = 0 of every segment (one segment: {0})
+    const uint32_t* used;       // bitmap over the flat index: bit = Position::used of (chr, idx) — the LIVE state (view 0)
     // Predicted views 1.. of it (engine.cpp) are copy-on-write at a granularity of 4-KB pages (1024 words, 32768 positions).
     // The private pages live BEHIND the live bitmap in the same allocation, and viewTab[v * nPages + page] is the word offset
     // from a page of the live bitmap to view v's copy of it (0 if the view shares the live page): word w of view v is
     // used[w + viewTab[v * nPages + (w >> 10)]].
     const uint32_t* viewTab;
     uint32_t nPages;
-    uint32_t nChr, nVertex, nPos;
+    uint32_t nChr, nVertex, nSeg;
+    uint64_t nPos;              // length of the flat tables
 };
 
 // The `used` state one seed reads: the live bitmap, or a predicted view of it through that view's page table.
@@ -122,6 +137,7 @@ struct LcbSeedOut {            // per-seed header written by the kernels (40 B)
     uint32_t nFp;              // number of footprint intervals (= instances ever created)
     uint32_t poolInst;         // instances in the pool when the seed ended (on an overflow: what the next variant has to hold at least)
 };
+struct LcbFpOut { unsigned long long lo, hi; };   // one footprint interval: flat positions [lo, hi]
 struct LcbSeedCtr { uint64_t c[16]; };  // [0..8): lcb_counters order in stats mode, a cheap profile in the instrumented variant; [8..16): vote sections (instrumented)
 
 struct LcbWork {               // per-workgroup global-memory workspace slots + the work queue of one launch
@@ -168,19 +184,19 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
     L.pSlots = o; o = lcb_align16(o + 4ull * (pathCap / 2 + 1));
     L.body = o; o = lcb_align16(o + 8ull * bodyCap);
     L.best = o; o = lcb_align16(o + 16ull * bestCap);
-    L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap);
+    L.ck = o; o = lcb_align16(o + 6ull * 4 * bestCap + 4ull * (LCB_MAX_SEG + 1));   // (+ the per-segment cursors of the ordered index)
     L.inst = o; o = lcb_align16(o + 9ull * 4 * instCap);
-    L.fp = o; o = lcb_align16(o + 2ull * 4 * instCap);
+    L.fp = o; o = lcb_align16(o + 3ull * 4 * instCap);                                // lo, hi, segment
     const uint32_t idxCap = voteCap ? instCap : 0;             // the index / list / vote arrays only exist in huge mode
     L.ordKey = o; o = lcb_align16(o + 2ull * 4 * idxCap);
-    L.ordIdx = o; o = lcb_align16(o + 2ull * 2 * idxCap);
-    L.good = o; o = lcb_align16(o + 2ull * idxCap);
-    L.goodPos = o; o = lcb_align16(o + 2ull * idxCap);
-    L.touch = o; o = lcb_align16(o + 2ull * idxCap);
+    L.ordIdx = o; o = lcb_align16(o + 2ull * 4 * idxCap);          // (the huge variant's indices are 32-bit: LcbCfg<3>::Idx)
+    L.good = o; o = lcb_align16(o + 4ull * idxCap);
+    L.goodPos = o; o = lcb_align16(o + 4ull * idxCap);
+    L.touch = o; o = lcb_align16(o + 4ull * idxCap);
     L.vKey = o; o = lcb_align16(o + 4ull * voteCap);
     L.vCount = o; o = lcb_align16(o + 4ull * voteCap);
-    L.vLast = o; o = lcb_align16(o + 4ull * voteCap);
-    L.vTouched = o; o = lcb_align16(o + 2ull * voteCap);
+    L.vLast = o; o = lcb_align16(o + 8ull * voteCap);
+    L.vTouched = o; o = lcb_align16(o + 4ull * voteCap);
     L.total = lcb_align16(o);
     return L;
 }
@@ -215,8 +231,10 @@ __host__ __device__ inline LcbSlotLayout lcb_slot_layout(uint32_t pathCap, uint3
 // wave-uniform value -> scalar register (every lane must hold the same value; uniform control flow only)
 __device__ __forceinline__ uint32_t lcb_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int32_t lcb_rfl(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t lcb_rfl(uint64_t v) { return ((uint64_t)lcb_rfl((uint32_t)(v >> 32)) << 32) | lcb_rfl((uint32_t)v); }
 // value of lane `l` (l wave-uniform) -> scalar register
 __device__ __forceinline__ uint32_t lcb_rl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint64_t lcb_rl(uint64_t v, uint32_t l) { return ((uint64_t)lcb_rl((uint32_t)(v >> 32), l) << 32) | lcb_rl((uint32_t)v, l); }
 __device__ __forceinline__ int32_t lcb_rl(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
 
 // Wave-wide max / min of a 32-bit value as a scalar: four row-shift steps inside the 16-lane rows, two row broadcasts,
@@ -237,11 +255,22 @@ __device__ __forceinline__ uint32_t lcb_wave_umin(uint32_t v) { return ~lcb_wave
 #define LCB_FLAG_POS 1u
 #define LCB_FLAG_BACKFIN 2u
 #define LCB_FLAG_FRONTFIN 4u
-#define LCB_FLAG_BITS 3u       // iFlags = (chromosome << 3) | flags
+#define LCB_FLAG_BITS 3u       // iFlags = (chromosome word << 3) | flags   (chromosome word: segment << LCB_SEG_SHIFT | chromosome)
+#define LCB_FLAG_SEG_SHIFT (LCB_SEG_SHIFT + LCB_FLAG_BITS)
 
-template <int MODE_>
+template <bool WIDE> struct LcbWidth { typedef uint32_t T; };
+template <> struct LcbWidth<true> { typedef uint64_t T; };
+
+template <int MODE_, bool SEG_>
 struct LcbStateT {
     static constexpr int MODE = MODE_;
+    typedef typename LcbCfg<MODE_>::Idx Idx;
+    typedef typename LcbCfg<MODE_>::VLast VLast;
+    static constexpr uint32_t NONE = (uint32_t)(Idx)~(Idx)0;      // "no position" in goodPos
+    static constexpr uint32_t LAST_SHIFT = 4u * sizeof(VLast);     // bits of the step in a VLast
+    static constexpr bool SEG = SEG_;          // the input has more than one segment (>= 2^32 positions, or a test asked for it)
+    typedef typename LcbWidth<SEG_>::T Flat;   // a flat position (segBase + g): 64-bit with several segments, else g itself
+    typedef typename LcbWidth<SEG_>::T OccIdx; // an index into the occurrence records
     // (Keeping the fields of the first pool entries of the big variant in LDS, -DLCB_BIG_HOT of round 2, was measured in round 3:
     // -1 % - the HBM-resident fields are not what makes the big variant slow - and removed.)
     typedef uint32_t* FieldU;
@@ -250,17 +279,19 @@ struct LcbStateT {
     LcbUsed U;                 // the `used` state this seed reads
     LcbKParams P;
     uint32_t lane;
+    const uint64_t* segBase;   // SEG: LDS copy of T.segBase
+    uint32_t* segFirst;        // SEG: [nSeg + 1] first entry of every segment in the ordered index (LDS)
     // instance pool (SoA) — pool index order == allInstance_ order (path.h:684)
     FieldU iFrontG, iBackG, iFrontPos, iBackPos, iLo, iHi, iFlags;
     FieldI iFrontDist, iBackDist;
     uint32_t* ordKey;          // instance_ ordered sets flattened: keys (flat compare position) ... [2][instCap], half `cur` is live
-    uint16_t* ordIdx;          // ... and pool indices, double buffered the same way
-    uint16_t* good;            // goodInstance_ (path.h:685), pool indices in append order
-    uint16_t* goodPos;         // inverse of `good`: position of an instance in the good list, or LCB_NONE16
+    Idx* ordIdx;               // ... and pool indices, double buffered the same way
+    Idx* good;                 // goodInstance_ (path.h:685), pool indices in append order
+    Idx* goodPos;              // inverse of `good`: position of an instance in the good list, or NONE
     // The instances the last successful push extended or created (after Init: the initial instances). Exactly these end at
     // the path end (their end distance equals the flank, and path distances are strictly monotone), so they are the voters
     // of the next vote (blocksfinder.h:716-717) — no scan over the instance list is needed.
-    uint16_t* touch;
+    Idx* touch;
     uint32_t nTouch, nInit;
     uint32_t endInst;          // instances in the pool when the seed ended (reported with an overflow status: the host picks the next variant by it)
     // Footprint: per instance ever created, the range of flat positions whose `used` bit was read as 0 and could
@@ -268,6 +299,8 @@ struct LcbStateT {
     // against an older `used` snapshot is still exact iff no bit inside these ranges has been set since
     // (bits only go 0 -> 1 and the computation is deterministic). Survives the replay's Clear.
     FieldU fpLo, fpHi;
+    uint8_t* fpSeg8;           // SEG: segment of every footprint slot (LDS-resident pools: bytes; else words behind fpHi)
+    uint32_t* fpSeg32;
     uint32_t nFp;
     // The replay (blocksfinder.h:271-284) re-creates pool entries 0 .. n0-1 exactly as the forward extension had created them
     // (same occurrences, same order), so they keep their footprint slots. What the backward extension creates afterwards re-uses
@@ -279,8 +312,8 @@ struct LcbStateT {
     // vote table (open addressing): key, accumulated weight, (list ordinal << 16) | step of the last contribution
     int32_t* vKey;
     uint32_t* vCount;
-    uint32_t* vLast;
-    uint16_t* vTouched;        // slots claimed in the current vote, in claim order
+    VLast* vLast;
+    Idx* vTouched;             // slots claimed in the current vote, in claim order
     uint32_t* vNClaimed;       // LDS counter: number of them
     uint32_t* vTicket;         // LDS counter: next entry of the touch list to hand to a wavefront (votes shared by more than two wavefronts)
     uint32_t* vOvf;            // LDS flag: a walk of the current vote could not place a vertex
@@ -295,7 +328,7 @@ struct LcbStateT {
     int32_t* pKeys;
     uint32_t* pSlots;
     uint32_t pathCap, pathShift;
-    unsigned long long* body;  // right body: (strand << 32) | g of the iterator whose outgoing edge was pushed
+    unsigned long long* body;  // right body: (strand << 40) | (segment << 32) | g of the iterator whose outgoing edge was pushed
     uint32_t bodyCap;
     uint4* best;
     uint32_t bestCap;
@@ -324,6 +357,18 @@ __device__ __forceinline__ uint32_t lcb_fp_slot(const ST& S, uint32_t i)
     if (i < S.fpSplit) return i;
     const uint32_t f = i + S.fpShift;
     return f < S.instCap ? f : i;      // no room for a slot of its own: it shares the old one (a superset: still exact)
+}
+
+// segment of footprint slot fs (SEG kernels)
+template <class ST>
+__device__ __forceinline__ void lcb_fp_set_seg(ST& S, uint32_t fs, uint32_t seg)
+{
+    if (ST::SEG) { if (LcbCfg<ST::MODE>::INST_LDS) S.fpSeg8[fs] = (uint8_t)seg; else S.fpSeg32[fs] = seg; }
+}
+template <class ST>
+__device__ __forceinline__ uint32_t lcb_fp_get_seg(const ST& S, uint32_t fs)
+{
+    return ST::SEG ? (LcbCfg<ST::MODE>::INST_LDS ? (uint32_t)S.fpSeg8[fs] : S.fpSeg32[fs]) : 0u;
 }
 
 // All fields of instance i, one per lane (lane f < 9 holds field f), with ONE load: the field arrays are equally spaced (lcb_process_body).
@@ -360,31 +405,48 @@ __device__ __forceinline__ uint32_t lcb_uword(const LcbUsed& U, uint32_t w)
     return U.live[w];
 }
 
-__device__ __forceinline__ bool lcb_used_bit(const LcbUsed& U, uint32_t g)
+// Flat positions (segBase + g) are 64-bit; the bitmap has fewer than 2^32 words (2^37 positions: 4 TB of tables), so a word index
+// is 32-bit. With one segment the base is the constant 0 and everything below folds back to 32-bit arithmetic on g.
+template <class ST>
+__device__ __forceinline__ typename ST::Flat lcb_seg_base(const ST& S, uint32_t seg) { return ST::SEG ? (typename ST::Flat)S.segBase[seg] : (typename ST::Flat)0; }
+// segment of a chromosome word / of an instance's flag word
+__device__ __forceinline__ uint32_t lcb_cw_seg(uint32_t cw) { return cw >> LCB_SEG_SHIFT; }
+__device__ __forceinline__ uint32_t lcb_fl_seg(uint32_t fl) { return fl >> LCB_FLAG_SEG_SHIFT; }
+
+// occurrences [o0, o1) of vertex |id| = av
+template <bool SEG>
+__device__ __forceinline__ typename LcbWidth<SEG>::T lcb_occ_start(const LcbTables& T, uint32_t av) { return SEG ? (typename LcbWidth<SEG>::T)T.occStart64[av] : (typename LcbWidth<SEG>::T)T.occStart32[av]; }
+
+// (F: uint32_t or uint64_t)
+template <class F>
+__device__ __forceinline__ bool lcb_used_bit(const LcbUsed& U, F f)
 {
-    return (lcb_uword(U, g >> 5) >> (g & 31)) & 1u;
+    return (lcb_uword(U, (uint32_t)(f >> 5)) >> ((uint32_t)f & 31u)) & 1u;
 }
 
-// JunctionSequentialIterator::IsUsed (junctionstorage.h:270-283): `used` marks the edge idx -> idx+1.
-__device__ __forceinline__ bool lcb_it_used(const LcbUsed& U, uint32_t g, bool positive, uint32_t lo)
+// JunctionSequentialIterator::IsUsed (junctionstorage.h:270-283): `used` marks the edge idx -> idx+1. (sb: base of the segment of g)
+template <class F>
+__device__ __forceinline__ bool lcb_it_used(const LcbUsed& U, F sb, uint32_t g, bool positive, uint32_t lo)
 {
-    if (positive) return lcb_used_bit(U, g);
-    return g > lo ? lcb_used_bit(U, g - 1) : false;
+    if (positive) return lcb_used_bit(U, (F)(sb + g));
+    return g > lo ? lcb_used_bit(U, (F)(sb + g - 1)) : false;
 }
 
-// JunctionSequentialIterator::GetChar (junctionstorage.h:234-243)
-__device__ __forceinline__ uint8_t lcb_it_char(const LcbTables& T, uint32_t g, bool positive)
+// JunctionSequentialIterator::GetChar (junctionstorage.h:234-243), f = flat index
+template <class F>
+__device__ __forceinline__ uint8_t lcb_it_char(const LcbTables& T, F f, bool positive)
 {
-    return positive ? T.posCh[g] : T.posRevCh[g];
+    return positive ? T.posCh[f] : T.posRevCh[f];
 }
 
 // Any used bit in [a, b)?  This is the `used` walk of Path::Compatible (path.h:387-393) for both strands:
-// + strand visits bits a..b-1 going up, - strand visits bits b-1..a going down.
-__device__ inline bool lcb_range_any_used(const LcbUsed& U, uint32_t a, uint32_t b)
+// + strand visits bits a..b-1 going up, - strand visits bits b-1..a going down. (flat indices)
+template <class F>
+__device__ inline bool lcb_range_any_used(const LcbUsed& U, F a, F b)
 {
     if (a >= b) return false;
-    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
-    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
+    const uint32_t ma = 0xFFFFFFFFu << ((uint32_t)a & 31), mb = 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
     if (wa == wb) return (lcb_uword(U, wa) & ma & mb) != 0;
     if (lcb_uword(U, wa) & ma) return true;
     for (uint32_t w = wa + 1; w < wb; w++)
@@ -393,11 +455,12 @@ __device__ inline bool lcb_range_any_used(const LcbUsed& U, uint32_t a, uint32_t
 }
 
 // Number of iterations the reference's walk makes over [a, b) (stats mode only).
-__device__ inline uint32_t lcb_range_walk_steps(const LcbUsed& used, uint32_t a, uint32_t b, bool up)
+template <class F>
+__device__ inline uint32_t lcb_range_walk_steps(const LcbUsed& used, F a, F b, bool up)
 {
     uint32_t steps = 0;
-    if (up) { for (uint32_t g = a; g < b; g++) { steps++; if (lcb_used_bit(used, g)) break; } }
-    else { for (uint32_t g = b; g > a; g--) { steps++; if (lcb_used_bit(used, g - 1)) break; } }
+    if (up) { for (F g = a; g < b; g++) { steps++; if (lcb_used_bit(used, g)) break; } }
+    else { for (F g = b; g > a; g--) { steps++; if (lcb_used_bit(used, (F)(g - 1))) break; } }
     return steps;
 }
 
@@ -488,6 +551,7 @@ __device__ inline void lcb_path_clear(ST& S)
     if (BW && S.nPath) for (uint32_t i = S.lane; i < (uint32_t)BW; i += 64) S.bloom[i] = 0;
     S.nPath = 0; S.nRight = 0; S.nLeft = 0; S.nInst = 0; S.nGood = 0; S.cur = 0; S.nTouch = 0;
     S.rightFlank = 0; S.leftFlank = 0;
+    if (ST::SEG && S.lane <= LCB_MAX_SEG) S.segFirst[S.lane] = 0;
     LCB_WAVE_SYNC();
 }
 
@@ -501,15 +565,18 @@ __device__ __forceinline__ int64_t lcb_real_length(const ST& S, uint32_t i)
     return (int64_t)lcb_absdiff(S.iFrontPos[i], S.iBackPos[i]);
 }
 
+// The ordered index is sorted by (segment, g): the entries of segment s are [segFirst[s], segFirst[s + 1]) and their keys are plain
+// 32-bit g (an occurrence is only ever compared with instances of its own chromosome, hence of its own segment). One segment:
+// the whole index, no cursors.
 // Rebuilds the ordered index after m inserts of one chunk. The insert list (position in the OLD order,
-// key, pool index) is in scr[0..m), scr[64..64+m), scr[128..128+m), ascending by position then key.
+// key, pool index; SEG: segment) is in scr[0..m), scr[64..64+m), scr[128..128+m), scr[192..192+m), ascending by position then key.
 template <class ST>
 __device__ inline void lcb_order_merge(ST& S, uint32_t m)
 {
     const uint32_t n = S.nInst - m;     // old element count (nInst already includes the new ones)
     const uint32_t c = S.cur, d = c ^ 1;
-    const uint32_t* ck = S.ordKey + c * S.instCap; const uint16_t* ci = S.ordIdx + c * S.instCap;
-    uint32_t* dk = S.ordKey + d * S.instCap; uint16_t* di = S.ordIdx + d * S.instCap;
+    const uint32_t* ck = S.ordKey + c * S.instCap; const typename ST::Idx* ci = S.ordIdx + c * S.instCap;
+    uint32_t* dk = S.ordKey + d * S.instCap; typename ST::Idx* di = S.ordIdx + d * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         uint32_t cnt = 0;
         for (uint32_t r = 0; r < m; r++) cnt += (S.scr[r] <= i) ? 1u : 0u;
@@ -519,7 +586,12 @@ __device__ inline void lcb_order_merge(ST& S, uint32_t m)
     if (S.lane < m) {
         const uint32_t at = S.scr[S.lane] + S.lane;
         dk[at] = S.scr[64 + S.lane];
-        di[at] = (uint16_t)S.scr[128 + S.lane];
+        di[at] = (typename ST::Idx)S.scr[128 + S.lane];
+    }
+    if (ST::SEG && S.lane <= LCB_MAX_SEG) {          // cursor t moves up by the inserts into the segments below t
+        uint32_t cnt = 0;
+        for (uint32_t r = 0; r < m; r++) cnt += (S.scr[192 + r] < S.lane) ? 1u : 0u;
+        S.segFirst[S.lane] += cnt;
     }
     S.cur = d;
     LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
@@ -533,19 +605,23 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
     lcb_path_insert(S, vid);          // distanceKeeper_.Set(vid, 0)
     if (S.status) return;
     const uint32_t av = (uint32_t)(vid < 0 ? -vid : vid);
-    const uint32_t o0 = lcb_rfl(T.occStart[av]), o1 = lcb_rfl(T.occStart[av + 1]);
-    for (uint32_t base = o0; base < o1; base += 64) {
-        const uint32_t j = base + S.lane;
+    typedef typename ST::Flat Flat;
+    typedef typename ST::OccIdx OccIdx;
+    const OccIdx o0 = lcb_rfl(lcb_occ_start<ST::SEG>(T, av)), o1 = lcb_rfl(lcb_occ_start<ST::SEG>(T, av + 1));
+    for (OccIdx base = o0; base < o1; base += 64) {
+        const OccIdx j = base + S.lane;
         bool ok = false;
-        uint32_t g = 0, chr = 0, lo = 0, hi = 0, pos = 0;
+        uint32_t g = 0, chr = 0, lo = 0, hi = 0, pos = 0;       // chr: the chromosome word (segment | chromosome)
         bool positive = false;
         if (j < o1) {
             if (STATS) S.cOcc++;
             const uint4 rec = T.occRec[j];
             g = rec.x; chr = rec.y; pos = rec.z;
-            lo = T.chrStart[chr]; hi = T.chrStart[chr + 1];
+            const uint2 lh = T.chrLoHi[chr & LCB_CHR_MASK];
+            lo = lh.x; hi = lh.y;
             positive = ((int32_t)rec.w == vid);
-            ok = !lcb_it_used(S.U, g, positive, lo) && (int32_t)lcb_it_char(T, g, positive) == ch;
+            const Flat sb = lcb_seg_base(S, lcb_cw_seg(chr));
+            ok = !lcb_it_used(S.U, sb, g, positive, lo) && (int32_t)lcb_it_char(T, (Flat)(sb + g), positive) == ch;
         }
         const unsigned long long m = __ballot(ok);
         const uint32_t cnt = (uint32_t)__popcll(m);
@@ -555,17 +631,26 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
             S.iFrontG[i] = g; S.iBackG[i] = g; S.iFrontPos[i] = pos; S.iBackPos[i] = pos;
             S.iFrontDist[i] = 0; S.iBackDist[i] = 0; S.iLo[i] = lo; S.iHi[i] = hi;
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
-            if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; }        // the replay re-creates instance i at the same occurrence
-            S.ordKey[S.cur * S.instCap + i] = g;   // occurrences ascend in g, so pool order == key order here
-            S.ordIdx[S.cur * S.instCap + i] = (uint16_t)i;
-            S.goodPos[i] = LCB_NONE16;
-            S.touch[i] = (uint16_t)i;              // every initial instance ends at the seed vertex: they vote first
+            if (i >= S.nFp) { S.fpLo[i] = g; S.fpHi[i] = g; lcb_fp_set_seg(S, i, lcb_cw_seg(chr)); }   // the replay re-creates instance i at the same occurrence
+            S.ordKey[S.cur * S.instCap + i] = g;   // occurrences ascend in (segment, g), so pool order == key order here
+            S.ordIdx[S.cur * S.instCap + i] = (typename ST::Idx)i;
+            S.goodPos[i] = ST::NONE;
+            S.touch[i] = (typename ST::Idx)i;              // every initial instance ends at the seed vertex: they vote first
         }
         S.nInst += cnt;
         if (S.nInst > S.nFp) S.nFp = S.nInst;
     }
     S.nTouch = S.nInst; S.nInit = S.nInst;
     LCB_WAVE_SYNC();
+    if (ST::SEG) {
+        // cursor t = number of instances in the segments below t (the pool is sorted by segment here)
+        if (S.lane <= LCB_MAX_SEG) {
+            uint32_t a = 0, b = S.nInst;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (lcb_fl_seg(S.iFlags[mid]) < S.lane) a = mid + 1; else b = mid; }
+            S.segFirst[S.lane] = a;
+        }
+        LCB_WAVE_SYNC();
+    }
 }
 
 // ---- the vote: MostPopularVertex (blocksfinder.h:708-768) --------------------------------------
@@ -588,13 +673,15 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // with the path set in LDS always walk exactly.
 // (Tried and measured slower on the MI355X, profiles/r03: requesting the next chunk of a voter ahead of time with unconditional,
 // straight-line loads - the main wavefront is bound by instruction issue, not by the round trips the prefetch hides.)
-struct LcbVoter { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; };
+template <class F> struct LcbVoterT { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; F sb; };   // sb: base of the voter's segment
 struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
 template <bool STATS, bool PROF = false, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
                                      uint32_t waveId, uint32_t nWaves, bool exact)
 {
     const LcbTables& T = S.T;
+    typedef typename ST::Flat Flat;
+    typedef LcbVoterT<Flat> LcbVoter;
     const uint32_t vmask = S.voteCap - 1;
     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
     const uint32_t depth = (uint32_t)S.P.depth, maxBranch = (uint32_t)S.P.maxBranch;
@@ -616,7 +703,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 if (t >= nTouch) return false;
                 const uint32_t i = lcb_rfl((uint32_t)S.touch[t]);
                 const uint32_t e = useGood ? lcb_rfl((uint32_t)S.goodPos[i]) : i;      // position in the voting list (its order breaks ties)
-                if (e == LCB_NONE16) continue;
+                if (e == ST::NONE) continue;
                 const uint32_t f = lcb_inst_fields(S, i);
                 const uint32_t fl = lcb_rl(f, LCB_F_FLAGS), fp = lcb_rl(f, LCB_F_FRONTPOS), bp = lcb_rl(f, LCB_F_BACKPOS);
                 v.e = e; v.i = i;
@@ -628,6 +715,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 v.positive = (fl & LCB_FLAG_POS) != 0;
                 v.dir = (forward == v.positive) ? 1 : -1;
                 v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                      // steps for which it.Valid() holds
+                v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(fl)]) : (Flat)0;
                 return true;
             }
         }
@@ -641,7 +729,7 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 if (t < nTouch) {
                     fI = S.touch[t];
                     fE = useGood ? (uint32_t)S.goodPos[fI] : fI;          // position in the voting list (its order breaks ties)
-                    is = fE != LCB_NONE16;
+                    is = fE != ST::NONE;
                     if (is) {
                         fFl = S.iFlags[fI];
                         const uint32_t fp = S.iFrontPos[fI], bp = S.iBackPos[fI];
@@ -661,9 +749,11 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
             v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
             const uint32_t hi = lcb_rl(fHi, b);
             v.weight = lcb_rl(fW, b);
-            v.positive = (lcb_rl(fFl, b) & LCB_FLAG_POS) != 0;
+            const uint32_t vfl = lcb_rl(fFl, b);
+            v.positive = (vfl & LCB_FLAG_POS) != 0;
             v.dir = (forward == v.positive) ? 1 : -1;
             v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
+            v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(vfl)]) : (Flat)0;
             return true;
         }
     };
@@ -676,11 +766,12 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
         w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
         w.pos = 0; w.id = 0; w.uw = 0;
         if (w.valid) {
-            w.pos = T.posPos[w.g];
-            w.id = T.posId[w.g];
+            // (wave-uniform table base + 32-bit lane offset)
+            w.pos = (T.posPos + v.sb)[w.g];
+            w.id = (T.posId + v.sb)[w.g];
             // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
-            const uint32_t ub = w.g - (v.positive ? 0u : 1u);
-            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, ub >> 5) >> (ub & 31);
+            const Flat ub = v.sb + (w.g - (v.positive ? 0u : 1u));
+            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, (uint32_t)(ub >> 5)) >> ((uint32_t)ub & 31u);
         }
         return w;
     };
@@ -717,11 +808,11 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                 }
                 if (old == LCB_EMPTY_KEY) {
                     const uint32_t t = atomicAdd(S.vNClaimed, 1u);
-                    if (t < claimCap) S.vTouched[t] = (uint16_t)h; else *S.vOvf = 1u;
+                    if (t < claimCap) S.vTouched[t] = (typename ST::Idx)h; else *S.vOvf = 1u;
                 }
                 if (old == LCB_EMPTY_KEY || old == vid) {
                     atomicAdd(&S.vCount[h], cur.weight);
-                    atomicMax(&S.vLast[h], (cur.e << 16) | d);
+                    atomicMax(&S.vLast[h], ((typename ST::VLast)cur.e << ST::LAST_SHIFT) | d);
                 } else *S.vOvf = 1u;
             }
             if (first < 64) {
@@ -764,12 +855,15 @@ __device__ inline LcbBest lcb_vote_argmax(const ST& S, bool forward, bool useGoo
     for (uint32_t q = s0 + S.lane; q < s1; q += 64) {
         const uint32_t t = S.vTouched[q];
         const int32_t key = S.vKey[t];
-        const uint32_t cnt = S.vCount[t], last = S.vLast[t];
-        const uint32_t e = last >> 16, d = last & 0xFFFFu;
+        const uint32_t cnt = S.vCount[t];
+        const typename ST::VLast last = S.vLast[t];
+        const uint32_t e = (uint32_t)(last >> ST::LAST_SHIFT), d = (uint32_t)(last & (((typename ST::VLast)1 << ST::LAST_SHIFT) - 1));
         const uint32_t i = useGood ? S.good[e] : e;
         const uint32_t g0 = forward ? S.iBackG[i] : S.iFrontG[i];
-        // JunctionSequentialIterator::operator< (junctionstorage.h:349-362): negative strand first, then chr, idx
-        const uint32_t hi = ((S.iFlags[i] & LCB_FLAG_POS) << 31) | (g0 >> 1), lo = (g0 << 31) | d;
+        // JunctionSequentialIterator::operator< (junctionstorage.h:349-362): negative strand first, then chr, idx = (segment, g);
+        // the step d has 16 bits (lcb_device_create checks -b)
+        const uint32_t afl = S.iFlags[i];
+        const uint32_t hi = ((afl & LCB_FLAG_POS) << 31) | (ST::SEG ? lcb_fl_seg(afl) << 26 : 0u) | (g0 >> 6), lo = (g0 << 26) | d;
         if (cnt > bCnt || (cnt == bCnt && (hi < bHi || (hi == bHi && lo < bLo)))) { bCnt = cnt; bHi = hi; bLo = lo; bVid = key; bE = e; }
     }
     LcbBest r;
@@ -928,51 +1022,62 @@ __device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& 
 
 // One occurrence of the pushed vertex: its record plus the three `used` words around it, so that IsUsed and (almost
 // always) the Compatible gap test need no further global loads.
-struct LcbOcc { uint4 rec; uint32_t lo, hi, wbase, uw0, uw1, uw2; };
+// g0: the g of bit 0 of uw0 (modulo 2^32: only differences g - g0 < 96 are used); sb: base of the occurrence's segment
+template <class F> struct LcbOccT { uint4 rec; uint32_t lo, hi, g0, uw0, uw1, uw2; F sb; };
 
-__device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, uint32_t j, bool active)
+template <class J>
+__device__ __forceinline__ uint4 lcb_load_rec(const LcbTables& T, J j, bool active)
 {
     uint4 r = uint4{0u, 0u, 0u, 0u};
     if (active) r = T.occRec[j];
     return r;
 }
 
-__device__ __forceinline__ LcbOcc lcb_finish_occ(const LcbTables& T, const LcbUsed& U, const uint4& rec, bool active)
+template <class ST>
+__device__ __forceinline__ LcbOccT<typename ST::Flat> lcb_finish_occ(const ST& S, const uint4& rec, bool active)
 {
-    LcbOcc o;
-    o.rec = rec; o.lo = 0; o.hi = 0; o.wbase = 0; o.uw0 = o.uw1 = o.uw2 = 0;
+    const LcbTables& T = S.T;
+    const LcbUsed& U = S.U;
+    typedef typename ST::Flat Flat;
+    LcbOccT<Flat> o;
+    o.rec = rec; o.lo = 0; o.hi = 0; o.g0 = 0; o.uw0 = o.uw1 = o.uw2 = 0; o.sb = 0;
     if (active) {
-        o.lo = T.chrStart[rec.y]; o.hi = T.chrStart[rec.y + 1];
-        const uint32_t wi = rec.x >> 5;
-        o.wbase = wi ? wi - 1 : 0;
+        const uint2 lh = T.chrLoHi[rec.y & LCB_CHR_MASK];
+        o.lo = lh.x; o.hi = lh.y;
+        o.sb = lcb_seg_base(S, lcb_cw_seg(rec.y));
+        const Flat f = o.sb + rec.x;
+        const uint32_t wi = (uint32_t)(f >> 5);
+        const uint32_t wbase = wi ? wi - 1 : 0;
+        o.g0 = rec.x - ((uint32_t)f & 31u) - (wi ? 32u : 0u);
         if (U.tab) {
             // the three words around the occurrence almost always share its page: one table entry serves them
             const uint32_t pg = wi >> LCB_PAGE_SHIFT, d = U.tab[pg];
-            const uint32_t w1 = o.wbase + 1, w2 = o.wbase + 2;
-            o.uw0 = U.live[o.wbase + ((o.wbase >> LCB_PAGE_SHIFT) == pg ? d : U.tab[o.wbase >> LCB_PAGE_SHIFT])];
+            const uint32_t w1 = wbase + 1, w2 = wbase + 2;
+            o.uw0 = U.live[wbase + ((wbase >> LCB_PAGE_SHIFT) == pg ? d : U.tab[wbase >> LCB_PAGE_SHIFT])];
             o.uw1 = U.live[w1 + ((w1 >> LCB_PAGE_SHIFT) == pg ? d : U.tab[w1 >> LCB_PAGE_SHIFT])];
             o.uw2 = U.live[w2 + ((w2 >> LCB_PAGE_SHIFT) == pg ? d : U.tab[w2 >> LCB_PAGE_SHIFT])];
-        } else { o.uw0 = U.live[o.wbase]; o.uw1 = U.live[o.wbase + 1]; o.uw2 = U.live[o.wbase + 2]; }
+        } else { o.uw0 = U.live[wbase]; o.uw1 = U.live[wbase + 1]; o.uw2 = U.live[wbase + 2]; }
     }
     return o;
 }
 
 // (The three words are combined with shifts, never selected by a computed index: a select among members of the struct turns into a
 // dynamically indexed load, which keeps the whole LcbOcc in scratch memory - 64 B per lane written and read back in every push.)
-__device__ __forceinline__ bool lcb_occ_bit(const LcbOcc& o, uint32_t g)
+template <class F>
+__device__ __forceinline__ bool lcb_occ_bit(const LcbOccT<F>& o, uint32_t g)
 {
-    const uint32_t off = g - (o.wbase << 5);                // 0..95 for g and g-1
+    const uint32_t off = g - o.g0;                          // 0..95 for g and g-1
     const uint64_t lo = (uint64_t)o.uw0 | ((uint64_t)o.uw1 << 32);
     return off < 64u ? ((lo >> off) & 1ull) != 0 : ((o.uw2 >> (off - 64u)) & 1u) != 0;
 }
 
 // lcb_range_any_used over [a, b), served from the cached words when the range lies inside them.
-__device__ __forceinline__ bool lcb_range_any_used_c(const LcbUsed& U, const LcbOcc& o, uint32_t a, uint32_t b)
+template <class F>
+__device__ __forceinline__ bool lcb_range_any_used_c(const LcbUsed& U, const LcbOccT<F>& o, uint32_t a, uint32_t b)
 {
     if (a >= b) return false;
-    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
-    if (wa < o.wbase || wb > o.wbase + 2) return lcb_range_any_used(U, a, b);
-    const uint32_t oa = a - (o.wbase << 5), ob = b - (o.wbase << 5);          // bit offsets into the 96 cached bits, oa < ob <= 96
+    const uint32_t oa = a - o.g0, ob = b - o.g0;                              // bit offsets into the 96 cached bits: oa < ob <= 96 if the range lies inside
+    if (oa >= 96u || ob > 96u || ob < oa) return lcb_range_any_used(U, (F)(o.sb + a), (F)(o.sb + b));
     const uint64_t lo = (uint64_t)o.uw0 | ((uint64_t)o.uw1 << 32);
     bool any = false;
     if (oa < 64u) {
@@ -989,7 +1094,7 @@ __device__ __forceinline__ bool lcb_range_any_used_c(const LcbUsed& U, const Lcb
 }
 
 // What a push needs to know about the walked edge (wave-uniform, in scalar registers).
-struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posIt, posN; int32_t ech; uint32_t o0, o1; };
+template <class J> struct LcbEdgeT { uint32_t gIt, segIt; bool itPositive; int32_t idIt, idN; uint32_t posIt, posN; int32_t ech; J o0; uint32_t nOcc; };   // occurrences [o0, o0 + nOcc) of the pushed vertex
 
 // ---- a push: PointPushBack / PointPushFront with their workers (path.h:430-602) ------------------
 // Per-occurrence outcomes.
@@ -1004,16 +1109,18 @@ struct LcbEdge { uint32_t gIt; bool itPositive; int32_t idIt, idN; uint32_t posI
 // rec0: the occurrence records o0 + lane of the pushed vertex, already loaded by the caller.
 // Returns false iff the vertex is already in the path (path.h:571-574,589-592).
 template <bool BACK, bool STATS, bool PROF, class ST>
-__device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint4& rec0)
+__device__ inline bool lcb_push(ST& S, const LcbEdgeT<typename ST::OccIdx>& E, bool record, const uint4& rec0)
 {
     const LcbTables& T = S.T;
+    typedef typename ST::Flat Flat;
+    typedef typename ST::OccIdx OccIdx;
     constexpr bool HOIST = !LcbCfg<ST::MODE>::INST_LDS;
     const uint64_t tq0 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
     const int32_t vertex = E.itPositive ? E.idN : -E.idN;            // pushed vertex
     const int32_t otherVertex = E.itPositive ? E.idIt : -E.idIt;     // e.GetEndVertex() for a front push
-    const uint32_t o0 = E.o0, o1 = E.o1;
+    const OccIdx o0 = E.o0, o1 = E.o0 + E.nOcc;
     // the dependent loads of the first chunk (chromosome start, `used` words) fly while the path set is updated
-    LcbOcc occ = lcb_finish_occ(T, S.U, rec0, o0 + S.lane < o1);
+    LcbOccT<Flat> occ = lcb_finish_occ(S, rec0, S.lane < E.nOcc);
     bool inPath = LcbCfg<ST::MODE>::BW ? lcb_bloom_maybe(S, vertex) : true;   // (an LDS-resident set is probed directly)
     if (inPath) { uint32_t probes = 0; inPath = lcb_path_probe(S, vertex, probes); if (PROF && probes > S.pfMaxProbe) S.pfMaxProbe = probes; }
     if (inPath) return false;
@@ -1028,18 +1135,18 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
     const int64_t B = S.P.maxBranch;
     uint32_t nTouch = 0;                                             // instances this push extends or creates
     if (PROF && LCB_PROF_PUSH) S.pfTWalk += wall_clock64() - tq0;
-    for (uint32_t base = o0; base < o1; base += 64) {
+    for (OccIdx base = o0; base < o1; base += 64) {
         const uint64_t tq1 = (PROF && LCB_PROF_PUSH) ? wall_clock64() : 0;
-        const uint32_t j = base + S.lane;
+        const OccIdx j = base + S.lane;
         const bool active = j < o1;
         const uint32_t n = S.nInst;
         const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-        const uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
+        const typename ST::Idx* oIdx = S.ordIdx + S.cur * S.instCap;
         uint32_t g = 0, chr = 0, lo = 0, pos = 0, u = 0, cand = 0, act = LCB_ACT_NONE;
         uint32_t stCall = 0, stStep = 0;                             // stats: Compatible calls / walk steps of this occurrence
         uint32_t lenBefore = 0, lenAfter = 0;
         bool positive = false, usedS = false, usesP = false;
-        if (base != o0) occ = lcb_finish_occ(T, S.U, lcb_load_rec(T, j, active), active);
+        if (base != o0) occ = lcb_finish_occ(S, lcb_load_rec(T, j, active), active);
         if (active) {
             if (STATS) S.cOcc++;
             g = occ.rec.x; chr = occ.rec.y; pos = occ.rec.z;
@@ -1050,6 +1157,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             // read unconditionally - three rounds of independent reads instead of five dependent ones - was 1 % SLOWER on every
             // workload: a step is bound by the instructions the seed's wavefront issues, not by its LDS round trips.)
             uint32_t a = 0, b = n;
+            if (ST::SEG) { const uint32_t sg = lcb_cw_seg(chr); a = S.segFirst[sg]; b = S.segFirst[sg + 1]; }   // the entries of the occurrence's segment
             while (a < b) { const uint32_t mid = (a + b) >> 1; if (g < oKey[mid]) b = mid; else a = mid + 1; }
             u = a;
             uint32_t x = 0, p = 0, xFl = 0, pFl = 0;
@@ -1101,15 +1209,15 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
                         const int64_t realDiff = positive ? endPos - startPos : startPos - endPos;
                         const int64_t ancestralDiff = BACK ? (int64_t)distance - cd : (int64_t)cd - distance;
                         const uint32_t ga = g < cg ? g : cg, gb = g < cg ? cg : g;
-                        if (STATS) stStep = lcb_range_walk_steps(S.U, ga, gb, positive);
+                        if (STATS) stStep = lcb_range_walk_steps(S.U, (Flat)(occ.sb + ga), (Flat)(occ.sb + gb), positive);
                         bool okDist = realDiff >= 0;
                         if (okDist && (realDiff > B || ancestralDiff > B)) {
                             // only an exact next-edge continuation is accepted (path.h:407-411,420-424)
                             const uint32_t gs = BACK ? cg : g, ge = BACK ? g : cg;      // start, end
                             const bool adjacent = positive ? (ge == gs + 1) : (gs == ge + 1);
-                            okDist = adjacent && (int32_t)lcb_it_char(T, gs, positive) == ech;
+                            okDist = adjacent && (int32_t)lcb_it_char(T, (Flat)(occ.sb + gs), positive) == ech;
                             if (okDist && !BACK) {
-                                const int32_t idE = T.posId[ge];
+                                const int32_t idE = T.posId[(Flat)(occ.sb + ge)];
                                 okDist = (positive ? idE : -idE) == otherVertex;       // start1.GetVertexId() == e.GetEndVertex()
                             }
                         }
@@ -1163,7 +1271,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             const uint32_t posT = lcb_bcast(positive ? 1u : 0u, t);
             if (active && usesP && prior && !(extXM & below & ~((1ull << s0) - 1)) && act != LCB_ACT_SKIP) {
                 stCall = 1;
-                stStep = (posT != 0) == positive ? lcb_range_walk_steps(S.U, gT, g, positive) : 0u;
+                stStep = (posT != 0) == positive ? lcb_range_walk_steps(S.U, (Flat)(occ.sb + gT), (Flat)(occ.sb + g), positive) : 0u;
             }
             S.cCompatCall += stCall; S.cCompatStep += stStep;
         }
@@ -1194,10 +1302,10 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
         if (S.nInst + m > S.instCap) { S.status = LCB_ST_INST_OVF; return true; }
         if (becameGood) {
             const uint32_t at = S.nGood + (uint32_t)__popcll(goodM & ((1ull << S.lane) - 1));
-            S.good[at] = (uint16_t)cand; S.goodPos[cand] = (uint16_t)at;
+            S.good[at] = (typename ST::Idx)cand; S.goodPos[cand] = (typename ST::Idx)at;
         }
         S.nGood += (uint32_t)__popcll(goodM);
-        if (ext) S.touch[nTouch + (uint32_t)__popcll(extM & ((1ull << S.lane) - 1))] = (uint16_t)cand;
+        if (ext) S.touch[nTouch + (uint32_t)__popcll(extM & ((1ull << S.lane) - 1))] = (typename ST::Idx)cand;
         nTouch += (uint32_t)__popcll(extM);
         if (ins) {
             const uint32_t r = (uint32_t)__popcll(insM & ((1ull << S.lane) - 1));
@@ -1208,13 +1316,14 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
             S.iFlags[i] = (chr << LCB_FLAG_BITS) | (positive ? LCB_FLAG_POS : 0u);
             {   // the creating read (the occurrence's own `used` bit was 0)
                 const uint32_t fs = lcb_fp_slot(S, i);
-                if (fs >= S.nFp) { S.fpLo[fs] = g; S.fpHi[fs] = g; }
+                if (fs >= S.nFp) { S.fpLo[fs] = g; S.fpHi[fs] = g; lcb_fp_set_seg(S, fs, lcb_cw_seg(chr)); }
                 else if (HOIST) { atomicMin(&S.fpLo[fs], g); atomicMax(&S.fpHi[fs], g); }     // (slots in the HBM workspace are only ever UPDATED with atomics: the walks of the other wavefronts update them at the L2)
                 else { if (g < S.fpLo[fs]) S.fpLo[fs] = g; if (g > S.fpHi[fs]) S.fpHi[fs] = g; }
             }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
-            S.goodPos[i] = LCB_NONE16;
-            S.touch[nTouch + r] = (uint16_t)i;
+            if (ST::SEG) S.scr[192 + r] = lcb_cw_seg(chr);
+            S.goodPos[i] = ST::NONE;
+            S.touch[nTouch + r] = (typename ST::Idx)i;
         }
         nTouch += m;
         S.nInst += m;
@@ -1228,7 +1337,7 @@ __device__ inline bool lcb_push(ST& S, const LcbEdge& E, bool record, const uint
     if (BACK) {
         if (record) {
             if (S.nRight >= S.bodyCap) { S.status = LCB_ST_PATH_OVF; return true; }
-            if (S.lane == 0) S.body[S.nRight] = ((unsigned long long)(E.itPositive ? 1u : 0u) << 32) | E.gIt;
+            if (S.lane == 0) S.body[S.nRight] = ((unsigned long long)(E.itPositive ? 1u : 0u) << 40) | ((unsigned long long)E.segIt << 32) | E.gIt;
         }
         S.nRight++;
         S.rightFlank = distance;
@@ -1270,7 +1379,7 @@ __device__ inline void lcb_snapshot(ST& S)
         const uint32_t i = S.good[e];
         const uint32_t fl = S.iFlags[i];
         uint4 r;
-        r.x = fl >> LCB_FLAG_BITS; r.y = S.iFrontG[i] - S.iLo[i]; r.z = S.iBackG[i] - S.iLo[i]; r.w = (fl & LCB_FLAG_POS);
+        r.x = (fl >> LCB_FLAG_BITS) & LCB_CHR_MASK; r.y = S.iFrontG[i] - S.iLo[i]; r.z = S.iBackG[i] - S.iLo[i]; r.w = (fl & LCB_FLAG_POS);
         S.best[e] = r;
     }
     S.nBest = S.nGood;
@@ -1287,11 +1396,12 @@ __device__ inline void lcb_checkpoint(ST& S)
     if (n > cap) return;
     uint32_t* c = S.ck;
     const uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-    const uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    const typename ST::Idx* oIdx = S.ordIdx + S.cur * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         c[i] = S.iBackG[i]; c[cap + i] = S.iBackPos[i]; c[2 * cap + i] = (uint32_t)S.iBackDist[i]; c[3 * cap + i] = S.iFlags[i];
         c[4 * cap + i] = oKey[i]; c[5 * cap + i] = oIdx[i];
     }
+    if (ST::SEG && S.lane <= LCB_MAX_SEG) c[6 * cap + S.lane] = S.segFirst[S.lane];
     S.ckN = S.nRight; S.ckInst = n; S.ckGood = S.nGood; S.ckPath = S.nPath; S.ckFlank = S.rightFlank;
 }
 
@@ -1302,15 +1412,16 @@ __device__ inline void lcb_restore_checkpoint(ST& S)
 {
     LCB_WAVE_SYNC();
     for (uint32_t i = S.ckPath + S.lane; i < S.nPath; i += 64) S.pKeys[S.pSlots[i]] = LCB_EMPTY_KEY;
-    for (uint32_t e = S.ckGood + S.lane; e < S.nGood; e += 64) S.goodPos[S.good[e]] = LCB_NONE16;   // they became good after the checkpoint
+    for (uint32_t e = S.ckGood + S.lane; e < S.nGood; e += 64) S.goodPos[S.good[e]] = ST::NONE;   // they became good after the checkpoint
     const uint32_t n = S.ckInst, cap = S.bestCap;
     const uint32_t* c = S.ck;
     uint32_t* oKey = S.ordKey + S.cur * S.instCap;
-    uint16_t* oIdx = S.ordIdx + S.cur * S.instCap;
+    typename ST::Idx* oIdx = S.ordIdx + S.cur * S.instCap;
     for (uint32_t i = S.lane; i < n; i += 64) {
         S.iBackG[i] = c[i]; S.iBackPos[i] = c[cap + i]; S.iBackDist[i] = (int32_t)c[2 * cap + i]; S.iFlags[i] = c[3 * cap + i];
-        oKey[i] = c[4 * cap + i]; oIdx[i] = (uint16_t)c[5 * cap + i];
+        oKey[i] = c[4 * cap + i]; oIdx[i] = (typename ST::Idx)c[5 * cap + i];
     }
+    if (ST::SEG && S.lane <= LCB_MAX_SEG) S.segFirst[S.lane] = c[6 * cap + S.lane];
     S.nPath = S.ckPath; S.nInst = n; S.nGood = S.ckGood; S.nRight = S.ckN; S.nLeft = 0;
     S.rightFlank = S.ckFlank; S.leftFlank = 0; S.nTouch = 0;        // (no vote follows before the next push or the backward phase)
     LCB_WAVE_SYNC();
@@ -1319,22 +1430,24 @@ __device__ inline void lcb_restore_checkpoint(ST& S)
 // ---- edge batches ---------------------------------------------------------------------------------
 // Up to 64 consecutive edges to push, one per lane: the table rows of both ends and the CSR bounds of the pushed vertex
 // are fetched for all of them at once (two dependent global round trips per batch instead of three per push).
-struct LcbEdgeBatch { uint32_t gIt, itPos, posIt, posN, o0, o1; int32_t idIt, idN, ech; };
+template <class J> struct LcbEdgeBatchT { uint32_t gIt, segIt, itPos, posIt, posN, nOcc; J o0; int32_t idIt, idN, ech; };
 
 // Edges along a chromosome walk: edge l goes from position g + dir*l to g + dir*(l+1) (ExtendPathForward/Backward,
 // blocksfinder.h:789-802,852-865). Returns the number of edges up to the first position whose vertex is `next`
 // (64 if it is further away; the caller then asks for the following batch).
 template <bool FORWARD, class ST>
-__device__ inline uint32_t lcb_batch_from_walk(const ST& S, uint32_t g, int dir, bool positive, uint32_t lo, uint32_t hi, int32_t next, LcbEdgeBatch& b)
+__device__ inline uint32_t lcb_batch_from_walk(const ST& S, uint32_t seg, uint32_t g, int dir, bool positive, uint32_t lo, uint32_t hi, int32_t next, LcbEdgeBatchT<typename ST::OccIdx>& b)
 {
     const LcbTables& T = S.T;
+    typedef typename ST::Flat Flat;
+    const Flat sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[seg]) : (Flat)0;       // (seg is wave-uniform: the chromosome of the origin instance)
     const int64_t q0 = (int64_t)g + (int64_t)dir * (int64_t)S.lane, q1 = q0 + dir;
     const bool v0 = q0 >= (int64_t)lo && q0 < (int64_t)hi, v1 = q1 >= (int64_t)lo && q1 < (int64_t)hi;
-    b.gIt = (uint32_t)q0; b.itPos = positive ? 1u : 0u;
-    b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.o1 = 0;
+    b.gIt = (uint32_t)q0; b.segIt = seg; b.itPos = positive ? 1u : 0u;
+    b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.nOcc = 0;
     int32_t ch0 = 0, ch1 = 0;
-    if (v0) { b.idIt = T.posId[q0]; b.posIt = T.posPos[q0]; ch0 = (int32_t)lcb_it_char(T, (uint32_t)q0, positive); }
-    if (v1) { b.idN = T.posId[q1]; b.posN = T.posPos[q1]; ch1 = (int32_t)lcb_it_char(T, (uint32_t)q1, positive); }
+    if (v0) { b.idIt = (T.posId + sb)[(uint32_t)q0]; b.posIt = (T.posPos + sb)[(uint32_t)q0]; ch0 = (int32_t)lcb_it_char(T, (Flat)(sb + (uint32_t)q0), positive); }
+    if (v1) { b.idN = (T.posId + sb)[(uint32_t)q1]; b.posN = (T.posPos + sb)[(uint32_t)q1]; ch1 = (int32_t)lcb_it_char(T, (Flat)(sb + (uint32_t)q1), positive); }
     // e.GetChar(): outgoing -> char at the iterator, ingoing -> char at the previous position (junctionstorage.h:191-227)
     b.ech = FORWARD ? ch0 : ch1;
     // the walk stops at the first position whose vertex is `next`; positions past the chromosome end never match
@@ -1347,33 +1460,36 @@ __device__ inline uint32_t lcb_batch_from_walk(const ST& S, uint32_t g, int dir,
     else if (firstEnd < 64) n = firstEnd;                                               // ran off the chromosome (cannot happen for a voted vertex)
     if (S.lane < n) {
         const uint32_t av = (uint32_t)(b.idN < 0 ? -b.idN : b.idN);
-        b.o0 = T.occStart[av]; b.o1 = T.occStart[av + 1];
+        b.o0 = lcb_occ_start<ST::SEG>(T, av); b.nOcc = (uint32_t)(lcb_occ_start<ST::SEG>(T, av + 1) - b.o0);
     }
     return n;
 }
 
 // Edges of the recorded right body [from, from + 64) for the replay (blocksfinder.h:271-284).
 template <class ST>
-__device__ inline void lcb_batch_from_body(const ST& S, uint32_t from, uint32_t n, LcbEdgeBatch& b)
+__device__ inline void lcb_batch_from_body(const ST& S, uint32_t from, uint32_t n, LcbEdgeBatchT<typename ST::OccIdx>& b)
 {
     const LcbTables& T = S.T;
-    b.gIt = 0; b.itPos = 0; b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.o1 = 0;
+    typedef typename ST::Flat Flat;
+    b.gIt = 0; b.segIt = 0; b.itPos = 0; b.idIt = 0; b.idN = 0; b.posIt = 0; b.posN = 0; b.ech = 0; b.o0 = 0; b.nOcc = 0;
     if (S.lane < n) {
         const unsigned long long r = S.body[from + S.lane];
-        b.gIt = (uint32_t)r; b.itPos = (uint32_t)(r >> 32);
-        const uint32_t gN = b.itPos ? b.gIt + 1 : b.gIt - 1;
-        b.idIt = T.posId[b.gIt]; b.idN = T.posId[gN]; b.posIt = T.posPos[b.gIt]; b.posN = T.posPos[gN];
-        b.ech = (int32_t)lcb_it_char(T, b.gIt, b.itPos != 0);
+        b.gIt = (uint32_t)r; b.segIt = ST::SEG ? ((uint32_t)(r >> 32) & 0xFFu) : 0u; b.itPos = (uint32_t)(r >> 40);
+        const Flat sb = lcb_seg_base(S, b.segIt);
+        const Flat fIt = sb + b.gIt, fN = b.itPos ? fIt + 1 : fIt - 1;
+        b.idIt = T.posId[fIt]; b.idN = T.posId[fN]; b.posIt = T.posPos[fIt]; b.posN = T.posPos[fN];
+        b.ech = (int32_t)lcb_it_char(T, fIt, b.itPos != 0);
         const uint32_t av = (uint32_t)(b.idN < 0 ? -b.idN : b.idN);
-        b.o0 = T.occStart[av]; b.o1 = T.occStart[av + 1];
+        b.o0 = lcb_occ_start<ST::SEG>(T, av); b.nOcc = (uint32_t)(lcb_occ_start<ST::SEG>(T, av + 1) - b.o0);
     }
 }
 
-__device__ __forceinline__ LcbEdge lcb_edge_of(const LcbEdgeBatch& b, uint32_t l)
+template <class J>
+__device__ __forceinline__ LcbEdgeT<J> lcb_edge_of(const LcbEdgeBatchT<J>& b, uint32_t l)
 {
-    LcbEdge e;
-    e.gIt = lcb_rl(b.gIt, l); e.itPositive = lcb_rl(b.itPos, l) != 0; e.idIt = lcb_rl(b.idIt, l); e.idN = lcb_rl(b.idN, l);
-    e.posIt = lcb_rl(b.posIt, l); e.posN = lcb_rl(b.posN, l); e.ech = lcb_rl(b.ech, l); e.o0 = lcb_rl(b.o0, l); e.o1 = lcb_rl(b.o1, l);
+    LcbEdgeT<J> e;
+    e.gIt = lcb_rl(b.gIt, l); e.segIt = lcb_rl(b.segIt, l); e.itPositive = lcb_rl(b.itPos, l) != 0; e.idIt = lcb_rl(b.idIt, l); e.idN = lcb_rl(b.idN, l);
+    e.posIt = lcb_rl(b.posIt, l); e.posN = lcb_rl(b.posN, l); e.ech = lcb_rl(b.ech, l); e.o0 = lcb_rl(b.o0, l); e.nOcc = lcb_rl(b.nOcc, l);
     return e;
 }
 
@@ -1401,20 +1517,22 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
         // there the one-load form made the register allocator of the compact instantiation spill whole 16-register tuples)
         constexpr bool ONE = !LcbCfg<ST::MODE>::INST_LDS;
         const uint32_t f = ONE ? lcb_inst_fields(S, oi) : 0u;
-        const bool positive = ((ONE ? lcb_rl(f, LCB_F_FLAGS) : lcb_rfl(S.iFlags[oi])) & LCB_FLAG_POS) != 0;
+        const uint32_t ofl = ONE ? lcb_rl(f, LCB_F_FLAGS) : lcb_rfl(S.iFlags[oi]);
+        const bool positive = (ofl & LCB_FLAG_POS) != 0;
+        const uint32_t oseg = ST::SEG ? lcb_fl_seg(ofl) : 0u;
         uint32_t g = ONE ? (FORWARD ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG)) : lcb_rfl(FORWARD ? S.iBackG[oi] : S.iFrontG[oi]);
         const int dir = (FORWARD == positive) ? 1 : -1;
         const uint32_t lo = ONE ? lcb_rl(f, LCB_F_LO) : lcb_rfl(S.iLo[oi]), hi = ONE ? lcb_rl(f, LCB_F_HI) : lcb_rfl(S.iHi[oi]);
         for (;;) {
-            LcbEdgeBatch bt;
-            const uint32_t nE = lcb_batch_from_walk<FORWARD>(S, g, dir, positive, lo, hi, next, bt);
+            LcbEdgeBatchT<typename ST::OccIdx> bt;
+            const uint32_t nE = lcb_batch_from_walk<FORWARD>(S, oseg, g, dir, positive, lo, hi, next, bt);
             if (nE == 0) break;                                      // defensive: a voted vertex is always reached
             // occurrence records of the first edge; those of edge l+1 are requested before edge l is pushed
-            uint4 rec = lcb_load_rec(T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            uint4 rec = lcb_load_rec(T, lcb_rl(bt.o0, 0) + S.lane, S.lane < lcb_rl(bt.nOcc, 0));
             for (uint32_t l = 0; l < nE; l++) {
-                const LcbEdge E = lcb_edge_of(bt, l);
+                const LcbEdgeT<typename ST::OccIdx> E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(T, p0 + S.lane, p0 + S.lane < p1); }
+                if (l + 1 < nE) recN = lcb_load_rec(T, lcb_rl(bt.o0, l + 1) + S.lane, S.lane < lcb_rl(bt.nOcc, l + 1));
                 LCB_MARK(S, 6, 3); LCB_MARK(S, 8, E.gIt);
                 const uint64_t tp0 = PROF ? wall_clock64() : 0;
                 success = lcb_push<FORWARD, STATS, PROF>(S, E, true, rec);
@@ -1481,13 +1599,13 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
         }
         while (from < nEdge && !S.status) {
             const uint32_t nE = nEdge - from < 64 ? nEdge - from : 64;
-            LcbEdgeBatch bt;
+            LcbEdgeBatchT<typename ST::OccIdx> bt;
             lcb_batch_from_body(S, from, nE, bt);
-            uint4 rec = lcb_load_rec(S.T, lcb_rl(bt.o0, 0) + S.lane, lcb_rl(bt.o0, 0) + S.lane < lcb_rl(bt.o1, 0));
+            uint4 rec = lcb_load_rec(S.T, lcb_rl(bt.o0, 0) + S.lane, S.lane < lcb_rl(bt.nOcc, 0));
             for (uint32_t l = 0; l < nE && !S.status; l++) {
-                const LcbEdge E = lcb_edge_of(bt, l);
+                const LcbEdgeT<typename ST::OccIdx> E = lcb_edge_of(bt, l);
                 uint4 recN = uint4{0u, 0u, 0u, 0u};
-                if (l + 1 < nE) { const uint32_t p0 = lcb_rl(bt.o0, l + 1), p1 = lcb_rl(bt.o1, l + 1); recN = lcb_load_rec(S.T, p0 + S.lane, p0 + S.lane < p1); }
+                if (l + 1 < nE) recN = lcb_load_rec(S.T, lcb_rl(bt.o0, l + 1) + S.lane, S.lane < lcb_rl(bt.nOcc, l + 1));
                 lcb_push<true, STATS, PROF>(S, E, false, rec);
                 rec = recN;
             }
@@ -1502,7 +1620,7 @@ __device__ inline void lcb_process_seed(ST& S, int32_t vid, int32_t ch, int64_t&
     if (!S.status && !dead) {
         // The first backward vote: the instances whose FRONT is the seed vertex (front distance 0 = left flank) are the
         // initial ones, pool entries [0, nInit) — back pushes leave fronts alone and create instances at distance > 0.
-        for (uint32_t i = S.lane; i < S.nInit; i += 64) S.touch[i] = (uint16_t)i;
+        for (uint32_t i = S.lane; i < S.nInit; i += 64) S.touch[i] = (typename ST::Idx)i;
         S.nTouch = S.nInit;
         LCB_WAVE_SYNC();
         for (;;) {                                                   // blocksfinder.h:292-306 (stray ';' at :297, Q1)
@@ -1529,7 +1647,7 @@ struct LcbLaunchArgs {
     LcbSeedOut* out;
     LcbSeedCtr* ctr;
     uint4* arena;
-    uint2* fpArena;
+    LcbFpOut* fpArena;
     unsigned long long arenaCap, fpCap, arenaBase, fpBase;
     unsigned long long* arenaCursor;
     unsigned long long* fpCursor;
@@ -1541,10 +1659,10 @@ struct LcbLaunchArgs {
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
-template <int MODE, bool STATS, int NW, bool PROF>
+template <int MODE, bool STATS, int NW, bool PROF, bool SEG = false>
 __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P, const LcbKSeed* seeds, uint32_t nSeeds,
                                         const LcbWork& W, LcbSeedOut* out, uint4* arena, unsigned long long arenaCap,
-                                        uint2* fpArena, unsigned long long fpCap)
+                                        LcbFpOut* fpArena, unsigned long long fpCap)
 {
     typedef LcbCfg<MODE> Cfg;
     constexpr bool INST_LDS = Cfg::INST_LDS, IDX_LDS = Cfg::IDX_LDS;
@@ -1552,17 +1670,22 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     __shared__ uint32_t sInst[INST_LDS ? 9 * IC : 1];
     __shared__ uint32_t sFp[INST_LDS ? 2 * IC : 1];
     __shared__ uint32_t sOrdKey[IDX_LDS ? 2 * IC : 1];
-    __shared__ uint16_t sOrdIdx[IDX_LDS ? 2 * IC : 1];
-    __shared__ uint16_t sGood[IDX_LDS ? IC : 1];
-    __shared__ uint16_t sGoodPos[IDX_LDS ? IC : 1];
-    __shared__ uint16_t sTouch[IDX_LDS ? IC : 1];
+    typedef typename Cfg::Idx Idx;
+    typedef typename Cfg::VLast VLast;
+    __shared__ Idx sOrdIdx[IDX_LDS ? 2 * IC : 1];
+    __shared__ Idx sGood[IDX_LDS ? IC : 1];
+    __shared__ Idx sGoodPos[IDX_LDS ? IC : 1];
+    __shared__ Idx sTouch[IDX_LDS ? IC : 1];
     __shared__ int32_t sVKey[IDX_LDS ? VC : 1];
     __shared__ uint32_t sVCount[IDX_LDS ? VC : 1];
-    __shared__ uint32_t sVLast[IDX_LDS ? VC : 1];
-    __shared__ uint16_t sVTouched[IDX_LDS ? VC : 1];
+    __shared__ VLast sVLast[IDX_LDS ? VC : 1];
+    __shared__ Idx sVTouched[IDX_LDS ? VC : 1];
     __shared__ uint32_t sBloom[BW ? BW : 1];
     __shared__ int32_t sPath[PC ? PC : 1];
-    __shared__ uint32_t sScr[3 * 64];
+    __shared__ uint32_t sScr[(SEG ? 4 : 3) * 64];
+    __shared__ uint64_t sSegBase[SEG ? LCB_MAX_SEG : 1];
+    __shared__ uint32_t sSegFirst[SEG ? LCB_MAX_SEG + 2 : 1];
+    __shared__ uint8_t sFpSeg[(SEG && INST_LDS) ? IC : 1];
     __shared__ uint32_t sMisc[4];
     __shared__ uint32_t sMail[LCB_MAIL_WORDS];
     __shared__ uint32_t sPart[8 * NW];
@@ -1575,9 +1698,14 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         sArgs.roundIdx = W.roundIdx; sArgs.roundOut = W.roundOut; sArgs.roundState = W.roundState;
     }
 
-    LcbStateT<MODE> S;
+    LcbStateT<MODE, SEG> S;
     S.T = T; S.P = P; S.U = lcb_used_of(T, 0);
     S.lane = threadIdx.x & 63u;
+    S.segBase = sSegBase; S.segFirst = sSegFirst;
+    if (SEG) {
+        if (threadIdx.x < LCB_MAX_SEG) sSegBase[threadIdx.x] = threadIdx.x < T.nSeg ? T.segBase[threadIdx.x] : 0ull;
+        if (threadIdx.x < LCB_MAX_SEG + 2) sSegFirst[threadIdx.x] = 0;
+    }
     uint8_t* slot = W.base + (uint64_t)blockIdx.x * W.slotBytes;
     const LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, INST_LDS ? 0 : W.instCap, IDX_LDS ? 0 : W.voteCap);
     S.pSlots = (uint32_t*)(slot + L.pSlots);
@@ -1593,6 +1721,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
     if (INST_LDS) { instBase = sInst; instStride = IC; fpBase = sFp; }
     else { instBase = (uint32_t*)(slot + L.inst); instStride = W.instCap; fpBase = (uint32_t*)(slot + L.fp); }
     S.fpLo = fpBase; S.fpHi = fpBase + instStride;
+    S.fpSeg8 = sFpSeg; S.fpSeg32 = INST_LDS ? nullptr : fpBase + 2 * instStride;
     if (IDX_LDS) {
         S.instCap = IC;
         S.ordKey = sOrdKey; S.ordIdx = sOrdIdx; S.good = sGood; S.goodPos = sGoodPos; S.touch = sTouch;
@@ -1601,10 +1730,10 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         for (uint32_t h = threadIdx.x; h < VC; h += 64 * NW) { sVKey[h] = LCB_EMPTY_KEY; sVCount[h] = 0; sVLast[h] = 0; }
     } else {
         S.instCap = W.instCap;
-        S.ordKey = (uint32_t*)(slot + L.ordKey); S.ordIdx = (uint16_t*)(slot + L.ordIdx);
-        S.good = (uint16_t*)(slot + L.good); S.goodPos = (uint16_t*)(slot + L.goodPos); S.touch = (uint16_t*)(slot + L.touch);
+        S.ordKey = (uint32_t*)(slot + L.ordKey); S.ordIdx = (Idx*)(slot + L.ordIdx);
+        S.good = (Idx*)(slot + L.good); S.goodPos = (Idx*)(slot + L.goodPos); S.touch = (Idx*)(slot + L.touch);
         S.vKey = (int32_t*)(slot + L.vKey); S.vCount = (uint32_t*)(slot + L.vCount);
-        S.vLast = (uint32_t*)(slot + L.vLast); S.vTouched = (uint16_t*)(slot + L.vTouched);
+        S.vLast = (VLast*)(slot + L.vLast); S.vTouched = (Idx*)(slot + L.vTouched);
         S.voteCap = W.voteCap;
     }
     S.bloom = sBloom;
@@ -1701,7 +1830,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         }
         // footprint intervals (one per instance ever created), widened by one position on the low side
         // because the - strand reads bit g-1
-        uint2* fpa = sArgs.fpArena;
+        LcbFpOut* fpa = sArgs.fpArena;
         const uint32_t nfp = (S.status == LCB_ST_OK && fpa) ? S.nFp : 0u;
         unsigned long long fpo = 0;
         if (nfp) {
@@ -1715,7 +1844,8 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 // through a line this wavefront's L1 may still hold from an earlier plain read)
                 const uint32_t lo = INST_LDS ? S.fpLo[e] : __hip_atomic_load(&S.fpLo[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t hi = INST_LDS ? S.fpHi[e] : __hip_atomic_load(&S.fpHi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint2 r; r.x = lo ? lo - 1 : 0u; r.y = hi; fpa[fpo + e] = r;
+                const uint64_t sb = lcb_seg_base(S, lcb_fp_get_seg(S, e));
+                LcbFpOut r; r.lo = sb + (lo ? lo - 1 : 0u); r.hi = sb + hi; fpa[fpo + e] = r;
             }
         }
         // (no local arrays here: the compiler would move them to LDS, 48 B x every lane of the workgroup)
@@ -1778,15 +1908,15 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
         const LcbKSeed sd = seeds[s];
         const LcbUsed used = lcb_used_of(T, sd.view);
         const uint32_t av = (uint32_t)(sd.vid < 0 ? -sd.vid : sd.vid);
-        const uint32_t o1 = T.occStart[av + 1];
-        for (uint32_t j = T.occStart[av]; j < o1 && !alive; j++) {
+        const uint64_t o1 = T.occStart64 ? T.occStart64[av + 1] : (uint64_t)T.occStart32[av + 1];
+        for (uint64_t j = T.occStart64 ? T.occStart64[av] : (uint64_t)T.occStart32[av]; j < o1 && !alive; j++) {
             const uint4 rec = T.occRec[j];
             const bool positive = (int32_t)rec.w == sd.vid;
-            const uint32_t g = rec.x;
+            const uint64_t f = T.segBase[lcb_cw_seg(rec.y)] + rec.x;       // (a 32-entry table: cache-resident)
             bool isUsed;
-            if (positive) isUsed = lcb_used_bit(used, g);
-            else isUsed = g > T.chrStart[rec.y] ? lcb_used_bit(used, g - 1) : false;
-            alive = !isUsed && (int32_t)(positive ? T.posCh[g] : T.posRevCh[g]) == sd.ch;
+            if (positive) isUsed = lcb_used_bit(used, f);
+            else isUsed = rec.x > T.chrLoHi[rec.y & LCB_CHR_MASK].x ? lcb_used_bit(used, f - 1) : false;
+            alive = !isUsed && (int32_t)(positive ? T.posCh[f] : T.posRevCh[f]) == sd.ch;
         }
         (void)out;      // a dead seed needs no header: the host looks at the live list only (its result is empty by definition)
         if (!alive && roundIdx) roundState[roundIdx[s]] = LCB_RS_DEAD;     // ... and the commit kernel of a round passes over it
@@ -1831,17 +1961,18 @@ enum { LCB_CS_NEXT = 0,        // first seed of the next phase to commit (everyt
        LCB_CS_MARKED,          // something was committed in this round
        LCB_CS_WORDS = 8 };
 struct LcbCommitArgs {
-    const uint32_t* chrStart;      // [nChr+1]
+    const uint64_t* chrBase;       // [nChr] flat position of the chromosome's first occurrence
     uint32_t* used;                // the live bitmap (marked here)
     uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared per round
     const uint32_t* roundState;    // [n] LCB_RS_* per seed of the round
     const LcbSeedOut* roundOut;    // [n] headers of the final results
     const uint4* arena;            // (chr, front idx, back idx, strand)
-    const uint2* fpArena;          // footprint intervals [lo, hi] over flat positions
-    uint32_t n, phase, nPos;       // seeds of the round, seeds per phase (256), positions of the bitmaps
+    const LcbFpOut* fpArena;       // footprint intervals [lo, hi] over flat positions
+    uint32_t n, phase;             // seeds of the round, seeds per phase (256)
+    uint64_t nPos;                 // positions of the bitmap
     uint32_t* state;               // LCB_CS_* (host-visible; one thread reads and writes it)
     uint32_t* committed;           // out (host-visible): round indices of the committed seeds, in order
-    uint2* deltaList;              // the ranges this round's commits have marked so far (the summary of a later invocation is rebuilt from them) ...
+    LcbFpOut* deltaList;           // the ranges [lo, hi) this round's commits have marked so far (the summary of a later invocation is rebuilt from them) ...
     uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete: every page then counts as marked)
     uint32_t deltaCap;
     uint32_t pageShift;            // the coarse LDS summary of the round's marks has one bit per 2^pageShift positions (nPos >> pageShift <= LCB_COMMIT_PAGES)
@@ -1849,11 +1980,11 @@ struct LcbCommitArgs {
 #define LCB_COMMIT_PAGES 32768u    // bits of the summary (4 KB of LDS)
 
 // any set bit of `bits` in [a, b)? (bitmap words are read past the L1: other wavefronts mark them with atomics)
-__device__ inline bool lcb_bits_any(const uint32_t* bits, uint32_t a, uint32_t b)
+__device__ inline bool lcb_bits_any(const uint32_t* bits, uint64_t a, uint64_t b)
 {
     if (a >= b) return false;
-    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
-    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
+    const uint32_t ma = 0xFFFFFFFFu << ((uint32_t)a & 31), mb = 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
     for (uint32_t w = wa; w <= wb; w++) {
         uint32_t v = __hip_atomic_load(bits + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w == wa) v &= ma;
@@ -1863,25 +1994,25 @@ __device__ inline bool lcb_bits_any(const uint32_t* bits, uint32_t a, uint32_t b
     return false;
 }
 
-__device__ inline void lcb_bits_set(uint32_t* bits, uint32_t a, uint32_t b)
+__device__ inline void lcb_bits_set(uint32_t* bits, uint64_t a, uint64_t b)
 {
     if (a >= b) return;
-    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
+    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
     for (uint32_t w = wa; w <= wb; w++) {
         uint32_t m = 0xFFFFFFFFu;
-        if (w == wa) m &= 0xFFFFFFFFu << (a & 31);
-        if (w == wb) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+        if (w == wa) m &= 0xFFFFFFFFu << ((uint32_t)a & 31);
+        if (w == wb) m &= 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
         atomicOr(bits + w, m);
     }
 }
 
 // any set bit of `bits` in [a, b)? For ranges of thousands of positions: the words are requested eight at a time (independent loads,
 // one latency per batch instead of one per word) and read past the L1 like lcb_bits_any.
-__device__ inline bool lcb_bits_any_long(const uint32_t* bits, uint32_t a, uint32_t b)
+__device__ inline bool lcb_bits_any_long(const uint32_t* bits, uint64_t a, uint64_t b)
 {
     if (a >= b) return false;
-    const uint32_t wa = a >> 5, wb = (b - 1) >> 5;
-    const uint32_t ma = 0xFFFFFFFFu << (a & 31), mb = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
+    const uint32_t ma = 0xFFFFFFFFu << ((uint32_t)a & 31), mb = 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
     for (uint32_t w = wa; w <= wb; w += 8) {
         uint32_t v[8];
 #pragma unroll
@@ -1913,7 +2044,7 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
         const uint32_t nD = marked ? *A.deltaCount : 0u;
         for (uint32_t w = tid; w < LCB_COMMIT_PAGES / 32; w += nT) sPage[w] = nD > A.deltaCap ? 0xFFFFFFFFu : 0u;
         __syncthreads();
-        if (nD <= A.deltaCap) for (uint32_t r = tid; r < nD; r += nT) { const uint2 d = A.deltaList[r]; for (uint32_t q = d.x >> sh; q <= (d.y - 1u) >> sh; q++) atomicOr(&sPage[q >> 5], 1u << (q & 31)); }
+        if (nD <= A.deltaCap) for (uint32_t r = tid; r < nD; r += nT) { const LcbFpOut d = A.deltaList[r]; for (uint32_t q = (uint32_t)(d.lo >> sh); q <= (uint32_t)((d.hi - 1u) >> sh); q++) atomicOr(&sPage[q >> 5], 1u << (q & 31)); }
         __syncthreads();
     }
     uint32_t nCommitted = sFlag[5], stopKind = 0, stopAt = 0;
@@ -1946,9 +2077,9 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                     const unsigned long long fpOff = A.roundOut[qq].fpOff;
                     bool hit = false;
                     for (uint32_t k = lane; k < nFp; k += 64) {
-                        const uint2 f = A.fpArena[fpOff + k];
-                        const uint32_t a = f.x, b = f.y < A.nPos ? f.y : A.nPos - 1u;                 // positions a .. b
-                        for (uint32_t pg = a >> sh; pg <= b >> sh && !hit; pg++) hit = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
+                        const LcbFpOut f = A.fpArena[fpOff + k];
+                        const uint64_t a = f.lo, b = f.hi < A.nPos ? f.hi : A.nPos - 1u;              // positions a .. b
+                        for (uint32_t pg = (uint32_t)(a >> sh); pg <= (uint32_t)(b >> sh) && !hit; pg++) hit = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
                     }
                     if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
                 }
@@ -1971,7 +2102,7 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                     for (uint32_t k = lane; k < nInst; k += 64) {
                         const uint4 in = inst[k];
                         if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
-                        const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                        const uint64_t base = A.chrBase[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
                         if (lcb_bits_any_long(A.used, lo, hi)) conflict = true;
                     }
                     if (__ballot(conflict) != 0) { at = q; kind = 2; break; }
@@ -1979,12 +2110,12 @@ __device__ inline void lcb_commit_body(const LcbCommitArgs& A)
                     for (uint32_t k = lane; k < nInst; k += 64) {                            // Finalize: MarkUsed over [Front, Back)
                         const uint4 in = inst[k];
                         A.chrStamp[in.x] = ph + 1;
-                        const uint32_t base = A.chrStart[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
+                        const uint64_t base = A.chrBase[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
                         if (hi > lo) {
                             lcb_bits_set(A.used, lo, hi);
-                            for (uint32_t pg = lo >> sh; pg <= (hi - 1u) >> sh; pg++) atomicOr(&sPage[pg >> 5], 1u << (pg & 31));
+                            for (uint32_t pg = (uint32_t)(lo >> sh); pg <= (uint32_t)((hi - 1u) >> sh); pg++) atomicOr(&sPage[pg >> 5], 1u << (pg & 31));
                             const uint32_t slot = atomicAdd(A.deltaCount, 1u);
-                            if (slot < A.deltaCap) A.deltaList[slot] = uint2{lo, hi};
+                            if (slot < A.deltaCap) A.deltaList[slot] = LcbFpOut{lo, hi};
                         }
                     }
                     LCB_WAVE_SYNC();

@@ -136,7 +136,7 @@ int main(int argc, char** argv)
             for (int i = 0; i < nGpus; i++) ord.push_back(i);
             lcb_hooks hk;
             memset(&hk, 0, sizeof(hk));
-            hk.world = 1; hk.progress = 1;
+            hk.abi = LCB_ABI_VERSION; hk.world = 1; hk.progress = 1;
             // the same handle bench.py --gpus N times: devices + tables + RCCL once, then one pass
             lcb_gpus* set = lcb_gpus_create(g, ord.data(), nGpus, &p, nullptr, 0);
             if (!set) { fail(); break; }

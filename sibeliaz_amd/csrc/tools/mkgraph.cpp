@@ -67,8 +67,7 @@ inline int code(char c) {
 // filled concurrently: a slot is claimed with a compare-and-swap on its key, the masks are OR-ed in atomically.
 struct KmerTable {
     std::vector<std::atomic<uint64_t>> key;   // code + 1, 0 = empty
-    std::vector<std::atomic<uint32_t>> val;
-    std::vector<uint32_t> id;
+    std::vector<std::atomic<uint32_t>> val;   // the masks; after the junctions are known the same word holds the k-mer's id (bit 31 set)
     std::atomic<size_t> used{0};
     size_t mask = 0;
     explicit KmerTable(size_t cap) : key(cap), val(cap), mask(cap - 1)
@@ -98,7 +97,7 @@ struct KmerTable {
             uint64_t k = key[h].load(std::memory_order_relaxed);
             if (k == 0) {
                 if (key[h].compare_exchange_strong(k, kmer + 1, std::memory_order_relaxed)) {
-                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 7) { full.store(true, std::memory_order_relaxed); return false; }
+                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 9) { full.store(true, std::memory_order_relaxed); return false; }   // (load factor 0.9: a table of 2^31 slots is 24 GB)
                     k = kmer + 1;
                 }
             }
@@ -204,7 +203,6 @@ int main(int argc, char** argv) {
             });
         }
         PHASE("junction occurrences");
-        table.id.assign(cap, 0);
         uint32_t nextId = 1;
         uint64_t written = 0;
         FILE* f = fopen(out.c_str(), "wb");
@@ -222,8 +220,10 @@ int main(int argc, char** argv) {
             for (; c < chunks.size() && chunks[c].rec == r; c++) {
                 for (const Occ& o : found[c]) {
                     const size_t h = ((size_t)o.slotHi << 32) | o.slotLo;
-                    if (!table.id[h]) table.id[h] = nextId++;
-                    put(o.pos, o.fwd ? (int64_t)table.id[h] : -(int64_t)table.id[h]);
+                    uint32_t v = table.val[h].load(std::memory_order_relaxed);
+                    if (!(v & 0x80000000u)) { v = 0x80000000u | nextId++; table.val[h].store(v, std::memory_order_relaxed); }     // (the masks are no longer needed)
+                    const int64_t id = (int64_t)(v & 0x7FFFFFFFu);
+                    put(o.pos, o.fwd ? id : -id);
                     written++;
                 }
                 std::vector<Occ>().swap(found[c]);

@@ -36,12 +36,13 @@ int main(int argc, char** argv)
         std::vector<uint32_t> chrStart(1, 0);
         for (uint32_t i = 0; i < nChr; i++) chrStart.push_back(chrStart.back() + 40 + rnd(600));
         const uint32_t nPos = chrStart.back(), words = nPos / 32 + 2;
+        const std::vector<uint64_t> chrBase(chrStart.begin(), chrStart.end() - 1);
         std::vector<uint32_t> used(words, 0), stamp(nChr + 1, 0);
         for (uint32_t k = rnd(4); k > 0; k--) { const uint32_t a = rnd(nPos); setBits(used, a, std::min(nPos, a + 1 + rnd(30))); }
         const uint32_t nRound = 8 + rnd(120);
         std::vector<uint32_t> seedIdx, off(1, 0), fpOff(1, 0);
         std::vector<uint4> inst;
-        std::vector<uint2> fp;
+        std::vector<LcbFpOut> fp;
         const uint32_t density = 1 + rnd(4);
         for (uint32_t s = 0; s < nRound; s++) {
             if (rnd(4) >= density) continue;                                          // a dead seed: not in the live list
@@ -51,16 +52,16 @@ int main(int argc, char** argv)
                 const bool pos = rnd(2) != 0;
                 inst.push_back(uint4{chr, pos ? a : b, pos ? b : a, pos ? 1u : 0u});
                 const uint32_t lo = chrStart[chr] + a, hi = chrStart[chr] + b;
-                fp.push_back(uint2{lo > 5 ? lo - rnd(6) : lo, std::min(nPos - 1, hi + rnd(6))});
+                fp.push_back(LcbFpOut{lo > 5 ? lo - rnd(6) : lo, std::min(nPos - 1, hi + rnd(6))});
             }
-            for (uint32_t k = rnd(3); k > 0; k--) { const uint32_t a = rnd(nPos); fp.push_back(uint2{a, std::min(nPos - 1, a + rnd(12))}); }
-            if (rnd(8) == 0) fp.push_back(uint2{rnd(nPos), 0xFFFFFFF0u});             // an over-wide interval (clamped by the kernel)
+            for (uint32_t k = rnd(3); k > 0; k--) { const uint32_t a = rnd(nPos); fp.push_back(LcbFpOut{a, std::min(nPos - 1, a + rnd(12))}); }
+            if (rnd(8) == 0) fp.push_back(LcbFpOut{rnd(nPos), 0xFFFFFFFFFFF0ull});             // an over-wide interval (clamped by the kernel)
             seedIdx.push_back(s); off.push_back((uint32_t)inst.size()); fpOff.push_back((uint32_t)fp.size());
         }
         const uint32_t nLive = (uint32_t)seedIdx.size();
         if (!nLive) { c--; continue; }
         if (inst.empty()) inst.push_back(uint4{0, 0, 0, 0});
-        if (fp.empty()) fp.push_back(uint2{0, 0});
+        if (fp.empty()) fp.push_back(LcbFpOut{0, 0});
         // ---- the sequential restatement (phase-start validation as the kernel does it: a footprint interval that touches a PAGE with a
         // mark of this round hands the phase over, stop kind 3 - a superset of the intervals that hold a marked bit)
         const uint32_t pageShift = 1u + (uint32_t)(c % 7);               // tiny pages: intervals span many of them
@@ -73,7 +74,7 @@ int main(int argc, char** argv)
             while (lqEnd < nLive && seedIdx[lqEnd] / phase == ph) lqEnd++;
             for (uint32_t q = lq; q < lqEnd && !rKind; q++)
                 for (uint32_t k = fpOff[q]; k < fpOff[q + 1]; k++)
-                    { bool pg = false; for (uint32_t q2 = fp[k].x >> pageShift; q2 <= std::min(fp[k].y, nPos - 1) >> pageShift; q2++) pg = pg || rPage[q2]; if (pg) { rStop = lq; rKind = 3; break; } }
+                    { bool pg = false; for (uint32_t q2 = (uint32_t)(fp[k].lo >> pageShift); q2 <= (uint32_t)(std::min<uint64_t>(fp[k].hi, nPos - 1) >> pageShift); q2++) pg = pg || rPage[q2]; if (pg) { rStop = lq; rKind = 3; break; } }
             if (rKind) break;
             for (uint32_t q = lq; q < lqEnd; q++) {
                 if (off[q + 1] - off[q] <= 1) continue;
@@ -99,7 +100,7 @@ int main(int argc, char** argv)
         // ---- the kernel body under the emulator (2, 4, 8 or 16 wavefronts), behind each of 1-4 launches of the round
         std::vector<uint32_t> committed(nRound, 0xFFFFFFFFu), state(LCB_CS_WORDS, 0u), roundState(nRound, LCB_RS_NONE);
         std::vector<LcbSeedOut> roundOut(nRound);
-        std::vector<uint2> deltaList(64 + rnd(2000));
+        std::vector<LcbFpOut> deltaList(64 + rnd(2000));
         uint32_t deltaCount = 0;
         const uint32_t nLaunch = 1 + rnd(4);
         std::vector<uint32_t> launchOf(nRound);                  // the launch that brings a seed's final result
@@ -118,7 +119,7 @@ int main(int argc, char** argv)
                 roundOut[i] = o; roundState[i] = LCB_RS_DONE;
             }
             LcbCommitArgs A;
-            A.chrStart = chrStart.data(); A.used = used.data(); A.chrStamp = stamp.data();
+            A.chrBase = chrBase.data(); A.used = used.data(); A.chrStamp = stamp.data();
             A.roundState = roundState.data(); A.roundOut = roundOut.data(); A.arena = inst.data(); A.fpArena = fp.data();
             A.n = nRound; A.phase = phase; A.nPos = nPos; A.state = state.data(); A.committed = committed.data();
             A.deltaList = deltaList.data(); A.deltaCount = &deltaCount; A.deltaCap = (uint32_t)deltaList.size();
@@ -137,7 +138,7 @@ int main(int argc, char** argv)
         for (size_t i = 0; ok && i < rCommitted.size(); i++) ok = committed[i] == seedIdx[rCommitted[i]];
         if (ok && deltaCount <= deltaList.size()) {              // the list of the round's marked ranges covers exactly what the round marked
             std::vector<uint32_t> cover(words, 0);
-            for (uint32_t r = 0; r < deltaCount; r++) setBits(cover, deltaList[r].x, deltaList[r].y);
+            for (uint32_t r = 0; r < deltaCount; r++) setBits(cover, (uint32_t)deltaList[r].lo, (uint32_t)deltaList[r].hi);
             ok = cover == rDelta;
         }
         waits += waited;

@@ -24,6 +24,7 @@
 #include "emu_runtime.h"
 #include "lcb_host.h"
 #include "lcb_kernel.h"
+#include "lcb_segments.h"
 #include "../../oracle/lcb_oracle.h"
 
 extern "C" size_t orc_used_stride(void);
@@ -39,7 +40,7 @@ struct EmuCtx {
     std::vector<uint8_t> slot;
     LcbWork W;
     uint32_t cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<uint2> fpArena;
+    std::vector<LcbFpOut> fpArena;
     std::vector<LcbSeedOut> out;
     std::vector<LcbSeedCtr> ctr;
     std::vector<uint4> arena;
@@ -47,10 +48,31 @@ struct EmuCtx {
     std::vector<size_t> which;
 };
 
+// A per-position table in the DEVICE's flat index space: the host array itself, or - with the gap hook (EMU_SEG_GAP: unused positions
+// between the segments, flat indices beyond 2^32) - a lazily zeroed allocation of which only the segments' pages are ever touched.
+template <class T_>
+struct DevTable {
+    const T_* p = nullptr; void* own = nullptr;
+    void set(const T_* host, const LcbSegPlan& pl)
+    {
+        if (!pl.gap) { p = host; return; }
+        own = calloc((size_t)pl.devPositions + 64, sizeof(T_));
+        if (!own) throw LcbError("emu: out of memory for a gapped table");
+        for (uint32_t sg = 0; sg < pl.nSeg(); sg++) memcpy((T_*)own + pl.segDev[sg], host + pl.segStart[sg], (size_t)(pl.segStart[sg + 1] - pl.segStart[sg]) * sizeof(T_));
+        p = (const T_*)own;
+    }
+    ~DevTable() { free(own); }
+};
+
 struct Emu {
     const lcb_graph* g;
     lcb_params p;
-    std::vector<uint32_t> chrStart32, used;      // used: the live bitmap (view 0), padded to whole pages, followed by the private pages of the views
+    LcbSegPlan plan;                             // EMU_SEG_CAP / EMU_SEG_GAP: many small segments / flat indices beyond 2^32 on a small input
+    bool seg = false;
+    std::vector<uint2> chrLoHi;
+    std::vector<uint32_t> occStart32;
+    DevTable<int32_t> dPosId; DevTable<uint32_t> dPosPos; DevTable<uint8_t> dPosCh, dPosRevCh;
+    std::vector<uint32_t> used;                  // used: the live bitmap (view 0) over the device's flat index, padded to whole pages, followed by the private pages of the views
     std::vector<uint32_t> viewTab;               // predicted views: page tables (word offset from a live page to the view's copy, 0 = shared)
     size_t usedWords = 0, nPages = 0;
     int nViewsAlloc = 0;
@@ -60,7 +82,7 @@ struct Emu {
     bool big = false;
     std::vector<uint4> occRec;
     std::vector<EmuCtx> ctx;                     // one per host thread
-    std::vector<uint2> fpArena;                  // merged results of the last run()
+    std::vector<LcbFpOut> fpArena;               // merged results of the last run()
     std::vector<LcbSeedOut> out;
     std::vector<LcbSeedCtr> octr;                // per-seed counters of the last run()
     std::vector<uint4> arena;
@@ -69,18 +91,29 @@ struct Emu {
 
     Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode >= 2)
     {
-        chrStart32.assign(g->chrStart.begin(), g->chrStart.end());
+        const uint64_t segCap = getenv("EMU_SEG_CAP") ? strtoull(getenv("EMU_SEG_CAP"), nullptr, 10) : 0, segGap = getenv("EMU_SEG_GAP") ? strtoull(getenv("EMU_SEG_GAP"), nullptr, 10) : 0;
+        plan = lcb_plan_segments(*g, segCap, segGap);
+        seg = plan.nSeg() > 1 || segCap != 0;
+        if (seg && getenv("EMU_SEG_VERBOSE")) fprintf(stderr, "emu: %u segments over %zu chromosomes, %llu device positions (gap %llu)\n", plan.nSeg(), (size_t)g->nChr(), (unsigned long long)plan.devPositions, (unsigned long long)plan.gap);
         const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT;
-        usedWords = ((g->nPos() / 32 + 2) + pageWords - 1) & ~(pageWords - 1);
+        usedWords = ((plan.devPositions / 32 + 2) + pageWords - 1) & ~(pageWords - 1);
         nPages = usedWords >> LCB_PAGE_SHIFT;
         used.assign(usedWords, 0);
         viewTab.assign(nPages, 0);
-        T.chrStart = chrStart32.data(); T.posId = g->posId.data(); T.posPos = g->posPos.data();
-        T.posCh = g->posCh.data(); T.posRevCh = g->posRevCh.data(); T.occStart = g->occStart.data();
+        chrLoHi.resize(g->nChr());
+        for (size_t c = 0; c < chrLoHi.size(); c++) chrLoHi[c] = uint2{plan.chrLo[c], plan.chrHi[c]};
+        dPosId.set(g->posId.data(), plan); dPosPos.set(g->posPos.data(), plan); dPosCh.set(g->posCh.data(), plan); dPosRevCh.set(g->posRevCh.data(), plan);
+        T.chrLoHi = chrLoHi.data(); T.segBase = plan.segDev.data(); T.posId = dPosId.p; T.posPos = dPosPos.p;
+        T.posCh = dPosCh.p; T.posRevCh = dPosRevCh.p;
+        occStart32.assign(g->occStart.begin(), g->occStart.end());       // (one segment: fewer than 2^32 occurrences)
+        T.occStart32 = seg ? nullptr : occStart32.data(); T.occStart64 = seg ? g->occStart.data() : nullptr;
         occRec.resize(g->nPos());
-        for (size_t j = 0; j < occRec.size(); j++) { const uint32_t q = g->occG[j]; occRec[j] = uint4{q, g->occChr[j], g->posPos[q], (uint32_t)g->posId[q]}; }
+        for (size_t j = 0; j < occRec.size(); j++) {
+            const uint64_t q = g->occG[j]; const uint32_t cw = plan.chrWord[g->occChr[j]];
+            occRec[j] = uint4{(uint32_t)(q - plan.segStart[cw >> LCB_SEG_SHIFT]), cw, g->posPos[q], (uint32_t)g->posId[q]};
+        }
         T.occRec = occRec.data(); T.used = used.data(); T.viewTab = viewTab.data(); T.nPages = (uint32_t)nPages;
-        T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = (uint32_t)g->nPos();
+        T.nChr = g->nChr(); T.nVertex = g->nVertex; T.nPos = plan.devPositions; T.nSeg = plan.nSeg();
         KP.k = p.k; KP.minBlock = p.min_block; KP.maxBranch = p.max_branch; KP.maxFlank = p.max_flank; KP.depth = p.looking_depth;
         const char* te = getenv("EMU_THREADS");
         int nThreads = te ? atoi(te) : omp_get_max_threads();
@@ -117,7 +150,9 @@ struct Emu {
         for (int v = 1; v <= nViews; v++)
             for (int64_t m = 0; m < nMarks; m++) {
                 if ((int)marks[m].firstView > v) continue;
-                for (uint64_t q = marks[m].lo; q < marks[m].hi; q++) {
+                uint64_t mlo, mhi;
+                plan.rangeToDev(marks[m].lo, marks[m].hi, mlo, mhi);
+                for (uint64_t q = mlo; q < mhi; q++) {
                     const size_t page = q / pageBits;
                     uint32_t& e = viewTab[(size_t)v * nPages + page];
                     if (!e) {
@@ -149,11 +184,12 @@ struct Emu {
         if (!n) return;
         const char* nwEnv = getenv("EMU_NW");
         const int nw = nwEnv ? atoi(nwEnv) : 1;
-        LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); uint2* fa = c.fpArena.data();
+        LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); LcbFpOut* fa = c.fpArena.data();
         const size_t arc = c.arena.size(), fac = c.fpArena.size();
         const bool noStats = getenv("EMU_NOSTATS") != nullptr;     // the shipped instantiation (checkpointed replay, no event counters)
-#define EMU_RUN(M, ST, NW_, PF) do { if ((NW_) == 1) emu_run_wave(0, [&]() { lcb_process_body<M, ST, 1, PF>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); \
-                                       else emu_run_block(0, NW_, [&]() { lcb_process_body<M, ST, NW_, PF>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); } while (0)
+#define EMU_RUN_S(M, ST, NW_, PF, SG) do { if ((NW_) == 1) emu_run_wave(0, [&]() { lcb_process_body<M, ST, 1, PF, SG>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); \
+                                       else emu_run_block(0, NW_, [&]() { lcb_process_body<M, ST, NW_, PF, SG>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); } while (0)
+#define EMU_RUN(M, ST, NW_, PF) do { if (seg) EMU_RUN_S(M, ST, NW_, PF, true); else EMU_RUN_S(M, ST, NW_, PF, false); } while (0)
         // non-stats = the shipped code path (checkpointed replay, dead-seed early-out); the instrumented variant supplies push counts
         if (noStats && mode == 0 && nw == 1) EMU_RUN(0, false, 1, true);
         else if (noStats && mode == 0 && nw == 2) EMU_RUN(0, false, 2, true);
@@ -175,6 +211,7 @@ struct Emu {
         else if (!noStats && mode == 3 && nw == 4) EMU_RUN(3, true, 4, false);
         else { fprintf(stderr, "emu: no instantiation for mode %d, EMU_NW=%d, %s\n", mode, nw, noStats ? "no stats" : "stats"); exit(2); }
 #undef EMU_RUN
+#undef EMU_RUN_S
     }
 
     // runs the process kernel over the seeds: each host thread emulates ONE wavefront over its share of the seeds
@@ -275,7 +312,7 @@ struct EmuProcessor : LcbProcessor {
             if (o.status) throw LcbError("emulated kernel overflow");
             off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
             for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
-            for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
+            for (uint32_t e = 0; e < o.nFp; e++) { const LcbFpOut r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{emu->plan.toHost(r.lo), emu->plan.toHost(r.hi)}); }
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
         if (ctrSink) {       // stats-mode kernels: the per-seed event counters (engine's countEvents)
@@ -288,7 +325,7 @@ struct EmuProcessor : LcbProcessor {
     }
     void mark(const uint64_t* r, int64_t n) override
     {
-        for (int64_t i = 0; i < n; i++) for (uint64_t q = r[2 * i]; q < r[2 * i + 1]; q++) emu->used[q >> 5] |= 1u << (q & 31);
+        for (int64_t i = 0; i < n; i++) { uint64_t lo, hi; emu->plan.rangeToDev(r[2 * i], r[2 * i + 1], lo, hi); for (uint64_t q = lo; q < hi; q++) emu->used[q >> 5] |= 1u << (q & 31); }
     }
     void reset() override { emu->used.assign(emu->usedWords, 0u); emu->T.used = emu->used.data(); emu->nViewsAlloc = 0; emu->viewTab.assign(emu->nPages, 0); emu->T.viewTab = emu->viewTab.data(); }
     // begin / end (the engine plans a stop's speculative jobs while the results the stop needs are computed): the emulated launch
@@ -319,16 +356,16 @@ struct EmuProcessor : LcbProcessor {
     // (seeds that overflowed their kernel variant have no final result yet: the kernel must wait for them) and once after the retries
     std::vector<uint32_t> dcStamp, dcCommitted, dcState, dcRound;
     std::vector<LcbSeedOut> dcOut;
-    std::vector<uint2> dcList;
+    std::vector<LcbFpOut> dcList;
     uint32_t dcDeltaCount = 0;
     int64_t commitKernels = 0, commitWaited = 0;
     bool processRound(const lcb_seed* sd, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
                       std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
     {
         if (getenv("EMU_HOST_COMMIT") || n <= 0) return false;
-        static_assert(sizeof(lcb_instance) == sizeof(uint4) && sizeof(lcb_fp) == sizeof(uint2), "layouts the commit kernel reads");
+        static_assert(sizeof(lcb_instance) == sizeof(uint4), "layouts the commit kernel reads");
         dcDeltaCount = 0;
-        dcList.assign(getenv("EMU_DELTA_CAP") ? (size_t)atoi(getenv("EMU_DELTA_CAP")) : 4096, uint2{0u, 0u});
+        dcList.assign(getenv("EMU_DELTA_CAP") ? (size_t)atoi(getenv("EMU_DELTA_CAP")) : 4096, LcbFpOut{0u, 0u});
         dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign((size_t)n, 0u); dcState.assign(LCB_CS_WORDS, 0u);
         dcRound.assign((size_t)n, LCB_RS_NONE); dcOut.assign((size_t)n, LcbSeedOut{});
         const int nw = getenv("EMU_COMMIT_NW") ? atoi(getenv("EMU_COMMIT_NW")) : 4;
@@ -346,11 +383,11 @@ struct EmuProcessor : LcbProcessor {
                 dcRound[(size_t)i] = (o.nInst == 0 && o.nFp == 0) ? LCB_RS_DEAD : LCB_RS_DONE;
             }
             LcbCommitArgs A;
-            A.chrStart = emu->chrStart32.data(); A.used = emu->used.data(); A.chrStamp = dcStamp.data();
+            A.chrBase = emu->plan.chrDev.data(); A.used = emu->used.data(); A.chrStamp = dcStamp.data();
             A.roundState = dcRound.data(); A.roundOut = dcOut.data(); A.arena = emu->arena.data(); A.fpArena = emu->fpArena.data();
-            A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = (uint32_t)emu->g->nPos();
+            A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = emu->plan.devPositions;
             A.state = dcState.data(); A.committed = dcCommitted.data(); A.deltaList = dcList.data(); A.deltaCount = &dcDeltaCount; A.deltaCap = (uint32_t)dcList.size();
-            A.pageShift = getenv("EMU_COMMIT_PAGE_SHIFT") ? (uint32_t)atoi(getenv("EMU_COMMIT_PAGE_SHIFT")) : 5u; while ((A.nPos >> A.pageShift) >= LCB_COMMIT_PAGES) A.pageShift++;
+            A.pageShift = getenv("EMU_COMMIT_PAGE_SHIFT") ? (uint32_t)atoi(getenv("EMU_COMMIT_PAGE_SHIFT")) : 5u; while ((A.nPos >> A.pageShift) >= (uint64_t)LCB_COMMIT_PAGES) A.pageShift++;
             const uint32_t before = dcState[LCB_CS_NEXT];
             if (nw == 16) emu_run_block(0, 16, [&]() { lcb_commit_body<16>(A); });
             else if (nw == 8) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
@@ -373,7 +410,7 @@ struct EmuProcessor : LcbProcessor {
             if (o.status) throw LcbError("emulated kernel overflow");
             off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
             for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
-            for (uint32_t e = 0; e < o.nFp; e++) { const uint2 r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{r.x, r.y}); }
+            for (uint32_t e = 0; e < o.nFp; e++) { const LcbFpOut r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{emu->plan.toHost(r.lo), emu->plan.toHost(r.hi)}); }
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
         committed.assign(dcCommitted.begin(), dcCommitted.begin() + dcState[LCB_CS_NCOMMITTED]);
@@ -489,7 +526,7 @@ int main(int argc, char** argv)
                 for (int64_t c = 0; c < orc_n_chr(og); c++) {
                     const uint8_t* u = orc_chr_used(og, c);
                     for (int64_t i = 0; i < orc_chr_n_pos(og, c); i++)
-                        if (u[(size_t)i * stride]) { const uint64_t q = g->chrStart[c] + i; emu.used[q >> 5] |= 1u << (q & 31); }
+                        if (u[(size_t)i * stride]) { const uint64_t q = emu.plan.toDev(g->chrStart[c] + i); emu.used[q >> 5] |= 1u << (q & 31); }
                 }
             }
             if (getenv("EMU_ONLY")) { const lcb_seed one = seeds[atoi(getenv("EMU_ONLY"))]; seeds.assign(1, one); }
@@ -507,7 +544,7 @@ int main(int argc, char** argv)
                     // footprint intervals set to used, Process() must still give this result - it never read those bits as 0.
                     const LcbSeedOut& o = emu.out[i];
                     std::vector<uint8_t> keep((size_t)g->nPos(), 0);
-                    for (uint32_t e = 0; e < o.nFp; e++) { const uint2 f = emu.fpArena[o.fpOff + e]; for (uint32_t q = f.x; q <= f.y && q < keep.size(); q++) keep[q] = 1; }
+                    for (uint32_t e = 0; e < o.nFp; e++) { const LcbFpOut f = emu.fpArena[o.fpOff + e]; for (uint64_t q = emu.plan.toHost(f.lo); q <= emu.plan.toHost(f.hi) && q < keep.size(); q++) keep[q] = 1; }
                     const size_t stride = orc_used_stride();
                     std::vector<uint8_t*> flipped;
                     for (int64_t c = 0; c < orc_n_chr(og); c++) {
@@ -560,8 +597,9 @@ int main(int argc, char** argv)
                 cfg.roundFixed = envInt("LCB_ROUND_FIXED") != 0; cfg.maxJobs = envInt("LCB_MAX_JOBS");
                 if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F"));
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
+                if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN") ? envInt("LCB_LAZY_SPAN") : -1;
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls (host commit only)
-                cfg.hostCommit = getenv("EMU_HOST_COMMIT") != nullptr;       // default: the commit kernel body under the emulator commits the clean prefix of every round
+                cfg.hostCommit = getenv("EMU_HOST_COMMIT") != nullptr;       // the round's speculative launch as a background batch (needs EMU_SIDE_LANES)       // default: the commit kernel body under the emulator commits the clean prefix of every round
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -624,6 +662,7 @@ int main(int argc, char** argv)
                         proc.views = getenv("EMU_VIEWS") ? atoi(getenv("EMU_VIEWS")) : 64;
                         EmuRankLink link{&ex, r};
                         LcbEngineConfig cfg; cfg.roundPhases = R; cfg.rank = r; cfg.world = world;
+                        if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = atoi(getenv("LCB_LAZY_SPAN")) ? atoi(getenv("LCB_LAZY_SPAN")) : -1;
                         cfg.allgather = emuAllgather; cfg.allgatherUser = &link;
                         lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocksOf[(size_t)r], &statsOf[(size_t)r]);
                     } catch (std::exception& e) { errOf[(size_t)r] = e.what(); }

@@ -237,6 +237,7 @@ int main(int argc, char** argv)
         if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F", 0));
         if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
         cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
+        if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN", 0) ? envInt("LCB_LAZY_SPAN", 0) : -1;
         std::vector<lcb_block> blocks;
         LcbEngineStats es;
         const auto t0 = std::chrono::steady_clock::now();

@@ -32,6 +32,8 @@ CASES = [
     # ... and at the Gbp scale one box generates in about a minute (8 x 24 chromosomes = 1.24 Gbp, 16 x 20 = 1.0 Gbp)
     ("config4_primates8_scaled", "primates8_scaled", 150),
     ("config5_mice16_scaled", "mice16_scaled", 150),
+    # ... and config 4's shape at 4.1 Gbp (P = 0.8 G occurrences: ~30 GB in the reference, most of the build container's memory)
+    ("config4_primates8_4g_scaled", "primates8_4g", 150),
 ]
 
 

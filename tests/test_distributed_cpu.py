@@ -64,7 +64,11 @@ def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
                                             # published through collective exchanges (batches computed at once / late / visible late / refused by a lane)
                                             ("nruns_abund", 2, {"EMU_SIDE_LANES": "2"}), ("tandem4", 3, {"EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "EMU_SIDE_DELAY": "2", "EMU_ROUNDS": "8"}),
                                             ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16"}),
-                                            ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"})])
+                                            ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"}),
+                                            # eight ranks (results do not depend on 1 / 2 / 4 / 8 ranks), with and without background batches
+                                            ("twogenomes", 8, {}), ("nruns_abund", 8, {"EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1"}),
+                                            # ... and with positions as (segment, offset) pairs (the SEG kernels; test_host_cpu.py)
+                                            ("tandem4", 4, {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "99991", "EMU_SIDE_LANES": "2"})])
 def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, env):
     """The multi-rank round engine with the wave emulator as each rank's device: every launch (rounds AND job launches against
     predicted `used` views) is dealt to the ranks, per-seed results and REAL footprints cross pack / all-gather / unpack, every

@@ -30,7 +30,7 @@ def _sha256(path):
     return h.hexdigest()
 
 
-def check_case(name, g, out_dir):
+def check_case(name, g, out_dir, device_opts=None):
     """One full-size case through the C ABI against the reference's hashes (also used by scripts/check_fullsize_scaled.py for the
     Gbp-scale cases of tests/golden/fullsize_scaled.json, which the default suite cannot afford: 2.5 minutes of generation each)."""
     import bench
@@ -40,7 +40,7 @@ def check_case(name, g, out_dir):
     threads = min(32, os.cpu_count() or 1)
     st = sibeliaz_amd.JunctionStorage(w["graph"], [w["fasta"]], g["k"], threads=threads, abundance=g["a"])
     p = sibeliaz_amd.Params.make(g["k"], b=g["b"], m=g["m"])
-    dev = sibeliaz_amd.Device(st, p, 0)
+    dev = sibeliaz_amd.Device(st, p, 0, **(device_opts or {}))
     finder = sibeliaz_amd.BlocksFinder(st, g["k"])
     finder.FindBlocks(g["m"], g["b"], device=dev, threads=threads)
     out = os.path.join(out_dir, "out")

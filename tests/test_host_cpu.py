@@ -34,13 +34,13 @@ def test_ctypes_structs_have_the_layout_of_the_header(built, tmp_path):
     from sibeliaz_amd import api
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lcb.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lcb_stats), sizeof(lcb_hooks), '
-                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, kernel_side_ms), offsetof(lcb_hooks, host_commit), '
-                   'offsetof(lcb_device_opts, side_lanes)); return 0; }\n')
+                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, lazy_seeds), offsetof(lcb_hooks, lazy_span), '
+                   'offsetof(lcb_device_opts, seg_gap)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     want = [C.sizeof(api.Stats), C.sizeof(api.Hooks), C.sizeof(api.DeviceOpts), sibeliaz_amd.SEED_DTYPE.itemsize, sibeliaz_amd.BLOCK_DTYPE.itemsize,
-            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.kernel_side_ms.offset, api.Hooks.host_commit.offset, api.DeviceOpts.side_lanes.offset]
+            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.lazy_seeds.offset, api.Hooks.lazy_span.offset, api.DeviceOpts.seg_gap.offset]
     assert got == want
     header = open(os.path.join(ROOT, "include", "lcb.h")).read()
     assert int(re.search(r"#define LCB_ABI_VERSION (\d+)", header).group(1)) == api.ABI_VERSION == sibeliaz_amd.load_library().lcb_abi_version()
@@ -211,7 +211,20 @@ def emu_built():
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
-                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"})])
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"}),
+                                            # Positions as (segment, 32-bit offset) pairs - the SEG kernels that inputs of 2^32 junction occurrences and more run.
+                                            # EMU_SEG_CAP cuts a golden into segments of a few chromosomes (one chromosome each at the small values), EMU_SEG_GAP
+                                            # puts unused table space between them: with more than 2^32 the flat indices no longer fit 32 bits, i.e. every 64-bit
+                                            # address computation of the device code runs here (the gapped tables are lazily zeroed allocations)
+                                            ("collinear6", "seeds-init", {"EMU_SEG_CAP": "3000", "EMU_LIMIT": "1200"}),
+                                            ("twogenomes", "seeds-init", {"EMU_SEG_CAP": "4000", "EMU_SEG_GAP": "4300000000", "EMU_LIMIT": "400", "EMU_FP_CHECK": "1"}),
+                                            ("twogenomes", "seeds-final", {"EMU_SEG_CAP": "4000", "EMU_SEG_GAP": "4300000000", "EMU_NOSTATS": "1", "EMU_NW": "2"}),
+                                            ("inv_k25", "medium", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "777", "EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_FP_CHECK": "1"}),
+                                            ("inv_k25", "big", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "100000", "EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SCHED": "rr", "EMU_FP_CHECK": "1"}),
+                                            ("twogenomes", "huge", {"EMU_SEG_CAP": "1000", "EMU_LIMIT": "800"}),
+                                            ("nruns_abund", "find", {"EMU_SEG_CAP": "1500", "EMU_SEG_GAP": "1000"}),
+                                            ("twogenomes", "find", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "70000", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_NW": "2", "EMU_EXPECT_DEVICE_COMMIT": "1"}),
+                                            ("tandem4", "find", {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "123457", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "EMU_COMMIT_NW": "16"})])
 def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode, env, tmp_path):
     """The unmodified device code of lcb_kernel.h on the CPU wavefront emulator (tests/emu) vs the oracle: per-seed results,
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
