@@ -1446,8 +1446,8 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
     lcb_engine_run(g, p, seeds, nSeeds, proc, cfg, blocks, &es);
     lcb_device_drain_lanes(dev->impl);      // (the last batches are released but not retired: their kernel time belongs to this pass)
     if (getenv("LCB_VERBOSE"))
-        fprintf(stderr, "lcb engine: %.0f ms = processor %.0f + dry runs %.0f + rest %.0f (round setup %.0f, validation %.0f, commit %.0f, marks to the device %.0f, mirror of device commits %.0f) | "
-                        "device-resident commit: %lld rounds, %lld kernels, %lld given up\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs, es.sectionMs[LCB_SEC_SETUP],
+        fprintf(stderr, "lcb engine: %.0f ms = processor %.0f + dry runs %.0f (marks to the device %.0f, simulation %.0f; %lld views) + rest %.0f (round setup %.0f, validation %.0f, commit %.0f, marks to the device %.0f, mirror of device commits %.0f) | "
+                        "device-resident commit: %lld rounds, %lld kernels, %lld given up\n", es.wallMs, es.processMs, es.planMs, es.sectionMs[LCB_SEC_PLAN_FLUSH], es.sectionMs[LCB_SEC_PLAN_SIM], (long long)es.viewsBuilt, es.wallMs - es.processMs - es.planMs, es.sectionMs[LCB_SEC_SETUP],
                 es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_MIRROR], (long long)dev->impl->rc.rounds, (long long)dev->impl->rc.kernels,
                 (long long)dev->impl->rc.abandoned);
     if (stats) {

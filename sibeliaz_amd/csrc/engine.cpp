@@ -432,10 +432,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         };
 
         // Every predicted mark of the job's view is true by now - or, inside a dry run, still predicted (simP).
-        auto sidePlausible = [&](const SideJob& sj, const RangeSet* simP) -> bool {
+        auto sidePlausible = [&](const SideJob& sj) -> bool {
             if (sj.set < 0) return true;
             return viewSets[(size_t)sj.set].allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
-                                                       [&](const std::pair<uint64_t, uint64_t>& q) { return simP && simP->covers(q.first, q.second); });
+                                                       [&](const std::pair<uint64_t, uint64_t>&) { return false; });
         };
         // The commit needs the E / F of seed i now and a job for it is in flight: its result is taken (waiting for that one job)
         // if its view came true - at this point every commit the view predicted has either happened or will never happen -,
@@ -512,7 +512,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         auto takeSide = [&](int64_t i, bool isF) -> bool {
             const int32_t ref = (isF ? sideF : sideE)[(size_t)i];
             if (ref < 0) return false;
-            if (sideJobs[(size_t)ref].state != 0 || !sidePlausible(sideJobs[(size_t)ref], nullptr)) { dropSide(ref); return false; }
+            if (sideJobs[(size_t)ref].state != 0 || !sidePlausible(sideJobs[(size_t)ref])) { dropSide(ref); return false; }
             if (multi) {
                 exchangeSide(ref);
                 if (sideJobs[(size_t)ref].state == 0) throw LcbError("engine: the owner of a background job did not publish its result");
@@ -549,6 +549,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             inPlan = true;
             flush();                                // processor state == live state
             inPlan = false;
+            st.sectionMs[LCB_SEC_PLAN_FLUSH] += msSince(tPlan);
+            const auto tSim = std::chrono::steady_clock::now();
             RangeSet simP;                          // predicted marks on top of the live state
             std::vector<uint8_t> simChr(com.invalidChr.begin(), com.invalidChr.end());
             std::vector<uint32_t> simChrList(com.invalidList.begin(), com.invalidList.end());
@@ -584,11 +586,22 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 return false;
             };
             // would this result still be exact if the predicted marks came true? (conditions (1) and (2) against live + simP)
+            // "Is every predicted mark of view set v true by now or predicted by this dry run?" is asked once per view set and plan, not once
+            // per result or job that read the view (hundreds share one): the answer at the first question stands for the rest of the plan
+            // (a "yes" stays true - simP only grows; a "no" that would turn into a "yes" a few seeds later only costs a recomputation).
+            std::vector<int8_t> setFits(viewSets.size(), (int8_t)-1);
+            auto viewFits = [&](int32_t v) -> bool {
+                if (v < 0) return true;
+                if ((size_t)v >= setFits.size()) setFits.resize(viewSets.size(), (int8_t)-1);
+                int8_t& m = setFits[(size_t)v];
+                if (m < 0) m = viewSets[(size_t)v].allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
+                                                              [&](const std::pair<uint64_t, uint64_t>& q) { return simP.covers(q.first, q.second); }) ? 1 : 0;
+                return m != 0;
+            };
             auto simValid = [&](int32_t epoch, int32_t view, uint32_t& checkedTo, const lcb_fp* f, size_t nf) -> bool {
                 const RangeSet* P = view >= 0 ? &viewSets[(size_t)view] : nullptr;
                 // a predicted mark that is neither true yet nor predicted now voids the result (partly true + partly predicted is rare: treated as void)
-                if (P && !P->allPending([&](const std::pair<uint64_t, uint64_t>& q) { return com.allUsed(q.first, q.second); },
-                                        [&](const std::pair<uint64_t, uint64_t>& q) { return simP.covers(q.first, q.second); })) return false;
+                if (P && !viewFits(view)) return false;
                 const uint32_t last = (uint32_t)epochMarks.size() - 1;
                 for (uint32_t e = std::max((uint32_t)epoch, checkedTo); e <= last; e++) {
                     if (epochMarks[e].empty()) continue;
@@ -603,7 +616,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 if (!useSide) return false;
                 const int32_t ref = (isF ? sideF : sideE)[(size_t)j];
                 if (ref < 0) return false;
-                if (sideJobs[(size_t)ref].state == 0 && sidePlausible(sideJobs[(size_t)ref], &simP)) return true;
+                if (sideJobs[(size_t)ref].state == 0 && viewFits(sideJobs[(size_t)ref].set)) return true;
                 dropSide(ref);
                 return false;
             };
@@ -689,6 +702,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 simChrList.clear();
                 lv = lvEnd;
             }
+            st.sectionMs[LCB_SEC_PLAN_SIM] += msSince(tSim) - earlyMs;
             // ---- launch
             if (jobs.empty()) throw LcbError("engine: commit stopped but the dry run found nothing to compute");
             sub.clear(); subView.clear();

@@ -213,7 +213,9 @@ enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch 
        LCB_SEC_VALIDATE,       // phase-start validation of footprints against the marks since a result's launch
        LCB_SEC_COMMIT,         // weak conflict check, Finalize, marks into the epochs
        LCB_SEC_FLUSH,          // marks handed to the processor (LcbProcessor::mark)
-       LCB_SEC_MIRROR };       // block ids / BlockInstances / host bitmap of what the processor committed itself
+       LCB_SEC_MIRROR,         // block ids / BlockInstances / host bitmap of what the processor committed itself
+       LCB_SEC_PLAN_FLUSH,     // inside the dry runs (planMs): marks handed to the processor before a plan ...
+       LCB_SEC_PLAN_SIM };     // ... and the simulation of the rest of the round
 
 struct LcbEngineStats {
     int64_t seeds = 0, blocksFound = 0, failures = 0, rounds = 0, recomputeLaunches = 0, recomputedSeeds = 0, conflictLaunches = 0,

@@ -1317,7 +1317,9 @@ __device__ inline bool lcb_push(ST& S, const LcbEdgeT<typename ST::OccIdx>& E, b
             {   // the creating read (the occurrence's own `used` bit was 0)
                 const uint32_t fs = lcb_fp_slot(S, i);
                 if (fs >= S.nFp) { S.fpLo[fs] = g; S.fpHi[fs] = g; lcb_fp_set_seg(S, fs, lcb_cw_seg(chr)); }
+#ifndef LCB_TEST_PLAIN_FP_READ
                 else if (HOIST) { atomicMin(&S.fpLo[fs], g); atomicMax(&S.fpHi[fs], g); }     // (slots in the HBM workspace are only ever UPDATED with atomics: the walks of the other wavefronts update them at the L2)
+#endif
                 else { if (g < S.fpLo[fs]) S.fpLo[fs] = g; if (g > S.fpHi[fs]) S.fpHi[fs] = g; }
             }
             S.scr[r] = u; S.scr[64 + r] = g; S.scr[128 + r] = i;
@@ -1842,8 +1844,12 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             else for (uint32_t e = S.lane; e < nfp; e += 64) {
                 // (slots in the HBM workspace were updated with atomics at the L2 by every wavefront of the workgroup: read them there, not
                 // through a line this wavefront's L1 may still hold from an earlier plain read)
+#ifdef LCB_TEST_PLAIN_FP_READ      // (experiment build only: the read-out as it was before commit 0d6481f - can tests/test_gpu_segments.py see the stale line?)
+                const uint32_t lo = S.fpLo[e], hi = S.fpHi[e];
+#else
                 const uint32_t lo = INST_LDS ? S.fpLo[e] : __hip_atomic_load(&S.fpLo[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t hi = INST_LDS ? S.fpHi[e] : __hip_atomic_load(&S.fpHi[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 const uint64_t sb = lcb_seg_base(S, lcb_fp_get_seg(S, e));
                 LcbFpOut r; r.lo = sb + (lo ? lo - 1 : 0u); r.hi = sb + hi; fpa[fpo + e] = r;
             }

@@ -361,14 +361,15 @@ def test_persistent_gpu_set(built, case):
 
 
 @pytest.mark.parametrize("knobs,dev_opts", [({}, {}), ({"sync_jobs": 1}, {}), ({"round_fixed": 1, "round_phases": 1}, {}), ({"round_fixed": 1, "round_phases": 64, "max_jobs": 8}, {}),
-                                            ({}, {"arena": 64}), ({"round_fixed": 1, "round_phases": 64}, {"start_mode": 1, "path_cap": 512, "path_cap_max": 512}),
+                                            ({"lazy_span": -1}, {"arena": 64}), ({"round_fixed": 1, "round_phases": 64}, {"start_mode": 1, "path_cap": 512, "path_cap_max": 512}),
                                             ({}, {"batch": 300, "screen_min": 64})])
 def test_device_resident_commit_on_gpu(built, case, knobs, dev_opts):
     """SURVEY 8f-4, on by default: the clean prefix of every round is validated, conflict-checked and marked used by lcb_commit_kernel,
     chained behind every launch of the round on the launch's stream, over the results where the kernels left them; the host mirrors it
     and takes over at the first seed that needs a new computation. Same blocks and conflict count as the reference and as the host-only
     commit (lcb_hooks.host_commit) - with the default options, without side lanes, with one-phase rounds, with a tiny job cap, with a
-    result arena so small that rounds have to give the commit up (their arenas are reset between launches), with compact path sets so
+    result arena so small that rounds have to give the commit up (their arenas are reset between launches; no lazy round tails there: the few
+    rounds of a golden would all begin with seeds that overflow that arena), with compact path sets so
     small that seeds overflow into later launches of their round (the commit kernel waits for them), and with rounds of several
     screened launches. Something must actually have been committed on the device."""
     st, p, dev = _setup(case, **dev_opts)
