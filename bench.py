@@ -53,6 +53,8 @@ def _wl(strains, segments, seed, desc, k=15, b=200, m=50, a=150):
 WORKLOADS = {
     # SURVEY.md §8d config 3 at its stated size: 62 strains x ~4.5 Mbp = 281 Mbp, seed 1002
     "ecoli62": _wl(62, 1200, 1002, "62 synthetic E. coli-like strains (281 Mbp), k=15, b=200, m=50, a=150 [BASELINE configs[2]; SURVEY.md §8d config 3, lcb-synth seed 1002]"),
+    # the same genomes and graph with the abundance threshold the reference's README derives for them: a = 2 * 62 * 7 (README.md:161-175; SURVEY.md section 8d "report both")
+    "ecoli62_a868": dict(_wl(62, 1200, 1002, "62 synthetic E. coli-like strains (281 Mbp), k=15, b=200, m=50, a=868 = 2 * N * D [SURVEY.md §8d config 3, second abundance]", a=868), files="ecoli62"),
     # bounded samples of it for the CPU baseline: same generator and parameters, 1/10 and 1/40 of the ancestor's segments
     "ecoli62_small": _wl(62, 120, 1002, "62 synthetic strains (32 Mbp: config 3 with 1/10 of the segments), k=15, b=200, m=50, a=150"),
     "ecoli62_tiny": _wl(62, 30, 1002, "62 synthetic strains (8 Mbp: config 3 with 1/40 of the segments), k=15, b=200, m=50, a=150"),
@@ -104,7 +106,7 @@ def log(*a):
 
 def ensure_workload(name):
     w = WORKLOADS[name]
-    d = os.path.join(os.environ.get("LCB_BENCH_DIR", "/tmp/lcb_bench"), name)
+    d = os.path.join(os.environ.get("LCB_BENCH_DIR", "/tmp/lcb_bench"), w.get("files", name))       # (workloads that differ in parameters only share their files)
     os.makedirs(d, exist_ok=True)
     fa, gr = os.path.join(d, "genomes.fa"), os.path.join(d, "graph.bin")
     import fcntl
@@ -251,6 +253,8 @@ def cpu_baseline(workload, threads, full, our_gff_path, budget_s=600.0):
                           "the WHOLE benchmarked workload, " if on_whole else "", top["sample"], t32, top["runs"], top["analyze_s_median"], host,
                           "" if on_whole or not full else "; the run on the whole workload did not finish within its limit (legs['%s'])" % whole_tag),
             "gff_md5_equal": same_full if on_whole else bool(same_small), "gff_md5_equal_on_sample": bool(same_small),
+            "stated_comparison": "-t %d: the reference's own wrapper never asks for more (sibeliaz:139), and on this host -t 64 is SLOWER than -t %d (legs['t64_sample']; "
+                                 "north_star's 64-thread figure is that leg)" % (t32, t32),
             "legs": per_t,
             "note": "legs named *_sample run on the bounded samples named in them (1/10 of the segments; 1/40 for -t 1); the reference's own wrapper caps -t at 32 "
                     "(sibeliaz:139); every leg has a time limit so that the default run stays within minutes"}
@@ -433,10 +437,13 @@ def main():
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command
         # (scripts/gpu_r2_evidence.sh), committed with the profile summaries; only for the workload they were taken on
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
         if args.workload == "ecoli62" and n_gpus == 1 and os.path.exists(pmc_file):
-            traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r04/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+            pmc = json.load(open(pmc_file))
+            traffic = pmc["hbm_bytes_per_launch"]
+            traffic_src = ("profiles/r05/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs) of `bench.py --steps 1 --warmup 0` on this workload, "
+                           "FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md), per process-kernel launch; counted on a build of kernel sources %s, this build is %s"
+                           % (pmc.get("kernel_source_hash"), source_hash()))
         line = {
             "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -444,21 +451,21 @@ def main():
             "config": {"workload": w["desc"], "lcb_synth": w["synth"], "seeds": S, "junction_occurrences": storage.n_positions(),
                        "vertices": storage.GetVerticesNumber(), "phase_size": 256,
                        "parallelism": "one seed per workgroup: compact variant (2 wavefronts, 5 workgroups per CU) for launches of many seeds, wide variant (16 wavefronts "
-                                      "sharing the votes) for launches of few, big variant for seeds with thousands of instances; speculative rounds of up to 256 phases and dry-run job launches against predicted used views, exact footprint "
-                                      "validation; %d GPU(s)%s" % (n_gpus, ", every launch dealt to the ranks, ncclAllGather of results" if n_gpus > 1 else ", a stop's speculative jobs on side lanes"),
+                                      "sharing the votes) for launches of few, big variant for seeds with thousands of instances; speculative rounds of up to 256 phases with lazy tails and dry-run job launches against predicted used views, exact footprint "
+                                      "validation, ordered commit on the host; %d GPU(s)%s" % (n_gpus, ", every launch dealt to the ranks, ncclAllGather of results" if n_gpus > 1 else ", a stop's speculative jobs on side lanes"),
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
                        "job_launches": int(st["recompute_launches"]), "jobs": int(st["recomputed_seeds"]), "jobs_used": int(st["jobs_used"]),
                        "views_built": int(st["views_built"]), "over_predicted": int(st["over_predicted"]),
                        "conflict_launches": int(st["conflict_launches"]), "exchanges": int(st["exchanges"]),
                        "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
                        "early_critical_launches": int(st.get("early_critical", 0)),
-                       "device_resident_commit": {"results": int(st.get("device_commits", 0)), "whole_rounds": int(st.get("device_rounds", 0))},
+                       "lazy_seeds": int(st.get("lazy_seeds", 0)),
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())) if gpus is None else None,
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},
                        "untimed_s": {"load_graph": t_load, "enumerate_seeds": t_seeds, "create_device_upload_tables": t_upload}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_profiled": {"hbm_bytes_per_launch": traffic, "source": traffic_src} if traffic else None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "lcb_process_kernel (all variants)", "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": abytes / max(1.0, lps), "avg_launch_ms": kernel_ms / max(1, launches),
                          "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_busy_ms / args.steps, "bytes_per_seed": abytes / S,
@@ -491,6 +498,11 @@ def main():
                     line["cpu_baseline"] = cb
             except Exception as e:       # the reference's legs must never cost the line itself
                 line["cpu_baseline_error"] = repr(e)
+        # the other shapes of BASELINE.json on the scoreboard: lines of the same bench.py on the same build, run in the round's evidence call
+        # (scripts/r05/gpu_r5_evidence.sh) and committed with their logs - builder-run, not timed in this process
+        sec_file = os.path.join(ROOT, "profiles", "r05", "secondary.json")
+        if args.workload == "ecoli62" and os.path.exists(sec_file):
+            line["secondary"] = json.load(open(sec_file))
         print(json.dumps(line), flush=True)
     if world > 1:
         comm.close()

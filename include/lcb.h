@@ -98,8 +98,6 @@ typedef struct {
     int64_t side_taken;         /* ... results taken when the commit reached their seed */
     int64_t side_void;          /* ... jobs dropped: a mark of their view did not come true, superseded, or the round ended */
     int64_t side_failed;        /* ... jobs that ended without a result (stopped, or needed another kernel variant) */
-    int64_t device_commits;     /* results validated, conflict-checked and marked used by the device-side commit kernel (the host mirrors them) */
-    int64_t device_rounds;      /* ... rounds it committed from the first to the last seed */
     int64_t early_critical;     /* stops whose own jobs were computed while the host planned the rest */
     double kernel_busy_ms;      /* UNION of the hipEvent-timed kernel intervals of all streams: the time the GPU was busy with process kernels
                                    (kernel_ms is their SUM; the side lanes' kernels run beside the synchronous ones, so the sum can exceed the pass) */
@@ -253,9 +251,6 @@ typedef struct {
     int32_t sync_jobs;          /* 1: do not use the device's side lanes - every job of a stop's plan runs in one synchronous launch
                                    (the round-2 engine; for A/B runs and tests). With side lanes the results a stop cannot go on without
                                    are launched BEFORE the dry run that plans the rest of the stop's jobs (measured: profiles/r04/ab_first.txt) */
-    int32_t host_commit;        /* 1: the ordered commit of a round runs on the host only (for A/B runs and tests). Default: the clean prefix of
-                                   every round is validated, conflict-checked and marked used by lcb_commit_kernel on the device, chained behind
-                                   the round's kernels; the host mirrors those commits and takes over at the first seed that needs a new result */
     int32_t lazy_span;          /* a round spans at least this many phases: the phases beyond the (adaptive) size of its speculative launch get their
                                    phase-start results as background jobs against predicted views, planned while the commit works through the stops of the
                                    phases in front of them. Default 8; -1 = off (a round is exactly its speculative launch) */

@@ -6,7 +6,7 @@ results). Variants that differ in device options get a device of their own.
     python scripts/ab_engine.py --workload ecoli62 base hostc:host_commit=1 sync:sync_jobs=1 jobs512:max_jobs=512 lanes2:dev.side_lanes=2
 
 A variant is `name[:knob=value[,knob=value...]]`; knobs prefixed with `dev.` are fields of lcb_device_opts, the others of lcb_hooks.
-One line per variant: seeds/s, ms per pass (best of the passes), kernel time, launches, stops, jobs, side-lane and early / device-commit
+One line per variant: seeds/s, ms per pass (best of the passes), kernel time, launches, stops, jobs, side-lane, early-launch and lazy-tail
 counters, host time split."""
 import argparse
 import hashlib
@@ -67,10 +67,10 @@ def main():
                 print("%s: BLOCKS DIFFER from the first variant" % name, flush=True)
         dt, st = best
         print("%s: %.0f seeds/s, %.1f ms, kernel(sum) %.1f ms, launches %d, stops %d, jobs %d (used %d) | side batches %d jobs %d taken %d void %d failed %d | early %d | "
-              "device commits %d rounds %d | host ms: processor %.0f dry runs %.0f other %.0f" % (
+              "lazy seeds %d | host ms: processor %.0f dry runs %.0f other %.0f" % (
                   name, len(seeds) / dt, 1000 * dt, st["kernel_ms"], st["launches"], st["recompute_launches"], st["recomputed_seeds"], st["jobs_used"],
                   st["side_batches"], st["side_jobs"], st["side_taken"], st["side_void"], st["side_failed"], st.get("early_critical", 0),
-                  st["device_commits"], st["device_rounds"], st["process_ms"], st["plan_ms"], 1000 * dt - st["process_ms"] - st["plan_ms"]), flush=True)
+                  st.get("lazy_seeds", 0), st["process_ms"], st["plan_ms"], 1000 * dt - st["process_ms"] - st["plan_ms"]), flush=True)
     for d in devices.values():
         d.close()
 

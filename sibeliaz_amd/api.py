@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("recompute_launches", C.c_int64), ("recomputed_seeds", C.c_int64), ("conflict_launches", C.c_int64),
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
                 ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [
-                    (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "device_commits", "device_rounds", "early_critical")] + [
+                    (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "early_critical")] + [
                     ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64)]
 
 
@@ -56,15 +56,14 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("host_commit", C.c_int32),
-                ("lazy_span", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("lazy_span", C.c_int32)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.abi = ABI_VERSION
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "host_commit", "lazy_span")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "lazy_span")
 
 
 class DeviceOpts(C.Structure):

@@ -35,7 +35,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0; cfg.lazySpan = hooks->lazy_span;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span;
     }
     return cfg;
 }
@@ -236,7 +236,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.hostCommit = hooks->host_commit != 0; cfg.lazySpan = hooks->lazy_span;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -253,7 +253,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
             stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
             stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
-            stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
+            stats->early_critical = es.earlyCritical; stats->lazy_seeds = es.lazySeeds;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));

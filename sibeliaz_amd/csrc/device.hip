@@ -62,10 +62,9 @@ __global__ __launch_bounds__(64 * NW) void lcb_process_kernel(LcbTables T, LcbKP
     lcb_process_body<MODE, STATS, NW, PROF, SEG>(T, P, seeds, nSeeds, W, out, arena, arenaCap, fpArena, fpCap);
 }
 
-__global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive,
-                                                         const uint32_t* roundIdx, uint32_t* roundState)
+__global__ __launch_bounds__(256) void lcb_screen_kernel(LcbTables T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
 {
-    lcb_screen_body(T, seeds, nSeeds, out, live, nLive, roundIdx, roundState);
+    lcb_screen_body(T, seeds, nSeeds, out, live, nLive);
 }
 
 // Workspace slots start with an empty path set (and, in big mode, an empty vote table); the process
@@ -137,10 +136,6 @@ __global__ __launch_bounds__(256) void lcb_build_view_pages_kernel(uint32_t* liv
     }
 }
 
-// The device-resident ordered commit of a round's clean prefix (lcb_commit_body, lcb_kernel.h): one workgroup, chained behind every
-// launch of a round.
-#define LCB_NW_COMMIT 16
-__global__ __launch_bounds__(64 * LCB_NW_COMMIT) void lcb_commit_kernel(LcbCommitArgs A) { lcb_commit_body<LCB_NW_COMMIT>(A); }
 
 // STREAM triad a = b + s * c over 16-B words: the measured HBM rate the roofline figure is put beside (bench.py).
 __global__ __launch_bounds__(256) void lcb_triad_kernel(float4* a, const float4* b, const float4* c, float s, size_t n)
@@ -209,7 +204,6 @@ struct lcb_device_impl {
     LcbKParams KP{};
     LcbSegPlan plan;                             // host positions <-> (segment, g) of the device tables
     bool seg = false;                            // the SEG instantiations of the kernels run (several segments)
-    uint64_t* dChrBase = nullptr;                // [C] flat index of every chromosome's first position (commit kernel)
     std::vector<void*> owned;
     uint32_t* dUsed = nullptr;                   // the live bitmap
     size_t usedWords = 0;                        // its words (a multiple of the page size)
@@ -220,20 +214,6 @@ struct lcb_device_impl {
     hipStream_t ctlStream = nullptr;             // stop flags of the lanes are written from here
     uint32_t lanePoolPages = 0;                  // private pages per lane (fixed: the live bitmap cannot move while a lane is running)
     int64_t sideBatches = 0, sideJobs = 0, sideNoLane = 0, sideNoFit = 0;
-    // device-resident commit of a round (processRound): headers of the round's final results and their state per seed of the round,
-    // the list of the ranges the current round's commits marked, per-chromosome phase stamps, the commit kernel's state
-    struct RoundCtx {
-        bool active = false;                     // the current process() call is a round whose commit runs behind its launches
-        uint32_t n = 0, phase = 0;
-        LcbSeedOut* dOut = nullptr; uint32_t* dState = nullptr; size_t cap = 0;      // [cap] seeds of a round
-        uint32_t* dChrStamp = nullptr;
-        LcbFpOut* dDeltaList = nullptr; uint32_t* dDeltaCount = nullptr; uint32_t deltaCap = 1u << 16;      // ranges marked by the current round's commits
-        uint32_t* hIdx = nullptr;                // pinned: launch-local seed index -> index in the round
-        uint32_t* hState = nullptr;              // pinned: LCB_CS_* words
-        uint32_t* hCommitted = nullptr; size_t committedCap = 0;                   // pinned
-        bool arenaFresh = true;                  // the next launch of the round is its first: the arena allocators start at 0
-        int64_t rounds = 0, kernels = 0, abandoned = 0;
-    } rc;
     struct lcb_async_call* async = nullptr;      // the call begun with processBegin and not yet ended
     uint32_t* dCursor = nullptr;                 // [0] work tickets, [1] live seeds, [2..3] arena allocator (u64), [4..5] footprint allocator (u64)
     uint32_t* dLive = nullptr;                   // ticket -> seed index of a screened launch
@@ -371,18 +351,13 @@ struct lcb_device_impl {
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         W.dbg = (hDbg && grid <= dbgSlots) ? hDbg : nullptr;
         W.abort = nullptr;
-        // a launch of a round: final results are also kept on the device, for the commit kernel chained behind the launch
-        const bool round = rc.active && wait;
-        W.roundIdx = round ? rc.hIdx : nullptr; W.roundOut = round ? rc.dOut : nullptr; W.roundState = round ? rc.dState : nullptr;
         if (W.dbg) memset(hDbg, 0, (size_t)grid * 16 * sizeof(uint32_t));
         if (W.ctr && !stats) memset(hCtr, 0, (size_t)m * sizeof(LcbSeedCtr));   // screened-out seeds write no profile
         if (watchdogS > 0 || screen) for (uint32_t i = 0; i < m; i++) hOut[i].status = LCB_ST_PENDING;   // unfinished seeds can be named (and a header nobody wrote is noticed)
-        // (the launches of a round share the result arenas: the commit kernel reads the results of all of them in place)
-        HIP_CHECK(hipMemsetAsync(dCursor, 0, round && !rc.arenaFresh ? 8 : 32, stream));
-        if (round) rc.arenaFresh = false;
+        HIP_CHECK(hipMemsetAsync(dCursor, 0, 32, stream));
         HIP_CHECK(hipEventRecord(evA, stream));
         if (screen) {
-            hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1, W.roundIdx, W.roundState);
+            hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
             HIP_CHECK(hipGetLastError());
         }
 #define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))
@@ -398,19 +373,7 @@ struct lcb_device_impl {
 #undef LCB_LAUNCH_SEG
 #undef LCB_LAUNCH
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(evB, stream));       // [evA, evB]: screening + process kernel (the commit kernel behind them is not part of kernel_ms)
-        if (round) {
-            // the ordered commit of the round goes on as far as the results reach, behind the kernels that produced them
-            LcbCommitArgs A;
-            A.chrBase = dChrBase; A.used = dUsed; A.chrStamp = rc.dChrStamp;
-            A.roundState = rc.dState; A.roundOut = rc.dOut; A.arena = hArena; A.fpArena = hFp;
-            A.n = rc.n; A.phase = rc.phase; A.nPos = T.nPos;
-            A.state = rc.hState; A.committed = rc.hCommitted; A.deltaList = rc.dDeltaList; A.deltaCount = rc.dDeltaCount; A.deltaCap = rc.deltaCap;
-            A.pageShift = 10; while ((T.nPos >> A.pageShift) >= (uint64_t)LCB_COMMIT_PAGES) A.pageShift++;
-            hipLaunchKernelGGL(lcb_commit_kernel, dim3(1), dim3(64 * LCB_NW_COMMIT), 0, stream, A);
-            HIP_CHECK(hipGetLastError());
-            rc.kernels++;
-        }
+        HIP_CHECK(hipEventRecord(evB, stream));       // [evA, evB]: screening + process kernel
         if (screen) {      // the host only looks at the seeds that survived the screening
             HIP_CHECK(hipMemcpyAsync(hLive + batchCap, dCursor + 1, 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(hLive, dLive, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
@@ -528,7 +491,6 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             for (size_t c = 0; c < lh.size(); c++) lh[c] = uint2{plan.chrLo[c], plan.chrHi[c]};
             d->T.chrLoHi = d->upload(lh.data(), lh.size());
             d->T.segBase = d->upload(plan.segDev.data(), plan.segDev.size());
-            d->dChrBase = d->upload(plan.chrDev.data(), plan.chrDev.size());
         }
         d->T.posId = d->uploadSeg(g->posId.data(), plan);
         d->T.posPos = d->uploadSeg(g->posPos.data(), plan);
@@ -680,8 +642,6 @@ void lcb_device_destroy_impl(lcb_device* h)
             for (void* q : {(void*)L.hSeeds, (void*)L.hOut, (void*)L.hArena, (void*)L.hFp, (void*)L.hList, (void*)L.hCtl}) if (q) (void)hipHostFree(q);
             for (void* q : {(void*)L.dCtl, (void*)L.views.tab, (void*)L.views.dEntries, (void*)L.views.dVersions, (void*)L.views.dPieces, (void*)L.wide.base, (void*)L.big.base}) if (q) (void)hipFree(q);
         }
-        for (void* q : {(void*)d->rc.dOut, (void*)d->rc.dState, (void*)d->rc.dChrStamp, (void*)d->rc.dDeltaList, (void*)d->rc.dDeltaCount}) if (q) (void)hipFree(q);
-        for (void* q : {(void*)d->rc.hIdx, (void*)d->rc.hState, (void*)d->rc.hCommitted}) if (q) (void)hipHostFree(q);
         if (d->ctlStream) (void)hipStreamDestroy(d->ctlStream);
         if (d->views.tab) (void)hipFree(d->views.tab);
         if (d->views.dEntries) (void)hipFree(d->views.dEntries);
@@ -958,7 +918,6 @@ void fillSeeds(lcb_device_impl* d, const ProcAcc& A, const std::vector<int64_t>&
         const int64_t s = list[at + i];
         d->hSeeds[i].vid = A.seeds[s].vid; d->hSeeds[i].ch = A.seeds[s].ch; d->hSeeds[i].view = A.view ? A.view[s] : 0u; d->hSeeds[i].pad = 0;
     }
-    if (d->rc.active) for (uint32_t i = 0; i < m; i++) d->rc.hIdx[i] = (uint32_t)list[at + i];
 }
 
 // Takes the results of one finished launch out of the host buffers; seeds that overflowed go to the next variant's list.
@@ -1054,10 +1013,6 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
-            // (a round whose launches fill the shared result arenas: the arenas are emptied between launches again - from the NEXT batch on,
-            // which would otherwise find the allocator past the end and compute its seeds for nothing -, so the commit kernel can no longer
-            // find earlier results in place: what it has committed so far stands, the host commits the rest)
-            if (d->rc.active && (A.arenaOvf || hugeOverflow)) { d->rc.active = false; d->rc.abandoned++; }
         }
         if (A.growCompactPath) {
             // The compact path set starts small on purpose (the sets of all slots together stay cache-resident: 1280 x 128 KB)
@@ -1073,7 +1028,7 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->allocArena(d->arenaCap * 4);
             d->arenaGrown++;
         } else
-        if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) { if (d->rc.active) { d->rc.active = false; d->rc.abandoned++; } d->allocArena(d->arenaCap * 4); }   // not even one batch fitted
+        if (!A.todo[mode].empty() && mode < 3 && A.todo[mode].size() == list.size()) d->allocArena(d->arenaCap * 4);   // not even one batch fitted
         A.arenaOvf = 0;
         if (hugeOverflow) {
             // (statuses are per seed; growing everything keeps the logic simple and this path is rare)
@@ -1196,60 +1151,6 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
     d->wantFp = false;
 }
 
-// ---- device-resident ordered commit of a round (LcbProcessor::processRound) ---------------------------------------------------
-// process() of the n seeds of a round against the live state, with lcb_commit_kernel chained behind every launch of the call: the
-// kernels keep the header of every final result on the device under the seed's index in the round, instances and footprints stay in
-// the launch arenas (not reset between the launches of a round), and the commit kernel goes on - phase by phase, in seed order - as
-// far as final results reach. The host reads its state words and the committed list after the last launch.
-bool lcb_device_process_round_impl(lcb_device* h, const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst,
-                                   std::vector<uint64_t>& fpOffsets, std::vector<lcb_fp>& fpOut, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
-{
-    lcb_device_impl* d = h->impl;
-    if (d->stats || n <= 0 || phase <= 0 || n > (int64_t)(1u << 30) || d->hDbg || d->seedTrace || d->forceProf) return false;
-    d->use();
-    auto& R = d->rc;
-    static_assert(sizeof(lcb_instance) == 16 && sizeof(LcbFpOut) == 16, "layouts the commit kernel reads");
-    if ((size_t)n > R.cap) {
-        for (void* q : {(void*)R.dOut, (void*)R.dState}) if (q) HIP_CHECK(hipFree(q));
-        R.cap = std::max<size_t>((size_t)n, d->batchCap);
-        HIP_CHECK(hipMalloc((void**)&R.dOut, R.cap * sizeof(LcbSeedOut)));
-        HIP_CHECK(hipMalloc((void**)&R.dState, R.cap * 4));
-    }
-    if ((size_t)n > R.committedCap) {
-        if (R.hCommitted) HIP_CHECK(hipHostFree(R.hCommitted));
-        R.committedCap = std::max<size_t>((size_t)n, d->batchCap);
-        HIP_CHECK(hipHostMalloc((void**)&R.hCommitted, R.committedCap * 4, hipHostMallocDefault));
-    }
-    if (!R.dChrStamp) {
-        HIP_CHECK(hipMalloc((void**)&R.dChrStamp, ((size_t)d->g->nChr() + 1) * 4));
-        HIP_CHECK(hipMalloc((void**)&R.dDeltaList, (size_t)R.deltaCap * sizeof(LcbFpOut)));
-        HIP_CHECK(hipMalloc((void**)&R.dDeltaCount, 4));
-        HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
-        HIP_CHECK(hipHostMalloc((void**)&R.hIdx, (size_t)d->batchCap * 4, hipHostMallocDefault));
-        HIP_CHECK(hipHostMalloc((void**)&R.hState, 64, hipHostMallocDefault));
-        memset(R.hState, 0, 64);
-    }
-    HIP_CHECK(hipMemsetAsync(R.dDeltaCount, 0, 4, d->stream));
-    HIP_CHECK(hipMemsetAsync(R.dState, 0, (size_t)n * 4, d->stream));
-    HIP_CHECK(hipMemsetAsync(R.dChrStamp, 0, ((size_t)d->g->nChr() + 1) * 4, d->stream));
-    memset(R.hState, 0, 64);                     // (the stream is idle: every earlier call has been waited for)
-    R.n = (uint32_t)n; R.phase = (uint32_t)phase; R.arenaFresh = true; R.active = true;
-    inst.clear();
-    d->wantFp = true;
-    ProcAcc A;
-    accInit(d, A, seeds, n, nullptr, nullptr, nullptr, nullptr, true);
-    try { runToCompletion(d, A); } catch (...) { d->wantFp = false; R.active = false; throw; }
-    accLayout(A, offsets, inst, &fpOffsets, &fpOut);
-    d->wantFp = false;
-    R.active = false;
-    const uint32_t next = R.hState[LCB_CS_NEXT], nCom = R.hState[LCB_CS_NCOMMITTED];
-    stopKind = (int)R.hState[LCB_CS_STOPKIND]; stopAt = R.hState[LCB_CS_STOPAT];
-    if (nCom > (uint32_t)n || next > (uint32_t)n || stopKind < 0 || stopKind > 3 || stopKind == 1 || (stopKind && stopAt >= (uint32_t)n)) throw LcbError("device commit: inconsistent state");
-    committed.assign(R.hCommitted, R.hCommitted + nCom);
-    if (stopKind == 0 && next < (uint32_t)n) { stopKind = 3; stopAt = next; }     // the commit did not get further (the round's arenas had to be reset): the host goes on from this phase
-    R.rounds++;
-    return true;
-}
 
 // ---- side lanes: asynchronous job batches ---------------------------------------------------------------------------------
 // A batch = the speculative jobs of one stop of the ordered commit (engine.cpp). Its jobs run in the wide variant (16 wavefronts
@@ -1334,7 +1235,7 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
         W.base = w.base; W.slotBytes = w.slotBytes; W.pathCap = w.pathCap; W.bodyCap = w.bodyCap; W.bestCap = w.bestCap; W.instCap = w.instCap; W.voteCap = w.voteCap;
         W.cursor = L.dCtl + ticketWord; W.cursorBase = 0; W.live = list; W.nLive = L.dCtl + countWord;
         W.arenaCursor = (unsigned long long*)(L.dCtl + 2); W.arenaBase = 0; W.fpCursor = (unsigned long long*)(L.dCtl + 4); W.fpBase = 0;
-        W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8; W.roundIdx = nullptr; W.roundOut = nullptr; W.roundState = nullptr;
+        W.ctr = nullptr; W.dbg = nullptr; W.abort = L.dCtl + 8;
         const uint32_t grid = m < w.nSlots ? m : w.nSlots;
         HIP_CHECK(hipEventRecord(e0, q));
         if (w.mode == 2 && d->seg) hipLaunchKernelGGL((lcb_process_kernel<2, false, LCB_NW_BIG, false, true>), dim3(grid), dim3(64 * LCB_NW_BIG), 0, q, T, d->KP, L.hSeeds, (uint32_t)n, W, L.hOut, L.hArena, L.arenaCap, L.hFp, L.arenaCap);
@@ -1426,11 +1327,6 @@ struct DeviceProcessor : LcbProcessor {
     }
     int sidePoll(int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp) override { return lcb_device_side_poll_impl(dev, lane, k, wait, inst, fp); }
     void sideRelease(int lane) override { lcb_device_side_release_impl(dev, lane); }
-    bool processRound(const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
-                      std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
-    {
-        return lcb_device_process_round_impl(dev, seeds, n, phase, off, inst, fpOff, fp, committed, stopAt, stopKind);
-    }
 };
 
 }  // namespace
@@ -1446,10 +1342,8 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
     lcb_engine_run(g, p, seeds, nSeeds, proc, cfg, blocks, &es);
     lcb_device_drain_lanes(dev->impl);      // (the last batches are released but not retired: their kernel time belongs to this pass)
     if (getenv("LCB_VERBOSE"))
-        fprintf(stderr, "lcb engine: %.0f ms = processor %.0f + dry runs %.0f (marks to the device %.0f, simulation %.0f; %lld views) + rest %.0f (round setup %.0f, validation %.0f, commit %.0f, marks to the device %.0f, mirror of device commits %.0f) | "
-                        "device-resident commit: %lld rounds, %lld kernels, %lld given up\n", es.wallMs, es.processMs, es.planMs, es.sectionMs[LCB_SEC_PLAN_FLUSH], es.sectionMs[LCB_SEC_PLAN_SIM], (long long)es.viewsBuilt, es.wallMs - es.processMs - es.planMs, es.sectionMs[LCB_SEC_SETUP],
-                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_MIRROR], (long long)dev->impl->rc.rounds, (long long)dev->impl->rc.kernels,
-                (long long)dev->impl->rc.abandoned);
+        fprintf(stderr, "lcb engine: %.0f ms = processor %.0f + dry runs %.0f (marks to the device %.0f, simulation %.0f; %lld views) + rest %.0f (round setup %.0f, validation %.0f, commit %.0f, marks to the device %.0f)\n", es.wallMs, es.processMs, es.planMs, es.sectionMs[LCB_SEC_PLAN_FLUSH], es.sectionMs[LCB_SEC_PLAN_SIM], (long long)es.viewsBuilt, es.wallMs - es.processMs - es.planMs, es.sectionMs[LCB_SEC_SETUP],
+                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH]);
     if (stats) {
         double ms = 0, busy = 0, side = 0; int64_t l = 0;
         lcb_device_kernel_time_impl(dev, &ms, &l, &busy, &side);
@@ -1462,7 +1356,7 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
-        stats->device_commits = es.deviceCommits; stats->device_rounds = es.deviceRounds; stats->early_critical = es.earlyCritical;
+        stats->early_critical = es.earlyCritical;
         stats->lazy_seeds = es.lazySeeds;
     }
 }

@@ -218,10 +218,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     };
     std::vector<RangeSet> epochMarks;              // epochMarks[e]: ranges marked after launch e of this round and before launch e+1
     double lastInvalid = 1.0;
-    auto takeMarks = [&](bool alreadyInProcessor = false) {
+    auto takeMarks = [&]() {
         for (size_t i = 0; i + 1 < com.marks.size(); i += 2) {
             epochMarks.back().add(com.marks[i], com.marks[i + 1]);
-            if (!alreadyInProcessor) { pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]); }
+            pending.push_back(com.marks[i]); pending.push_back(com.marks[i + 1]);
         }
         com.marks.clear();
     };
@@ -244,9 +244,6 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     std::vector<int32_t> liveIdx;
     auto liveFrom = [&](int64_t i) { return (size_t)(std::lower_bound(liveIdx.begin(), liveIdx.end(), (int32_t)i) - liveIdx.begin()); };
 
-    // ---- device-resident commit of a round's clean prefix (processRound of the processor), one rank only
-    const bool useDevCommit = world == 1 && !cfg.hostCommit && !cfg.countEvents && !(cfg.exchangeAlways && cfg.allgather);
-    std::vector<uint32_t> dcCommitted;
     // ---- asynchronous job batches (side lanes of the processor). With several ranks (`multi`: every launch is dealt to the ranks) a
     // batch is dealt like a launch - job k of it runs on a lane of rank k % world - and results travel through exchangeSide below.
     const bool multi = world > 1 || (cfg.exchangeAlways && cfg.allgather);
@@ -378,16 +375,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         epochMarks.assign(1, RangeSet());
         // ---- speculative launch of the whole round (dealt to the ranks; on one rank with the ordered commit of the round's clean
         // prefix chained behind its kernels where the processor can do that)
-        bool devCommit = false;
-        uint32_t dcStopAt = 0; int dcStopKind = 0;
-        if (useDevCommit) {
-            const auto tp = std::chrono::steady_clock::now();
-            dcCommitted.clear();
-            devCommit = proc.processRound(seeds + pos, nEager, phase, round.off, round.inst, round.fpOff, round.fp, dcCommitted, dcStopAt, dcStopKind);
-            st.processMs += msSince(tp);
-            if (devCommit) launchOrdinal++;
-        }
-        if (!devCommit) processSharded(seeds + pos, nullptr, nEager, round, (uint64_t)pos);
+        processSharded(seeds + pos, nullptr, nEager, round, (uint64_t)pos);
         const auto tSetup = std::chrono::steady_clock::now();
         if (nEager < nRound) {                      // the lazy seeds: no result, nothing known
             round.off.resize((size_t)nRound + 1, round.off[(size_t)nEager]); round.fpOff.resize((size_t)nRound + 1, round.fpOff[(size_t)nEager]);
@@ -812,40 +800,16 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             }
         };
 
-        // ---- what the processor committed itself: block ids, BlockInstances and the host's copy of the bitmap follow
-        int64_t donePh = 0;                     // phases [0, donePh) of the round are committed
-        int64_t resumeAt = -1;                  // >= 0: the phase at donePh is validated and committed up to (not including) this seed, which conflicts
-        if (devCommit) {
-            const auto tMirror = std::chrono::steady_clock::now();
-            int64_t curPh = -1;
-            for (uint32_t i : dcCommitted) {
-                if ((int64_t)i >= nRound || round.off[i + 1] - round.off[i] <= 1) throw LcbError("engine: the processor committed a seed that has no block");
-                const int64_t ph = (int64_t)i / phase;
-                if (ph != curPh) { if (curPh >= 0) com.endPhase(); curPh = ph; }
-                com.finalize(round.inst.data() + round.off[i], round.off[i + 1] - round.off[i]);
-                takeMarks(true);
-                st.deviceCommits++;
-            }
-            if (dcStopKind == 0) { donePh = nEager; if (curPh >= 0) com.endPhase(); if (nEager == nRound) st.deviceRounds++; }
-            else {
-                donePh = ((int64_t)dcStopAt / phase) * phase;
-                if (curPh >= 0 && curPh * phase < donePh) com.endPhase();                 // (a stop at a phase start: the previous phase is closed)
-                if (dcStopKind == 2) resumeAt = (int64_t)dcStopAt;                          // ... inside a phase: its invalidChr_ stays
-            }
-            if (cfg.progress) for (int64_t i = ((pos + portion - 1) / portion) * portion; i < pos + donePh; i += portion) std::cout << '.' << std::flush;
-            st.sectionMs[LCB_SEC_MIRROR] += msSince(tMirror);
-        }
-        frozenTo = donePh;
+        frozenTo = 0;
 
         // ---- walk the round's phases in order -----------------------------------------------------------------------
-        for (int64_t ph = donePh; ph < nRound; ph += phase) {
+        for (int64_t ph = 0; ph < nRound; ph += phase) {
             const int64_t n = std::min<int64_t>(phase, nRound - ph);
-            const bool resumed = resumeAt >= 0 && ph == donePh;       // the device validated this phase and committed its seeds before resumeAt
             // (a) exact phase-start results for every seed of the phase
-            const size_t lv0 = liveFrom(resumed ? resumeAt : ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
+            const size_t lv0 = liveFrom(ph), lv1 = liveFrom(ph + n);   // the seeds of the phase that read or commit anything
             double inStop = st.processMs + st.planMs;       // (what the stops inside a section cost is accounted there)
             auto tSec = std::chrono::steady_clock::now();
-            for (; !resumed;) {
+            for (;;) {
                 bool all = true;
                 for (size_t q = lv0; q < lv1 && all; q++) {
                     const int64_t i = liveIdx[q];
@@ -869,7 +833,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             st.sectionMs[LCB_SEC_VALIDATE] += msSince(tSec) - (st.processMs + st.planMs - inStop);
             inStop = st.processMs + st.planMs; tSec = std::chrono::steady_clock::now();
             // (b) ordered commit (blocksfinder.h:372-414)
-            if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;   // (a resumed phase prints its dots here)
+            if (cfg.progress) for (int64_t i = ((pos + ph + portion - 1) / portion) * portion; i < pos + ph + n; i += portion) std::cout << '.' << std::flush;
             // the phase-start result of every seed is exact now: its events are the ones the reference's Process() call has
             if (cfg.countEvents) for (int64_t i = ph; i < ph + n; i++) addCounters(st.events, eIdx[(size_t)i] >= 0 ? cands[(size_t)eIdx[(size_t)i]].ctr : round.ctr[(size_t)i]);
             for (size_t q = lv0; q < lv1; q++) {

@@ -39,9 +39,6 @@ int lcb_device_side_lanes_impl(lcb_device* d);
 int lcb_device_side_begin_impl(lcb_device* d, const lcb_seed* seeds, const uint32_t* view, int64_t n, int nViews, const LcbViewMark* marks, int64_t nMarks);
 int lcb_device_side_poll_impl(lcb_device* d, int lane, int64_t k, bool wait, std::vector<lcb_instance>& inst, std::vector<lcb_fp>& fp);
 void lcb_device_side_release_impl(lcb_device* d, int lane);
-// a round with the device-resident ordered commit of its clean prefix chained behind its launches (LcbProcessor::processRound)
-bool lcb_device_process_round_impl(lcb_device* d, const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& offsets, std::vector<lcb_instance>& inst,
-                                   std::vector<uint64_t>& fpOffsets, std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind);
 double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);

@@ -123,21 +123,6 @@ struct LcbProcessor {
     // Nobody will ask for the batch's results any more: its jobs stop at their next step, the lane is free once they have.
     virtual void sideRelease(int lane) { (void)lane; }
 
-    // ---- device-resident ordered commit, optional. processRound = process() of ALL the seeds of a round against
-    // the live state (seed i of the call is seed i of the round; phases of `phase` seeds) with the thread-0 section of the reference
-    // (blocksfinder.h:372-414) for the round's clean prefix done where the results are: phase by phase, phase-start results that are
-    // still exact (no mark of this round inside their footprint) and pass the weak conflict check are committed - marked used in the
-    // processor's OWN state - until the first seed that needs a new computation. committed: the indices it committed, in order;
-    // stopKind 0: the whole round is committed; 1: a phase-start result of the phase that begins at seed stopAt is void; 2: seed
-    // stopAt conflicts (its phase is committed up to it); 3: the processor got no further than the phase that begins at stopAt
-    // (nothing is wrong with it: the device hands a phase over when a footprint lies near one of the round's marks and it would have
-    // to look closer). The engine assigns block ids, mirrors the marks and goes on from the stop.
-    // false: not supported (nothing was done; the engine calls process() and commits on the host).
-    virtual bool processRound(const lcb_seed* seeds, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
-                              std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind)
-    {
-        (void)seeds; (void)n; (void)phase; (void)off; (void)inst; (void)fpOff; (void)fp; (void)committed; (void)stopAt; (void)stopKind; return false;
-    }
 };
 
 // Side lanes for processors that have none of their own (the test stand-ins: callback, wavefront emulator, oracle model): a
@@ -204,7 +189,6 @@ struct LcbEngineConfig {
     int predictF = 0;         // 0 = default (3); 1 nothing, 2 free instances of E, 3 stale F else as 2
     bool countEvents = false; // sum the event counters of exactly the results the reference computes (stats-mode processor, one rank)
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
-    bool hostCommit = false;  // never use the processor's commitRound: the ordered commit of a round runs on the host only (A/B runs, tests)
     int lazySpan = 0;         // a round spans at least this many phases: those beyond the adaptive launch size get their phase-start results as jobs (0 = 8, -1 = off)
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
 };
@@ -213,7 +197,6 @@ enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch 
        LCB_SEC_VALIDATE,       // phase-start validation of footprints against the marks since a result's launch
        LCB_SEC_COMMIT,         // weak conflict check, Finalize, marks into the epochs
        LCB_SEC_FLUSH,          // marks handed to the processor (LcbProcessor::mark)
-       LCB_SEC_MIRROR,         // block ids / BlockInstances / host bitmap of what the processor committed itself
        LCB_SEC_PLAN_FLUSH,     // inside the dry runs (planMs): marks handed to the processor before a plan ...
        LCB_SEC_PLAN_SIM };     // ... and the simulation of the rest of the round
 
@@ -224,8 +207,6 @@ struct LcbEngineStats {
     int64_t jobsUsed = 0;         // ... results that were committed from (exactly validated)
     int64_t viewsBuilt = 0;       // predicted `used` views materialised
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
-    int64_t deviceCommits = 0;    // results committed by the processor itself (commitRound), and ...
-    int64_t deviceRounds = 0;     // ... rounds it committed completely
     int64_t earlyCritical = 0;    // stops whose own jobs ran while the rest was planned
     int64_t lazySeeds = 0;        // seeds of the lazy tails of the rounds (no speculative launch: their phase-start results are jobs)
     int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)

@@ -159,13 +159,7 @@ struct LcbWork {               // per-workgroup global-memory workspace slots + 
     LcbSeedCtr* ctr;           // per-seed counters (stats / instrumented variants), or null
     uint32_t* dbg;             // optional flight recorder: 16 words per workgroup (host watchdog prints them), or null
     const uint32_t* abort;     // asynchronous job batches (device.hip, side lanes): when the word becomes non-zero the seeds give up at their next vote
-    // Launches of a ROUND (device.hip, lcb_commit_body below): the header of a seed that ended with a final result is also kept on the
-    // device under the seed's index in the round - where the commit kernel that is chained behind the launch reads it.
-    const uint32_t* roundIdx;  // launch-local seed index -> index in the round, or null: not a round launch
-    LcbSeedOut* roundOut;      // [seeds of the round] headers of final results (arenaOff / fpOff index the launch's arenas, which a round never resets)
-    uint32_t* roundState;      // [seeds of the round] LCB_RS_*
 };
-enum { LCB_RS_NONE = 0, LCB_RS_DEAD = 1, LCB_RS_DONE = 2 };   // no final result yet / Path::Init finds nothing: empty result, no read / result in roundOut
 
 // ---- workspace layout (shared by host and device) -------------------------------------------
 struct LcbSlotLayout {
@@ -1657,7 +1651,6 @@ struct LcbLaunchArgs {
     const uint32_t* live;
     uint32_t cursorBase, nSeeds;
     const uint32_t* usedTab;       // page table of the `used` view of the seed wave 0 is working on (read by the helpers at each vote)
-    const uint32_t* roundIdx; LcbSeedOut* roundOut; uint32_t* roundState;
 };
 
 // NW = wavefronts per workgroup: wave 0 runs the per-seed algorithm, waves 1..NW-1 are vote helpers.
@@ -1697,7 +1690,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
         sArgs.seeds = seeds; sArgs.out = out; sArgs.ctr = W.ctr; sArgs.arena = arena; sArgs.fpArena = fpArena; sArgs.arenaCap = arenaCap; sArgs.fpCap = fpCap;
         sArgs.arenaBase = W.arenaBase; sArgs.fpBase = W.fpBase; sArgs.arenaCursor = W.arenaCursor; sArgs.fpCursor = W.fpCursor;
         sArgs.cursor = W.cursor; sArgs.cursorBase = W.cursorBase; sArgs.live = W.live; sArgs.nSeeds = W.live ? *W.nLive : nSeeds;
-        sArgs.roundIdx = W.roundIdx; sArgs.roundOut = W.roundOut; sArgs.roundState = W.roundState;
     }
 
     LcbStateT<MODE, SEG> S;
@@ -1876,12 +1868,6 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
             LcbSeedOut* o = sArgs.out + s;
             if (S.abort) __hip_atomic_store(&o->status, (uint32_t)S.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             else o->status = S.status;
-            if (sArgs.roundIdx && S.status == LCB_ST_OK) {          // a round launch: the final result is known to the commit kernel behind it
-                const uint32_t r = sArgs.roundIdx[s];
-                LcbSeedOut* q = sArgs.roundOut + r;
-                q->nInst = n; q->status = LCB_ST_OK; q->bestScore = bestScore; q->arenaOff = off; q->fpOff = fpo; q->nFp = nfp; q->poolInst = S.endInst;
-                sArgs.roundState[r] = LCB_RS_DONE;
-            }
             if ((STATS || PROF) && sArgs.ctr) {
                 uint64_t* k = sArgs.ctr[s].c;
                 if (STATS) { k[0] = c0; k[1] = c1; k[2] = c2; k[3] = c3; k[4] = n; k[5] = c4; k[6] = c5; k[7] = 1; }
@@ -1905,8 +1891,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
 // Process() returns nothing and reads no bit as 0: its header is final here. Later rounds consist almost entirely of such
 // seeds (their neighbourhood is covered by committed blocks); the others are queued for the process kernel, and the host
 // reads the headers of the queued seeds only. One thread per seed.
-__device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive,
-                                       const uint32_t* roundIdx, uint32_t* roundState)
+__device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds, uint32_t nSeeds, LcbSeedOut* out, uint32_t* live, uint32_t* nLive)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     bool alive = false;
@@ -1925,7 +1910,6 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
             alive = !isUsed && (int32_t)(positive ? T.posCh[f] : T.posRevCh[f]) == sd.ch;
         }
         (void)out;      // a dead seed needs no header: the host looks at the live list only (its result is empty by definition)
-        if (!alive && roundIdx) roundState[roundIdx[s]] = LCB_RS_DEAD;     // ... and the commit kernel of a round passes over it
     }
     // compact the live seeds in seed order within the wave (heavy seeds come first in the sorted seed list)
     const unsigned long long m = __ballot(alive);
@@ -1935,211 +1919,6 @@ __device__ inline void lcb_screen_body(const LcbTables& T, const LcbKSeed* seeds
         if (lane == 0) base = atomicAdd(nLive, (uint32_t)__popcll(m));
         base = lcb_rfl(base);
         if (alive) live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = s;
-    }
-}
-
-// ---- device-resident ordered commit ----------------------------------------------------
-// The thread-0 section of ProcessVertex::operator() (blocksfinder.h:372-414) with Finalize's MarkUsed (blocksfinder.h:312-332) for
-// the clean prefix of a round, where the results are: the kernel is chained behind every launch of a round on the launch's stream
-// (no host synchronisation in between) and walks the round's seeds in order, phase by phase, over the headers the process kernels
-// left in roundOut and the instances / footprints in the launch arenas -
-//   (0) a phase is entered once every seed of it has a final result (a seed that overflowed its kernel variant gets its result from a
-//       later launch of the round: the kernel returns and the invocation behind that launch goes on from the same phase);
-//   (a) phase start: the phase-start result of every seed of the phase must still be exact: no bit inside its footprint has been
-//       marked since the round was launched. The kernel decides that with a coarse summary of the round's marks in LDS (one bit per
-//       2^pageShift positions): a footprint interval none of whose pages holds a mark contains no marked bit. Where an interval
-//       touches a marked page the kernel does NOT look closer - it hands the round over to the host at that phase (stop kind 3), whose
-//       range sets answer the exact question in a microsecond; on the device the exact test of one interval is hundreds of dependent
-//       loads (measured: 14-48 ms per round of config 3, more than the round's process kernels);
-//   (b) ordered commit: a result of more than one instance whose instances touch no used position on the chromosomes committed to
-//       earlier in this phase (the weak check, blocksfinder.h:377-398) is finalised: its [Front, Back) ranges are marked in the live
-//       bitmap (and noted in the list of the round's marks) and the seed is appended to the committed list -
-// and stops for good at the first seed that needs a new computation (a conflict: blocksfinder.h:406) or a closer look (kind 3).
-// The host reads the state words and the committed list, assigns the block ids / BlockInstances of the committed seeds
-// (blocksfinder.h:314-329), mirrors the marks in its own copy of the bitmap and goes on from the stop with its planner.
-// ONE workgroup: phases are sequential by definition (a phase's validation needs the marks of the phases before it); inside a phase
-// the validation is spread over the wavefronts (lanes = footprint intervals) and the commit is lane-parallel over instances and words.
-// The summary of the round's marks is rebuilt from the list of their ranges at the start of an invocation.
-enum { LCB_CS_NEXT = 0,        // first seed of the next phase to commit (everything before it is committed or passed over)
-       LCB_CS_NCOMMITTED,      // entries of the committed list
-       LCB_CS_STOPKIND,        // 0 none so far, 2 seed STOPAT conflicts (its phase is committed up to it), 3 a footprint of the phase at STOPAT lies near a mark: the host decides
-       LCB_CS_STOPAT,
-       LCB_CS_MARKED,          // something was committed in this round
-       LCB_CS_WORDS = 8 };
-struct LcbCommitArgs {
-    const uint64_t* chrBase;       // [nChr] flat position of the chromosome's first occurrence
-    uint32_t* used;                // the live bitmap (marked here)
-    uint32_t* chrStamp;            // [nChr]: phase ordinal + 1 of the last commit to the chromosome (invalidChr_ of that phase); cleared per round
-    const uint32_t* roundState;    // [n] LCB_RS_* per seed of the round
-    const LcbSeedOut* roundOut;    // [n] headers of the final results
-    const uint4* arena;            // (chr, front idx, back idx, strand)
-    const LcbFpOut* fpArena;       // footprint intervals [lo, hi] over flat positions
-    uint32_t n, phase;             // seeds of the round, seeds per phase (256)
-    uint64_t nPos;                 // positions of the bitmap
-    uint32_t* state;               // LCB_CS_* (host-visible; one thread reads and writes it)
-    uint32_t* committed;           // out (host-visible): round indices of the committed seeds, in order
-    LcbFpOut* deltaList;           // the ranges [lo, hi) this round's commits have marked so far (the summary of a later invocation is rebuilt from them) ...
-    uint32_t* deltaCount;          // ... their number (device word; beyond deltaCap the list is incomplete: every page then counts as marked)
-    uint32_t deltaCap;
-    uint32_t pageShift;            // the coarse LDS summary of the round's marks has one bit per 2^pageShift positions (nPos >> pageShift <= LCB_COMMIT_PAGES)
-};
-#define LCB_COMMIT_PAGES 32768u    // bits of the summary (4 KB of LDS)
-
-// any set bit of `bits` in [a, b)? (bitmap words are read past the L1: other wavefronts mark them with atomics)
-__device__ inline bool lcb_bits_any(const uint32_t* bits, uint64_t a, uint64_t b)
-{
-    if (a >= b) return false;
-    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
-    const uint32_t ma = 0xFFFFFFFFu << ((uint32_t)a & 31), mb = 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
-    for (uint32_t w = wa; w <= wb; w++) {
-        uint32_t v = __hip_atomic_load(bits + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == wa) v &= ma;
-        if (w == wb) v &= mb;
-        if (v) return true;
-    }
-    return false;
-}
-
-__device__ inline void lcb_bits_set(uint32_t* bits, uint64_t a, uint64_t b)
-{
-    if (a >= b) return;
-    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
-    for (uint32_t w = wa; w <= wb; w++) {
-        uint32_t m = 0xFFFFFFFFu;
-        if (w == wa) m &= 0xFFFFFFFFu << ((uint32_t)a & 31);
-        if (w == wb) m &= 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
-        atomicOr(bits + w, m);
-    }
-}
-
-// any set bit of `bits` in [a, b)? For ranges of thousands of positions: the words are requested eight at a time (independent loads,
-// one latency per batch instead of one per word) and read past the L1 like lcb_bits_any.
-__device__ inline bool lcb_bits_any_long(const uint32_t* bits, uint64_t a, uint64_t b)
-{
-    if (a >= b) return false;
-    const uint32_t wa = (uint32_t)(a >> 5), wb = (uint32_t)((b - 1) >> 5);
-    const uint32_t ma = 0xFFFFFFFFu << ((uint32_t)a & 31), mb = 0xFFFFFFFFu >> (31 - ((uint32_t)(b - 1) & 31));
-    for (uint32_t w = wa; w <= wb; w += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) v[k] = w + k <= wb ? __hip_atomic_load(bits + w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (w == wa) v[0] &= ma;
-        if (wb - w < 8) {
-            const uint32_t last = wb - w;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) if (k == last) v[k] &= mb;
-        }
-        if (v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | v[7]) return true;
-    }
-    return false;
-}
-
-template <int NW>
-__device__ inline void lcb_commit_body(const LcbCommitArgs& A)
-{
-    __shared__ uint32_t sFlag[8];          // [0] phase flags (bit 0: a seed without a final result, 1: a seed with a result, 2: a seed with a block), [1] void phase-start result seen, [2] marked, [3] stop kind, [4] stop seed, [5] committed
-    __shared__ uint32_t sPage[LCB_COMMIT_PAGES / 32];      // coarse summary of the round's marks
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x, nT = 64u * NW;
-    if (tid == 0) { sFlag[2] = A.state[LCB_CS_MARKED]; sFlag[5] = A.state[LCB_CS_NCOMMITTED]; sFlag[6] = A.state[LCB_CS_NEXT]; sFlag[7] = A.state[LCB_CS_STOPKIND]; }
-    __syncthreads();
-    uint32_t ps = sFlag[6];
-    if (sFlag[7]) return;                  // the commit of this round has stopped for good
-    bool marked = sFlag[2] != 0;           // wave-uniform, identical in every wavefront
-    const uint32_t sh = A.pageShift;
-    {   // the summary of what earlier invocations of this round marked (a list that overflowed: every page counts as marked)
-        const uint32_t nD = marked ? *A.deltaCount : 0u;
-        for (uint32_t w = tid; w < LCB_COMMIT_PAGES / 32; w += nT) sPage[w] = nD > A.deltaCap ? 0xFFFFFFFFu : 0u;
-        __syncthreads();
-        if (nD <= A.deltaCap) for (uint32_t r = tid; r < nD; r += nT) { const LcbFpOut d = A.deltaList[r]; for (uint32_t q = (uint32_t)(d.lo >> sh); q <= (uint32_t)((d.hi - 1u) >> sh); q++) atomicOr(&sPage[q >> 5], 1u << (q & 31)); }
-        __syncthreads();
-    }
-    uint32_t nCommitted = sFlag[5], stopKind = 0, stopAt = 0;
-    while (ps < A.n) {
-        const uint32_t pe = ps + A.phase < A.n ? ps + A.phase : A.n, ph = ps / A.phase;
-        __syncthreads();                   // (sFlag is read below the previous iteration's writes)
-        if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; sFlag[3] = 0; }
-        __syncthreads();
-        // (0) every seed of the phase has its final result: all threads look at the seeds' states at once (a walk over the 256 states
-        // of a phase by one wavefront costs a dependent load per seed - 30 ms per round of config 3 when the kernel did that)
-        for (uint32_t q = ps + tid; q < pe; q += nT) {
-            const uint32_t r = A.roundState[q];
-            if (r == LCB_RS_NONE) atomicOr(&sFlag[0], 1u);
-            else if (r == LCB_RS_DONE) atomicOr(&sFlag[0], A.roundOut[q].nInst > 1u ? 6u : 2u);
-        }
-        __syncthreads();
-        const uint32_t flags = sFlag[0];
-        if (flags & 1u) break;             // a later launch of the round brings it: the next invocation goes on here
-        if (!(flags & 2u) || (!marked && !(flags & 4u))) { ps = pe; continue; }     // only dead seeds, or nothing to validate against and nothing to commit
-        // (a) every phase-start result of the phase is still exact (nothing to check before the first commit of the round): the wavefronts
-        // take the seeds of the phase 64 at a time (lanes = seeds: which of them have a result), then one seed at a time (lanes = intervals)
-        if (marked) {
-            for (uint32_t c0 = ps + 64u * wave; c0 < pe; c0 += 64u * NW) {
-                const uint32_t q = c0 + lane;
-                unsigned long long done = __ballot(q < pe && A.roundState[q] == LCB_RS_DONE);
-                while (done) {
-                    const uint32_t qq = c0 + (uint32_t)__ffsll((long long)done) - 1u;
-                    done &= done - 1;
-                    const uint32_t nFp = lcb_rfl(A.roundOut[qq].nFp);
-                    const unsigned long long fpOff = A.roundOut[qq].fpOff;
-                    bool hit = false;
-                    for (uint32_t k = lane; k < nFp; k += 64) {
-                        const LcbFpOut f = A.fpArena[fpOff + k];
-                        const uint64_t a = f.lo, b = f.hi < A.nPos ? f.hi : A.nPos - 1u;              // positions a .. b
-                        for (uint32_t pg = (uint32_t)(a >> sh); pg <= (uint32_t)(b >> sh) && !hit; pg++) hit = ((sPage[pg >> 5] >> (pg & 31)) & 1u) != 0;
-                    }
-                    if (__ballot(hit) != 0 && lane == 0) sFlag[1] = 1u;
-                }
-            }
-            __syncthreads();
-            if (sFlag[1]) { stopAt = ps; stopKind = 3; break; }
-        }
-        // (b) ordered commit: wavefront 0 finds the seeds with a block 64 at a time, then lanes = the instances of a seed
-        if (wave == 0 && (flags & 4u)) {
-            uint32_t kind = 0, at = 0;
-            for (uint32_t c0 = ps; c0 < pe && !kind; c0 += 64u) {
-                const uint32_t q0 = c0 + lane;
-                unsigned long long cand = __ballot(q0 < pe && A.roundState[q0] == LCB_RS_DONE && A.roundOut[q0].nInst > 1u);    // blocksfinder.h:375
-                while (cand) {
-                    const uint32_t q = c0 + (uint32_t)__ffsll((long long)cand) - 1u;
-                    cand &= cand - 1;
-                    const uint32_t nInst = lcb_rfl(A.roundOut[q].nInst);
-                    const uint4* inst = A.arena + A.roundOut[q].arenaOff;
-                    bool conflict = false;
-                    for (uint32_t k = lane; k < nInst; k += 64) {
-                        const uint4 in = inst[k];
-                        if (A.chrStamp[in.x] != ph + 1) continue;                            // only chromosomes committed to in this phase (invalidChr_)
-                        const uint64_t base = A.chrBase[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
-                        if (lcb_bits_any_long(A.used, lo, hi)) conflict = true;
-                    }
-                    if (__ballot(conflict) != 0) { at = q; kind = 2; break; }
-                    LCB_WAVE_SYNC();
-                    for (uint32_t k = lane; k < nInst; k += 64) {                            // Finalize: MarkUsed over [Front, Back)
-                        const uint4 in = inst[k];
-                        A.chrStamp[in.x] = ph + 1;
-                        const uint64_t base = A.chrBase[in.x], lo = base + (in.y < in.z ? in.y : in.z), hi = base + (in.y < in.z ? in.z : in.y);
-                        if (hi > lo) {
-                            lcb_bits_set(A.used, lo, hi);
-                            for (uint32_t pg = (uint32_t)(lo >> sh); pg <= (uint32_t)((hi - 1u) >> sh); pg++) atomicOr(&sPage[pg >> 5], 1u << (pg & 31));
-                            const uint32_t slot = atomicAdd(A.deltaCount, 1u);
-                            if (slot < A.deltaCap) A.deltaList[slot] = LcbFpOut{lo, hi};
-                        }
-                    }
-                    LCB_WAVE_SYNC();
-                    if (lane == 0) A.committed[nCommitted] = q;
-                    nCommitted++;
-                    marked = true;
-                }
-            }
-            if (lane == 0) { sFlag[2] = marked ? 1u : 0u; sFlag[3] = kind; sFlag[4] = at; sFlag[5] = nCommitted; }
-        }
-        __syncthreads();
-        if (flags & 4u) { marked = sFlag[2] != 0; nCommitted = sFlag[5]; }              // what wavefront 0 did is known to all
-        if ((flags & 4u) && sFlag[3]) { stopKind = sFlag[3]; stopAt = sFlag[4]; break; }
-        ps = pe;
-    }
-    if (tid == 0) {
-        A.state[LCB_CS_NEXT] = ps; A.state[LCB_CS_NCOMMITTED] = nCommitted; A.state[LCB_CS_MARKED] = marked ? 1u : 0u;
-        if (stopKind) { A.state[LCB_CS_STOPKIND] = stopKind; A.state[LCB_CS_STOPAT] = stopAt; }
     }
 }
 

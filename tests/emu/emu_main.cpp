@@ -126,7 +126,7 @@ struct Emu {
             if (getenv("EMU_PATH_CAP")) { W.pathCap = (uint32_t)atoi(getenv("EMU_PATH_CAP")); W.bodyCap = W.pathCap / 2; }   // tiny path sets: long probe chains, colliding home slots
             W.bestCap = mode == 0 ? LcbCfg<0>::IC : (mode == 1 ? LcbCfg<1>::IC : (mode == 2 ? LcbCfg<2>::IC : 8192));
             W.instCap = mode == 2 ? LcbCfg<2>::IC : (mode == 3 ? 8192 : 0); W.voteCap = mode == 3 ? 65536 : 0;
-            W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr; W.roundIdx = nullptr; W.roundOut = nullptr; W.roundState = nullptr;
+            W.live = nullptr; W.nLive = nullptr; W.ctr = nullptr;
             LcbSlotLayout L = lcb_slot_layout(W.pathCap, W.bodyCap, W.bestCap, W.instCap, W.voteCap);
             c.slot.assign(L.total, 0);
             int32_t* pk = (int32_t*)(c.slot.data() + L.pKeys);
@@ -262,11 +262,9 @@ struct Emu {
     // Like the product's retry chain (device.hip): seeds that overflow the LDS capacities of this mode are run again in the next
     // larger mode (small -> medium -> big), against the same `used` views.
     std::unique_ptr<Emu> next;
-    std::function<void()> afterFirstLaunch;      // (processRound: the commit kernel behind the first launch of a round)
     void runRetry(const std::vector<LcbKSeed>& seeds)
     {
         run(seeds);
-        if (afterFirstLaunch) afterFirstLaunch();
         std::vector<size_t> again;
         for (size_t i = 0; i < out.size(); i++) if (out[i].status >= LCB_ST_INST_OVF && out[i].status <= LCB_ST_BEST_OVF) again.push_back(i);
         if (again.empty() || mode >= 3) return;
@@ -351,73 +349,6 @@ struct EmuProcessor : LcbProcessor {
     }
     int maxViews() const override { return views; }
     int concurrency() const override { const char* e = getenv("EMU_CONCURRENCY"); return e ? atoi(e) : 16384; }
-    // device-resident commit of a round (processRound): the commit kernel body of lcb_kernel.h on EMU_COMMIT_NW (default 4) emulated
-    // wavefronts, on the emulator's bitmap, invoked like on the device behind every "launch" of the round - once after the first launch
-    // (seeds that overflowed their kernel variant have no final result yet: the kernel must wait for them) and once after the retries
-    std::vector<uint32_t> dcStamp, dcCommitted, dcState, dcRound;
-    std::vector<LcbSeedOut> dcOut;
-    std::vector<LcbFpOut> dcList;
-    uint32_t dcDeltaCount = 0;
-    int64_t commitKernels = 0, commitWaited = 0;
-    bool processRound(const lcb_seed* sd, int64_t n, int64_t phase, std::vector<uint64_t>& off, std::vector<lcb_instance>& inst, std::vector<uint64_t>& fpOff,
-                      std::vector<lcb_fp>& fp, std::vector<uint32_t>& committed, uint32_t& stopAt, int& stopKind) override
-    {
-        if (getenv("EMU_HOST_COMMIT") || n <= 0) return false;
-        static_assert(sizeof(lcb_instance) == sizeof(uint4), "layouts the commit kernel reads");
-        dcDeltaCount = 0;
-        dcList.assign(getenv("EMU_DELTA_CAP") ? (size_t)atoi(getenv("EMU_DELTA_CAP")) : 4096, LcbFpOut{0u, 0u});
-        dcStamp.assign(emu->g->nChr() + 1, 0u); dcCommitted.assign((size_t)n, 0u); dcState.assign(LCB_CS_WORDS, 0u);
-        dcRound.assign((size_t)n, LCB_RS_NONE); dcOut.assign((size_t)n, LcbSeedOut{});
-        const int nw = getenv("EMU_COMMIT_NW") ? atoi(getenv("EMU_COMMIT_NW")) : 4;
-        // EMU_COMMIT_HOLD=k: the result of every k-th seed stays hidden from the commit kernel behind the first launch, as if the seed
-        // had overflowed its kernel variant and got its result from a later launch of the round (the goldens have no such seeds)
-        const int hold = getenv("EMU_COMMIT_HOLD") ? atoi(getenv("EMU_COMMIT_HOLD")) : 0;
-        bool first = true;
-        auto commitKernel = [&]() {
-            // what the process (and screening) kernels of a round launch leave on the device: headers of final results, dead seeds
-            for (int64_t i = 0; i < n; i++) {
-                const LcbSeedOut& o = emu->out[(size_t)i];
-                if (o.status != 0 || dcRound[(size_t)i] != LCB_RS_NONE) continue;
-                if (first && hold > 0 && (i % hold) == hold - 1) continue;
-                dcOut[(size_t)i] = o;
-                dcRound[(size_t)i] = (o.nInst == 0 && o.nFp == 0) ? LCB_RS_DEAD : LCB_RS_DONE;
-            }
-            LcbCommitArgs A;
-            A.chrBase = emu->plan.chrDev.data(); A.used = emu->used.data(); A.chrStamp = dcStamp.data();
-            A.roundState = dcRound.data(); A.roundOut = dcOut.data(); A.arena = emu->arena.data(); A.fpArena = emu->fpArena.data();
-            A.n = (uint32_t)n; A.phase = (uint32_t)phase; A.nPos = emu->plan.devPositions;
-            A.state = dcState.data(); A.committed = dcCommitted.data(); A.deltaList = dcList.data(); A.deltaCount = &dcDeltaCount; A.deltaCap = (uint32_t)dcList.size();
-            A.pageShift = getenv("EMU_COMMIT_PAGE_SHIFT") ? (uint32_t)atoi(getenv("EMU_COMMIT_PAGE_SHIFT")) : 5u; while ((A.nPos >> A.pageShift) >= (uint64_t)LCB_COMMIT_PAGES) A.pageShift++;
-            const uint32_t before = dcState[LCB_CS_NEXT];
-            if (nw == 16) emu_run_block(0, 16, [&]() { lcb_commit_body<16>(A); });
-            else if (nw == 8) emu_run_block(0, 8, [&]() { lcb_commit_body<8>(A); });
-            else if (nw == 2) emu_run_block(0, 2, [&]() { lcb_commit_body<2>(A); });
-            else emu_run_block(0, 4, [&]() { lcb_commit_body<4>(A); });
-            commitKernels++;
-            if (!dcState[LCB_CS_STOPKIND] && dcState[LCB_CS_NEXT] < (uint32_t)n) commitWaited++;
-            (void)before;
-            first = false;
-        };
-        std::vector<LcbKSeed> ks;
-        for (int64_t i = 0; i < n; i++) ks.push_back(LcbKSeed{sd[i].vid, sd[i].ch, 0u, 0u});
-        emu->afterFirstLaunch = commitKernel;
-        try { emu->runRetry(ks); } catch (...) { emu->afterFirstLaunch = nullptr; throw; }
-        emu->afterFirstLaunch = nullptr;
-        commitKernel();                            // behind the last launch: every seed has its final result
-        off.assign((size_t)n + 1, 0); fpOff.assign((size_t)n + 1, 0); inst.clear(); fp.clear();
-        for (int64_t i = 0; i < n; i++) {
-            const LcbSeedOut& o = emu->out[(size_t)i];
-            if (o.status) throw LcbError("emulated kernel overflow");
-            off[(size_t)i] = inst.size(); fpOff[(size_t)i] = fp.size();
-            for (uint32_t e = 0; e < o.nInst; e++) { const uint4 r = emu->arena[o.arenaOff + e]; inst.push_back(lcb_instance{r.x, r.y, r.z, r.w}); }
-            for (uint32_t e = 0; e < o.nFp; e++) { const LcbFpOut r = emu->fpArena[o.fpOff + e]; fp.push_back(lcb_fp{emu->plan.toHost(r.lo), emu->plan.toHost(r.hi)}); }
-        }
-        off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
-        committed.assign(dcCommitted.begin(), dcCommitted.begin() + dcState[LCB_CS_NCOMMITTED]);
-        stopKind = (int)dcState[LCB_CS_STOPKIND]; stopAt = dcState[LCB_CS_STOPAT];
-        if (stopKind == 0 && dcState[LCB_CS_NEXT] < (uint32_t)n) throw LcbError("emu: the commit kernel behind the last launch of a round did not reach its end");
-        return true;
-    }
     // side lanes (EMU_SIDE_LANES=n): a background batch is computed on the spot and handed out job by job, EMU_SIDE_DELAY polls late
     // (EMU_SIDE_LATE=1: computed when first asked for, against the live state of that moment)
     LcbEagerSideLanes side{getenv("EMU_SIDE_LANES") ? atoi(getenv("EMU_SIDE_LANES")) : 0, getenv("EMU_SIDE_DELAY") ? atoi(getenv("EMU_SIDE_DELAY")) : 0, getenv("EMU_SIDE_LATE") != nullptr};
@@ -599,7 +530,6 @@ int main(int argc, char** argv)
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
                 if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN") ? envInt("LCB_LAZY_SPAN") : -1;
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls (host commit only)
-                cfg.hostCommit = getenv("EMU_HOST_COMMIT") != nullptr;       // the round's speculative launch as a background batch (needs EMU_SIDE_LANES)       // default: the commit kernel body under the emulator commits the clean prefix of every round
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
                 int diffs = 0;
@@ -610,10 +540,9 @@ int main(int argc, char** argv)
                         R, seeds.size(), blocks.size(), (long long)nb, (long long)es.blocksFound, (long long)st.blocks_found, (long long)es.failures,
                         (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds,
                         (long long)es.conflictLaunches, (long long)es.conflictSeeds, diffs);
-                fprintf(stderr, "       device-resident commit: %lld results, %lld whole rounds, %lld kernels (%lld waited for a later launch) | side lanes: %lld batches, %lld jobs, %lld taken | early critical launches %lld\n",
-                        (long long)es.deviceCommits, (long long)es.deviceRounds, (long long)proc.commitKernels, (long long)proc.commitWaited, (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.earlyCritical);
+                fprintf(stderr, "       side lanes: %lld batches, %lld jobs, %lld taken | early critical launches %lld | lazy seeds %lld\n",
+                        (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.earlyCritical, (long long)es.lazySeeds);
                 if (getenv("EMU_EXPECT_EARLY") && es.recomputeLaunches > 0 && es.earlyCritical == 0) { fprintf(stderr, "early critical launches expected but none happened\n"); return 1; }
-                if (getenv("EMU_EXPECT_DEVICE_COMMIT") && es.rounds > 1 && es.blocksFound > 0 && es.deviceCommits == 0) { fprintf(stderr, "device-resident commit expected but nothing was committed there\n"); return 1; }
                 fprintf(stderr, "       views %d: built %lld, job results used %lld | launches %llu, critical path %llu pushes (first jobs %llu), total %llu pushes\n", proc.views,
                         (long long)es.viewsBuilt, (long long)es.jobsUsed, (unsigned long long)emu.launches, (unsigned long long)emu.criticalPushes,
                         (unsigned long long)emu.firstPushes, (unsigned long long)emu.totalPushes);

@@ -263,8 +263,8 @@ int main(int argc, char** argv)
                 (long long)es.conflictLaunches, (long long)es.overPredicted, sec);
         if (es.earlyCritical) fprintf(stderr, "model: early critical launches %lld of %lld stops\n", (long long)es.earlyCritical, (long long)es.recomputeLaunches);
         fprintf(stderr, "model: host ms: engine %.0f = processor %.0f + dry runs %.0f + commit / validation / other %.0f\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs);
-        fprintf(stderr, "model:   of the rest: round setup %.0f, validation %.0f, commit %.0f, marks to the processor %.0f, mirror of device commits %.0f | of the dry runs: marks to the processor %.0f, simulation %.0f; views built %lld\n", es.sectionMs[LCB_SEC_SETUP],
-                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_MIRROR], es.sectionMs[LCB_SEC_PLAN_FLUSH], es.sectionMs[LCB_SEC_PLAN_SIM], (long long)es.viewsBuilt);
+        fprintf(stderr, "model:   of the rest: round setup %.0f, validation %.0f, commit %.0f, marks to the processor %.0f | of the dry runs: marks to the processor %.0f, simulation %.0f; views built %lld\n", es.sectionMs[LCB_SEC_SETUP],
+                es.sectionMs[LCB_SEC_VALIDATE], es.sectionMs[LCB_SEC_COMMIT], es.sectionMs[LCB_SEC_FLUSH], es.sectionMs[LCB_SEC_PLAN_FLUSH], es.sectionMs[LCB_SEC_PLAN_SIM], (long long)es.viewsBuilt);
         fprintf(stderr, "model: launches %zu (round %lld, job %lld), critical path %lld pushes, total %lld pushes | model ms: rounds %.0f + jobs %.0f + big %.0f (%lld launches) = %.0f\n",
                 proc.launches.size(), (long long)nRound, (long long)nJobs, (long long)critical, (long long)total, tRound / 1000, tJobs / 1000, tBig / 1000, (long long)bigLaunches,
                 (tRound + tJobs + tBig) / 1000);

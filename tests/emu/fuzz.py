@@ -38,18 +38,13 @@ def case_params(i, small=False):
             rnd.choice([("medium", {"EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "8", "EMU_NOSTATS": "1", "EMU_LIMIT": "150"}),
                         ("medium", {"EMU_NW": "8", "EMU_LIMIT": "150"}), ("big", {"EMU_NW": "4", "EMU_LIMIT": "150"})])]
     # the engine's asynchronous job batches (eager / late stand-ins, delayed visibility, refused batches) with the early critical launch
-    # (or a processor that refuses it), and the device-resident commit kernel body behind every launch of a round - or the host-only
-    # commit - with results that arrive from later launches of their round (drawn after everything else: earlier cases keep their runs)
+    # (or a processor that refuses it), and lazy round tails of several spans (drawn after everything else: earlier cases keep their runs)
     env3 = {"EMU_NOSTATS": "1", "EMU_ROUNDS": rnd.choice(["1", "7", "256"]), "EMU_SIDE_LANES": rnd.choice(["1", "2", "4"]),
             "EMU_SIDE_DELAY": rnd.choice(["0", "1", "3", "1000"]), "EMU_CONCURRENCY": rnd.choice(["4", "64", "16384"])}
     if rnd.random() < 0.5: env3["EMU_SIDE_LATE"] = "1"
     if rnd.random() >= 0.6: env3["EMU_NO_EARLY"] = "1"
     if rnd.random() < 0.3: env3["EMU_SIDE_CAP"] = rnd.choice(["8", "50"])
-    if rnd.random() >= 0.4: env3["EMU_HOST_COMMIT"] = "1"
-    else:
-        env3["EMU_COMMIT_NW"] = rnd.choice(["2", "4", "8", "16"])
-        if rnd.random() < 0.6: env3["EMU_COMMIT_HOLD"] = rnd.choice(["3", "17", "200"])
-        if rnd.random() < 0.3: env3["EMU_DELTA_CAP"] = rnd.choice(["1", "7"])
+    if rnd.random() >= 0.4: env3["LCB_LAZY_SPAN"] = rnd.choice(["0", "2", "16", "64"])      # (0: off; default 8)
     runs.append(("find", env3))
     return synth, (k, b, m, a), runs, (strains, segs)
 

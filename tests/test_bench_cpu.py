@@ -135,10 +135,10 @@ def test_ab_driver_runs_every_variant_once_loaded(fake_gpu, monkeypatch, capsys)
     spec = importlib.util.spec_from_file_location("ab_engine", os.path.join(ROOT, "scripts", "ab_engine.py"))
     ab = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ab)
-    assert ab.parse_variant("x:host_commit=1,dev.side_lanes=2,max_jobs=64") == ("x", {"side_lanes": 2}, {"host_commit": 1, "max_jobs": 64})
+    assert ab.parse_variant("x:lazy_span=-1,dev.side_lanes=2,max_jobs=64") == ("x", {"side_lanes": 2}, {"lazy_span": -1, "max_jobs": 64})
     assert ab.parse_variant("base") == ("base", {}, {})
-    monkeypatch.setattr(sys, "argv", ["ab_engine.py", "--workload", "ecoli10_tiny", "--threads", "2", "base", "hostc:host_commit=1", "lanes2:dev.side_lanes=2"])
+    monkeypatch.setattr(sys, "argv", ["ab_engine.py", "--workload", "ecoli10_tiny", "--threads", "2", "base", "nolazy:lazy_span=-1", "lanes2:dev.side_lanes=2"])
     ab.main()
     out = capsys.readouterr().out.strip().splitlines()
-    assert out[0].startswith("ecoli10_tiny:") and [ln.split(":")[0] for ln in out[1:]] == ["base", "hostc", "lanes2"]
+    assert out[0].startswith("ecoli10_tiny:") and [ln.split(":")[0] for ln in out[1:]] == ["base", "nolazy", "lanes2"]
     assert "DIFFER" not in "".join(out)

@@ -238,19 +238,18 @@ def test_find_blocks_gpus_one_process(built, case):
     assert finder.stats["exchanges"] > 0
 
 
-@pytest.mark.parametrize("host_commit", [0, 1])
-def test_screened_compact_rounds(built, case, host_commit):
+@pytest.mark.parametrize("lazy_span", [-1, 0])
+def test_screened_compact_rounds(built, case, lazy_span):
     """wide_threshold=1 / screen_min=1 make even the small rounds of the golden cases take the screened compact path (the screening
-    kernel finalises the seeds whose Path::Init finds nothing; the commit kernel of a round passes over them): same blocks with the
-    device-resident commit and with the host's."""
+    kernel finalises the seeds whose Path::Init finds nothing), with and without lazy round tails: the reference's blocks."""
     st, p, dev = _setup(case, wide_threshold=1, screen_min=1)
     finder = sibeliaz_amd.BlocksFinder(st, case.k)
-    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, host_commit=host_commit)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, lazy_span=lazy_span)
     got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
     assert got == case.golden("pretrim.tsv")
     summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
     assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
-    assert host_commit == 0 or finder.stats["device_commits"] == 0
+    assert (finder.stats["lazy_seeds"] > 0) == (lazy_span == 0 and finder.stats["rounds"] > 0 and len(st.seeds(4)) > 256)
 
 
 @pytest.mark.parametrize("knobs,dev_opts", [({"sync_jobs": 1}, {}), ({}, {"side_lanes": 1}), ({"max_jobs": 6}, {"side_lanes": 2}),
@@ -358,31 +357,6 @@ def test_persistent_gpu_set(built, case):
         assert got == case.golden("pretrim.tsv")
         assert finder.stats["exchanges"] > 0
     gpus.close()
-
-
-@pytest.mark.parametrize("knobs,dev_opts", [({}, {}), ({"sync_jobs": 1}, {}), ({"round_fixed": 1, "round_phases": 1}, {}), ({"round_fixed": 1, "round_phases": 64, "max_jobs": 8}, {}),
-                                            ({"lazy_span": -1}, {"arena": 64}), ({"round_fixed": 1, "round_phases": 64}, {"start_mode": 1, "path_cap": 512, "path_cap_max": 512}),
-                                            ({}, {"batch": 300, "screen_min": 64})])
-def test_device_resident_commit_on_gpu(built, case, knobs, dev_opts):
-    """SURVEY 8f-4, on by default: the clean prefix of every round is validated, conflict-checked and marked used by lcb_commit_kernel,
-    chained behind every launch of the round on the launch's stream, over the results where the kernels left them; the host mirrors it
-    and takes over at the first seed that needs a new computation. Same blocks and conflict count as the reference and as the host-only
-    commit (lcb_hooks.host_commit) - with the default options, without side lanes, with one-phase rounds, with a tiny job cap, with a
-    result arena so small that rounds have to give the commit up (their arenas are reset between launches; no lazy round tails there: the few
-    rounds of a golden would all begin with seeds that overflow that arena), with compact path sets so
-    small that seeds overflow into later launches of their round (the commit kernel waits for them), and with rounds of several
-    screened launches. Something must actually have been committed on the device."""
-    st, p, dev = _setup(case, **dev_opts)
-    finder = sibeliaz_amd.BlocksFinder(st, case.k)
-    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
-    for _ in range(2):                       # (a second pass on the same device: the delta bitmap is un-marked through the list of its ranges)
-        blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, **knobs)
-        got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
-        assert got == case.golden("pretrim.tsv")
-        assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
-        assert finder.stats["device_commits"] > 0 or int(summary["blocksFound"]) == 0
-    blocks2 = finder.FindBlocks(case.m, case.b, device=dev, threads=4, host_commit=1, **knobs)
-    assert blocks.tobytes() == blocks2.tobytes() and finder.stats["device_commits"] == 0
 
 
 @pytest.mark.parametrize("knobs,dev_opts", [({}, {}), ({"max_jobs": 6}, {"side_lanes": 1}), ({"round_fixed": 1, "round_phases": 1}, {}), ({}, {"start_mode": 3}),

@@ -159,7 +159,7 @@ def emu_built():
 
 @pytest.mark.parametrize("name,mode,env", [("inv_k25", "seeds-final", {}), ("inv_k25", "find", {}), ("twogenomes", "seeds-final", {"EMU_NW": "4"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64"}),
-                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_HOST_COMMIT": "1"}),     # the shipped kernels, ordered commit on the host only
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_LAZY_SPAN": "0"}),     # the shipped kernels, no lazy round tails
                                             # the shipped (non-stats) instantiation: checkpointed replay instead of a replay from Init
                                             ("inv_k25", "seeds-init", {"EMU_NOSTATS": "1"}), ("twogenomes", "medium", {"EMU_NOSTATS": "1", "EMU_LIMIT": "1500"}),
                                             # every kernel variant: wide (LDS path set), big (index in LDS, fields in the workspace), huge (all in the workspace)
@@ -192,20 +192,10 @@ def emu_built():
                                             ("tandem4", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "LCB_MAX_JOBS": "16", "EMU_SIDE_DELAY": "2"}),
                                             ("twogenomes", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
                                             ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1"}),
-                                            # device-resident ordered commit (the default whenever the engine does not count events): the commit kernel body
-                                            # of lcb_kernel.h under the emulator (2 / 4 / 8 / 16 wavefronts) behind every launch of a round - validates, conflict-checks and
-                                            # marks the clean prefix; EMU_COMMIT_HOLD hides every k-th result from the kernel behind the first launch (a seed that got its
-                                            # result from a later launch of the round: the kernel waits at its phase and the next invocation goes on there);
-                                            # EMU_DELTA_CAP: a list of the round's marked ranges so short that it overflows (whole-bitmap clear before the next round)
-                                            ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1"}),
-                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "EMU_COMMIT_NW": "16"}),
-                                            ("collinear6", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_ROUNDS": "1", "LCB_ROUND_FIXED": "1", "EMU_SHARE": "1", "EMU_DELTA_CAP": "3", "EMU_COMMIT_NW": "2"}),
-                                            ("inv_k25", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_DEVICE_COMMIT": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "EMU_COMMIT_HOLD": "97", "EMU_COMMIT_NW": "8"}),
-                                            ("twogenomes", "find", {"EMU_NOSTATS": "1", "EMU_ROUNDS": "64", "EMU_COMMIT_HOLD": "5", "EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000"}),
                                             # early critical launch (always with side lanes): the stop's own jobs are begun before the dry run that plans the rest;
                                             # with a lane for the rest, with batches the lanes refuse (the rest then runs synchronously behind the early jobs), and
                                             # with a processor that refuses the early launch (EMU_NO_EARLY: the stop's own jobs run after the dry run)
-                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "EMU_HOST_COMMIT": "1"}),
+                                            ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "3"}),
                                             ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2"}),
@@ -223,8 +213,8 @@ def emu_built():
                                             ("inv_k25", "big", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "100000", "EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SCHED": "rr", "EMU_FP_CHECK": "1"}),
                                             ("twogenomes", "huge", {"EMU_SEG_CAP": "1000", "EMU_LIMIT": "800"}),
                                             ("nruns_abund", "find", {"EMU_SEG_CAP": "1500", "EMU_SEG_GAP": "1000"}),
-                                            ("twogenomes", "find", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "70000", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_NW": "2", "EMU_EXPECT_DEVICE_COMMIT": "1"}),
-                                            ("tandem4", "find", {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "123457", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "EMU_COMMIT_NW": "16"})])
+                                            ("twogenomes", "find", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "70000", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_NW": "2"}),
+                                            ("tandem4", "find", {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "123457", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1"})])
 def test_kernel_logic_under_wave_emulator(built, emu_built, case_dir, name, mode, env, tmp_path):
     """The unmodified device code of lcb_kernel.h on the CPU wavefront emulator (tests/emu) vs the oracle: per-seed results,
     event counters and the whole round engine. Logic only — the GPU tests are the parity tests proper."""
@@ -274,12 +264,3 @@ def test_engine_model_at_scale(built, tmp_path_factory, env):
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
 
 
-def test_device_commit_kernel_on_random_rounds(built):
-    """lcb_commit_body (the device-resident ordered commit) on the wavefront emulator with 2 / 4 / 8 / 16 wavefronts against a
-    plain sequential restatement of blocksfinder.h:372-414 over random rounds whose results arrive in several launches (the kernel body is
-    invoked behind each and carries its state on): committed list, stop position and kind, the live bitmap, the delta bitmap and the list
-    of its ranges."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "build/commit_check"])
-    for seed in ("1", "2026"):
-        r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "commit_check"), "300", seed], capture_output=True, text=True)
-        assert r.returncode == 0 and " 0 mismatches" in r.stderr, r.stderr[-1500:]
