@@ -194,11 +194,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // has a workgroup of its own; jobs beyond the processor's seeds in flight only queue up behind speculation that may
     // never be used.
     const size_t maxJobs = (size_t)std::max(1, cfg.maxJobs > 0 ? cfg.maxJobs : proc.concurrency());
-    // ... and fewer where speculation does not pay: the cap adapts between maxJobs / 4 and maxJobs to the share of the background jobs of
-    // the last round that ended void (heavy, mutually invalidating seeds - config 3: 37 % void at 1 280 jobs per plan, 16 % and a 6 %
-    // shorter pass at 512 - against the light long paths of the k = 25 shapes: 22 % void, 5 % slower at 512; profiles/r05/ab_third.txt).
-    // A fixed cfg.maxJobs is taken as it is.
-    size_t jobCap = maxJobs;
+    // (Measured and removed, profiles/r05/ab_fourth.txt: a cap that adapts to the share of void background jobs of the last round. Config 3
+    // - heavy, mutually invalidating seeds, 37 % void - gains 5 % with a fixed cap of 512 and nothing with the adaptive one; the light
+    // long paths of the k = 25 shapes lose 5 % at 512 and 3 % with the adaptive one.)
     const int predictF = cfg.predictF > 0 ? cfg.predictF : 3;       // how the dry run predicts the F of a conflicting seed:
                                                                     // 1 nothing, 2 the still-free instances of E, 3 a stale F if there is one, else as 2
     const int world = cfg.world > 0 ? cfg.world : 1, rank = cfg.rank;
@@ -375,7 +373,6 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)std::max(roundPhases, std::min(lazySpan, maxRound)) * phase);
         const int64_t nEager = std::min<int64_t>(nRound, (int64_t)roundPhases * phase);     // seeds [nEager, nRound) are lazy
         int64_t eagerRecomputed = 0;
-        const int64_t sideJobsBefore = st.sideJobs, sideVoidBefore = st.sideVoid;
         st.rounds++;
         flush();                                    // processor state == live state at the start of phase `pos`
         epochMarks.assign(1, RangeSet());
@@ -630,7 +627,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             std::vector<lcb_instance> guess;
             size_t lv = liveFrom((midPhase ? stopAt : ph0));          // cursor into liveIdx (seeds that are not in it need nothing, commit nothing)
             for (int64_t ph = ph0; ph < lim; ph += phase) {
-                if (jobs.size() >= jobCap) break;      // enough speculation for one launch (the first job is always there)
+                if (jobs.size() >= maxJobs) break;      // enough speculation for one launch (the first job is always there)
                 const int64_t n = std::min<int64_t>(phase, nRound - ph);
                 const bool first = ph == ph0;
                 while (lv < liveIdx.size() && liveIdx[lv] < (first && midPhase ? stopAt : ph)) lv++;
@@ -882,11 +879,6 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         }
         if (useSide) for (size_t q = 0; q < sideJobs.size(); q++) if (sideJobs[q].state == 0) dropSide((int32_t)q);   // speculation beyond the round is void
         pos += nRound;
-        if (cfg.maxJobs <= 0 && st.sideJobs - sideJobsBefore >= 64) {
-            const double voidShare = (double)(st.sideVoid - sideVoidBefore) / (double)(st.sideJobs - sideJobsBefore);
-            if (voidShare > 0.30) jobCap = std::max<size_t>(std::max<size_t>(1, maxJobs / 4), jobCap / 2);
-            else if (voidShare < 0.20) jobCap = std::min(maxJobs, jobCap * 2);
-        }
         lastInvalid = (double)eagerRecomputed / (double)nEager;       // (what the adaptation judges: the speculative launch)
         if (!fixedRound) {
             if (lastInvalid > 0.25) roundPhases = std::max(1, roundPhases / 2);
