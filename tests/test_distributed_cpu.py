@@ -63,7 +63,7 @@ def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
                                             # the multi-rank engine is the single-rank engine: asynchronous job batches dealt to the ranks' side lanes, results
                                             # published through collective exchanges (batches computed at once / late / visible late / refused by a lane)
                                             ("nruns_abund", 2, {"EMU_SIDE_LANES": "2"}), ("tandem4", 3, {"EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "EMU_SIDE_DELAY": "2", "EMU_ROUNDS": "8"}),
-                                            ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16"}),
+                                            ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16", "LCB_LAZY_SPAN": "0"}),     # (no lazy tails: their batches of whole phases are all beyond this lane's cap)
                                             ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"}),
                                             # eight ranks (results do not depend on 1 / 2 / 4 / 8 ranks), with and without background batches
                                             ("twogenomes", 8, {}), ("nruns_abund", 8, {"EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1"}),
