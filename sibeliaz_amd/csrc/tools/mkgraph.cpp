@@ -97,11 +97,20 @@ struct KmerTable {
             uint64_t k = key[h].load(std::memory_order_relaxed);
             if (k == 0) {
                 if (key[h].compare_exchange_strong(k, kmer + 1, std::memory_order_relaxed)) {
-                    if (used.fetch_add(1, std::memory_order_relaxed) * 10 > (mask + 1) * 9) { full.store(true, std::memory_order_relaxed); return false; }   // (load factor 0.9: a table of 2^31 slots is 24 GB)
+                    // (the fill level is counted in batches per thread: one shared counter bumped for every new k-mer is a cache line that
+                    // hundreds of threads fight over - the GPU box's 256 threads generated a 4-Gbp graph SLOWER than 8 threads here)
+                    static thread_local uint32_t mine = 0;
+                    if (++mine == 1024) {
+                        mine = 0;
+                        if ((used.fetch_add(1024, std::memory_order_relaxed) + 1024 + 1024 * 512) * 10 > (mask + 1) * 9) { full.store(true, std::memory_order_relaxed); return false; }   // (load factor 0.9: a table of 2^31 slots is 24 GB)
+                    }
                     k = kmer + 1;
                 }
             }
-            if (k == kmer + 1) { val[h].fetch_or(bits, std::memory_order_relaxed); return true; }
+            if (k == kmer + 1) {
+                if ((val[h].load(std::memory_order_relaxed) & bits) != bits) val[h].fetch_or(bits, std::memory_order_relaxed);   // (most occurrences of a k-mer repeat what is known: a read, not a read-modify-write)
+                return true;
+            }
             if ((probes & 1023) == 1023 && full.load(std::memory_order_relaxed)) return false;
         }
         full.store(true, std::memory_order_relaxed);

@@ -92,7 +92,10 @@ struct Emu {
     Emu(const lcb_graph* graph, const lcb_params& prm, int kernelMode) : g(graph), p(prm), mode(kernelMode), big(kernelMode >= 2)
     {
         const uint64_t segCap = getenv("EMU_SEG_CAP") ? strtoull(getenv("EMU_SEG_CAP"), nullptr, 10) : 0, segGap = getenv("EMU_SEG_GAP") ? strtoull(getenv("EMU_SEG_GAP"), nullptr, 10) : 0;
-        plan = lcb_plan_segments(*g, segCap, segGap);
+        // EMU_SEG_MAX=n: at most about n segments whatever the size of the input (the gap hook with more than 2^32 positions costs address space per segment)
+        uint64_t segCapEff = segCap;
+        if (segCap && getenv("EMU_SEG_MAX")) segCapEff = std::max<uint64_t>(segCap, g->nPos() / (uint64_t)std::max(1, atoi(getenv("EMU_SEG_MAX"))) + 1);
+        plan = lcb_plan_segments(*g, segCapEff, segGap);
         seg = plan.nSeg() > 1 || segCap != 0;
         if (seg && getenv("EMU_SEG_VERBOSE")) fprintf(stderr, "emu: %u segments over %zu chromosomes, %llu device positions (gap %llu)\n", plan.nSeg(), (size_t)g->nChr(), (unsigned long long)plan.devPositions, (unsigned long long)plan.gap);
         const size_t pageWords = (size_t)1 << LCB_PAGE_SHIFT;

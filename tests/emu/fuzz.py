@@ -8,7 +8,8 @@ views, F prediction, job cap), `seeds-init` / `seeds-final` with the footprint-c
 outside a seed's footprint is set to used and the oracle must still reproduce the result), `seeds-init` with event counters, and one
 multi-wavefront variant (wide or big mode
 with helper wavefronts) on the heaviest seeds, and `find` once more with the engine's asynchronous features (side lanes with random delays,
-late batches and refused batches, the early critical launch, the device-resident commit kernel body with results that arrive late). Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
+late batches and refused batches, the early critical launch, lazy round tails of several spans), and two runs with positions as (segment, offset)
+pairs (small segments, gaps between them, flat indices beyond 2^32). Failing cases keep their inputs. tests/test_fuzz_emu.py runs a fixed handful of
 cases inside the CPU suite; the open-ended campaign is this script.
 """
 import os, random, subprocess, sys, time
@@ -46,6 +47,16 @@ def case_params(i, small=False):
     if rnd.random() < 0.3: env3["EMU_SIDE_CAP"] = rnd.choice(["8", "50"])
     if rnd.random() >= 0.4: env3["LCB_LAZY_SPAN"] = rnd.choice(["0", "2", "16", "64"])      # (0: off; default 8)
     runs.append(("find", env3))
+    # positions as (segment, offset) pairs - the SEG kernel instantiations: segments of a few hundred to a few thousand positions, with and
+    # without unused table space between them (every eighth case: more than 2^32 positions of it, i.e. flat indices beyond 32 bits), per-seed
+    # results with the footprint check and the whole engine (drawn last: earlier runs of a case stay what they were)
+    seg = {"EMU_SEG_CAP": rnd.choice(["300", "1000", "4000"])}
+    gap = rnd.choice(["0", "0", "77", "65536", "100003", "100003", "4300000000", "4300000000"])
+    if gap != "0": seg["EMU_SEG_GAP"] = gap
+    big = gap == "4300000000"
+    if big: seg["EMU_SEG_MAX"] = "2"               # two or three segments at most: the gapped tables are address space, the bitmap is real memory
+    runs.append((rnd.choice(["seeds-init", "seeds-final"]), dict(seg, EMU_NOSTATS="1", EMU_FP_CHECK="1", EMU_LIMIT="600", EMU_NW=rnd.choice(["1", "2"]))))
+    if not big: runs.append(("find", dict(seg, EMU_NOSTATS="1", EMU_ROUNDS=rnd.choice(["1", "7", "256"]), EMU_SIDE_LANES=rnd.choice(["1", "3"]), EMU_SIDE_DELAY=rnd.choice(["0", "2"]))))
     return synth, (k, b, m, a), runs, (strains, segs)
 
 

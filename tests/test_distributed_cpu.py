@@ -62,11 +62,11 @@ def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
 @pytest.mark.parametrize("name,ranks,env", [("inv_k25", 2, {}), ("nruns_abund", 3, {"EMU_VIEWS": "3"}), ("tandem4", 4, {"EMU_ROUNDS": "7"}),
                                             # the multi-rank engine is the single-rank engine: asynchronous job batches dealt to the ranks' side lanes, results
                                             # published through collective exchanges (batches computed at once / late / visible late / refused by a lane)
-                                            ("nruns_abund", 2, {"EMU_SIDE_LANES": "2"}), ("tandem4", 3, {"EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "EMU_SIDE_DELAY": "2", "EMU_ROUNDS": "8"}),
-                                            ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16", "LCB_LAZY_SPAN": "0"}),     # (no lazy tails: their batches of whole phases are all beyond this lane's cap)
+                                            ("nruns_abund", 2, {"EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8"}), ("tandem4", 3, {"EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "EMU_SIDE_DELAY": "2", "EMU_ROUNDS": "8"}),
+                                            ("nruns_abund", 4, {"EMU_SIDE_LANES": "1", "EMU_SIDE_CAP": "5", "LCB_MAX_JOBS": "16"}),
                                             ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"}),
                                             # eight ranks (results do not depend on 1 / 2 / 4 / 8 ranks), with and without background batches
-                                            ("twogenomes", 8, {}), ("nruns_abund", 8, {"EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1"}),
+                                            ("inv_k25", 8, {}), ("nruns_abund", 8, {"EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1", "LCB_LAZY_SPAN": "8"}),
                                             # ... and with positions as (segment, offset) pairs (the SEG kernels; test_host_cpu.py)
                                             ("tandem4", 4, {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "99991", "EMU_SIDE_LANES": "2"})])
 def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, env):
@@ -79,7 +79,8 @@ def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, en
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "all"])
     c = Case(name, str(tmp_path))
     r = subprocess.run([os.path.join(ROOT, "tests", "emu", "build", "emu_check"), c.graph, c.fasta, str(c.k), str(c.b), str(c.m), str(c.a), "find-ranks",
-                        str(tmp_path / "emu")], capture_output=True, text=True, env=dict(os.environ, EMU_NOSTATS="1", EMU_THREADS="2", EMU_RANKS=str(ranks), **env))
+                        str(tmp_path / "emu")], capture_output=True, text=True,
+                       env=dict(os.environ, EMU_NOSTATS="1", EMU_THREADS="2", EMU_RANKS=str(ranks), **dict({"LCB_LAZY_SPAN": "0"}, **env)))     # (lazy round tails: the cases that name them)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = re.findall(r"find-ranks rank \d+/%d: .* exchanges (\d+) .*diffs 0" % ranks, r.stderr)
     assert len(lines) == ranks and all(int(x) > 0 for x in lines), r.stderr[-1000:]
