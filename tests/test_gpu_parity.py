@@ -300,7 +300,7 @@ def test_footprints_cover_every_read_on_gpu(built, case, mode):
 @pytest.mark.parametrize("synth_seed", [7101, 7102, 7103, 7104, 7105, 7106, 7107, 7108])
 def test_footprints_cover_every_read_on_random_inputs(built, tmp_path, synth_seed):
     """The same property on RANDOM inputs (the bug class it guards - a read outside the footprint - showed on 6 of 11 random inputs under
-    the emulator in round 2 and on none of the goldens), for the compact, the wide and the big variant, in three `used` states - all unused,
+    the emulator in round 2 and on none of the goldens), for all four kernel variants, in three `used` states - all unused,
     random runs of used positions (any bitmap is a legal state for the kernels), the final state of a whole FindBlocks - and for up to
     120 seeds that yield a block per state (the heavy head of the seed order and a sample of the rest)."""
     import bench
@@ -323,7 +323,7 @@ def test_footprints_cover_every_read_on_random_inputs(built, tmp_path, synth_see
     rnd[n_pos:] = False
     states = {"unused": np.zeros(words * 32, dtype=bool), "random": rnd, "final": np.unpackbits(np.resize(final, words).view(np.uint8), bitorder="little").astype(bool)}
     checked = 0
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 4):
         dev = sibeliaz_amd.Device(st, p, 0, start_mode=mode)
         seeds = st.seeds(4)
         for name, base in states.items():
@@ -331,7 +331,7 @@ def test_footprints_cover_every_read_on_random_inputs(built, tmp_path, synth_see
             off, inst, fp_off, fp = dev.process_seeds_fp(seeds)
             good = [i for i in range(len(seeds)) if off[i + 1] - off[i] > 1]
             picked = sorted(set(good[:50] + good[50:: max(1, len(good) // 70)][:70]))       # the heavy head of the seed order and a sample of the rest
-            if mode == 3: picked = picked[:40]                                                # (big variant: one seed per CU, every launch is slow)
+            if mode >= 3: picked = picked[:40]                                                # (big, huge: one seed per CU or fewer, every launch is slow)
             for i in picked:
                 bits = np.ones(words * 32, dtype=bool)
                 for lo, hi in fp[int(fp_off[i]):int(fp_off[i + 1])]:
