@@ -71,7 +71,7 @@ class DeviceOpts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("abi", "compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
                                           "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")] + [
                     # test hooks of the (segment, offset) positions: small segments on small inputs, flat indices beyond 2^32 (lcb.h)
-                    ("seg_cap", C.c_uint64), ("seg_gap", C.c_uint64)]
+                    ("seg_cap", C.c_uint64), ("side_big_cap", C.c_uint32), ("reserved0", C.c_uint32), ("seg_gap", C.c_uint64)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

@@ -1221,6 +1221,7 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
             if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) mode = it->second; }
         }
         if (mode >= 3) L.hOut[i].status = LCB_ST_ABORTED;           // the huge variant does not run here: no result
+        else if (mode == 2 && d->o.side_big_cap && nB >= d->o.side_big_cap) L.hOut[i].status = LCB_ST_ABORTED;   // more heavy speculation than the lane's cap: no result (the plan's order is the order of need)
         else if (mode == 2) listB[nB++] = (uint32_t)i;
         else listW[nW++] = (uint32_t)i;
     }
