@@ -163,7 +163,8 @@ typedef struct {
     uint64_t seg_cap;        /* most junction occurrences per segment; default 2^32 - 2^20. Non-zero: the segment-aware kernels run even
                                 if everything fits one segment (small values cut a small input into many segments) */
     uint32_t side_big_cap;   /* most jobs of one background batch that run in the big variant (seeds known to need it: one workgroup per CU for tens of
-                                milliseconds each); the others get no result there - the commit computes them when it needs them. 0 = no cap */
+                                milliseconds each); the others get no result there - the commit computes them when it needs them. Default: the big-variant slots of a
+                                lane (one wave); 0xFFFFFFFF = no cap */
     uint32_t reserved0;
     uint64_t seg_gap;        /* unused positions between two segments of the device tables (0 = none): with 2^32 the flat indices of a
                                 small input exceed 32 bits, i.e. every 64-bit address computation of the kernels is exercised */

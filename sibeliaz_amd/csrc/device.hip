@@ -602,6 +602,11 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
             d->allocWork(L.wide);
             L.big = d->ws[2]; L.big.base = nullptr; L.big.nSlots = std::max(1u, std::min(o.big_slots, (nCu * 3) / 8));
             d->allocWork(L.big);
+            // A batch runs at most one wave of big-variant jobs (seeds known to need that variant: one workgroup per CU for tens of milliseconds,
+            // 2 GB of workspace writes per launch): beyond it heavy speculation is in the way of the commit's own launches more often than
+            // it is used. Config 3 -8 % per pass, the k = 25 shapes (few such jobs) unchanged; a third of that wave gains nothing
+            // (profiles/r05/ab_eighth_*.txt). The jobs over the cap get no result here: the commit computes them when it needs them.
+            if (!o.side_big_cap) o.side_big_cap = L.big.nSlots;
         }
     } catch (...) {
         lcb_device_destroy_impl(handle);
@@ -1221,7 +1226,7 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
             if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) mode = it->second; }
         }
         if (mode >= 3) L.hOut[i].status = LCB_ST_ABORTED;           // the huge variant does not run here: no result
-        else if (mode == 2 && d->o.side_big_cap && nB >= d->o.side_big_cap) L.hOut[i].status = LCB_ST_ABORTED;   // more heavy speculation than the lane's cap: no result (the plan's order is the order of need)
+        else if (mode == 2 && d->o.side_big_cap != 0xFFFFFFFFu && nB >= d->o.side_big_cap) L.hOut[i].status = LCB_ST_ABORTED;   // more heavy speculation than the lane's cap: no result (the plan's order is the order of need)
         else if (mode == 2) listB[nB++] = (uint32_t)i;
         else listW[nW++] = (uint32_t)i;
     }
