@@ -268,3 +268,59 @@ def test_engine_model_at_scale(built, tmp_path_factory, env):
     assert r.returncode == 0 and "FindBlocks: equal" in r.stderr, r.stderr[-1500:]
 
 
+
+
+def test_segment_plan_maps_positions(built, tmp_path):
+    """csrc/lcb_segments.h: the plan that cuts the flat position space into segments of whole chromosomes and translates between the host's dense
+    positions and the device's (segment, offset) layout - capacities that force a segment per chromosome, chromosomes larger than the capacity,
+    gaps between the segments (toDev / rangeToDev / toHost round trips at every chromosome boundary), and the limits it reports."""
+    src = tmp_path / "segplan.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <string>
+#include "lcb_segments.h"
+void lcb_set_error(const std::string&) {}
+static lcb_graph make(const std::vector<uint64_t>& len) {
+    lcb_graph g; g.chrStart.assign(1, 0);
+    for (uint64_t l : len) { g.chrStart.push_back(g.chrStart.back() + l); g.chrName.push_back("c"); }
+    g.posId.assign((size_t)g.chrStart.back(), 1);
+    return g;
+}
+int main() {
+    int bad = 0;
+    const std::vector<uint64_t> len = {100, 1, 250, 40, 40, 999, 3};
+    const lcb_graph g = make(len);
+    for (uint64_t cap : {0ull, 1ull, 41ull, 100ull, 290ull, 5000ull}) for (uint64_t gap : {0ull, 64ull, 70001ull, (1ull << 32) + 12345}) {
+        const LcbSegPlan p = lcb_plan_segments(g, cap, gap);
+        if (p.segStart.front() != 0 || p.segStart.back() != g.nPos()) bad++;
+        if (cap == 0 && p.nSeg() != 1) bad++;
+        if (cap == 1 && p.nSeg() != len.size()) bad++;                 // a chromosome longer than the capacity gets a segment of its own
+        if (p.devPositions != g.nPos() + (uint64_t)(p.nSeg() - 1) * gap) bad++;
+        for (uint32_t sg = 0; sg < p.nSeg(); sg++) {                   // a segment of several chromosomes holds at most `cap` positions
+            size_t nChr = 0;
+            for (size_t c = 0; c < len.size(); c++) nChr += (p.chrWord[c] >> LCB_SEG_SHIFT) == sg;
+            if (nChr == 0 || (nChr > 1 && cap && p.segStart[sg + 1] - p.segStart[sg] > cap)) bad++;
+        }
+        for (size_t c = 0; c < len.size(); c++) {
+            const uint32_t s = p.chrWord[c] >> LCB_SEG_SHIFT;
+            if ((p.chrWord[c] & LCB_CHR_MASK) != c || s >= p.nSeg()) { bad++; continue; }
+            if (p.segStart[s] + p.chrLo[c] != g.chrStart[c] || p.segStart[s] + p.chrHi[c] != g.chrStart[c + 1]) bad++;      // g bounds of the chromosome in its segment
+            if (p.chrDev[c] != p.segDev[s] + p.chrLo[c] || p.segDev[s] != p.segStart[s] + (uint64_t)s * gap) bad++;
+            for (uint64_t f : {g.chrStart[c], g.chrStart[c] + len[c] / 2, g.chrStart[c + 1] - 1}) {
+                if (p.segOfHost(f) != s) bad++;
+                if (p.toDev(f) != p.segDev[s] + (f - p.segStart[s]) || p.toHost(p.toDev(f)) != f) bad++;
+            }
+            uint64_t lo, hi;
+            p.rangeToDev(g.chrStart[c], g.chrStart[c + 1], lo, hi);      // a whole chromosome: its end may be the next segment's start
+            if (lo != p.chrDev[c] || hi - lo != len[c]) bad++;
+        }
+    }
+    // limits
+    try { lcb_plan_segments(make(std::vector<uint64_t>(40, 10)), 1, 0); bad++; } catch (LcbError&) {}      // 40 segments
+    printf("%d\n", bad);
+    return bad ? 1 : 0;
+}
+''')
+    exe = tmp_path / "segplan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "sibeliaz_amd", "csrc"), str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "0"
