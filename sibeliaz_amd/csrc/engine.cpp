@@ -368,7 +368,10 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // `lazySpan` phases; its speculative launch covers the first roundPhases of them (what the adaptation decided is worth computing
     // against the round-start state), the others have no phase-start result until a dry run asks for one as a job - in the
     // background, against the state predicted for their turn.
-    const int lazySpan = cfg.lazySpan < 0 ? 0 : (cfg.lazySpan ? cfg.lazySpan : 8);
+    // (Only with background batches and predicted views: without side lanes every stop would compute the lazy phases synchronously, without
+    // views against the live state - results that the next commit voids. The randomized emulator campaign found that configuration a
+    // hundred times slower than the round launch it replaces.)
+    const int lazySpan = (!useSide || maxViews <= 0 || cfg.lazySpan < 0) ? 0 : (cfg.lazySpan ? cfg.lazySpan : 8);
     for (int64_t pos = 0; pos < nSeeds;) {
         const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)std::max(roundPhases, std::min(lazySpan, maxRound)) * phase);
         const int64_t nEager = std::min<int64_t>(nRound, (int64_t)roundPhases * phase);     // seeds [nEager, nRound) are lazy
