@@ -196,7 +196,7 @@ def emu_built():
                                             # with a lane for the rest, with batches the lanes refuse (the rest then runs synchronously behind the early jobs), and
                                             # with a processor that refuses the early launch (EMU_NO_EARLY: the stop's own jobs run after the dry run)
                                             ("tandem4", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "3"}),
-                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "3", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4", "LCB_LAZY_SPAN": "8"}),
+                                            ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4", "LCB_LAZY_SPAN": "8"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
