@@ -3,7 +3,7 @@
 `--passes` passes of BlocksFinder::FindBlocks on the GPU and must produce the blocks of the first variant (the knobs never change
 results). Variants that differ in device options get a device of their own.
 
-    python scripts/ab_engine.py --workload ecoli62 base hostc:host_commit=1 sync:sync_jobs=1 jobs512:max_jobs=512 lanes2:dev.side_lanes=2
+    python scripts/ab_engine.py --workload ecoli62 base lazyoff:lazy_span=-1 sync:sync_jobs=1 jobs512:max_jobs=512 lanes2:dev.side_lanes=2
 
 A variant is `name[:knob=value[,knob=value...]]`; knobs prefixed with `dev.` are fields of lcb_device_opts, the others of lcb_hooks.
 One line per variant: seeds/s, ms per pass (best of the passes), kernel time, launches, stops, jobs, side-lane, early-launch and lazy-tail
