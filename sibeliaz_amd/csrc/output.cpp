@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iterator>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -47,6 +49,67 @@ inline char reverseChar(char c)
     switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; }
     return 'N';
 }
+
+// The bases of one chromosome held by the blocks visited so far: disjoint runs [first, second) that never touch (hold() merges
+// neighbours), so that both ends of a run border free positions.
+class HeldRuns {
+    std::map<uint64_t, uint64_t> run;
+    typedef std::map<uint64_t, uint64_t>::iterator It;
+    It covering(uint64_t p, bool& inside)                                                // the run with the largest first <= p
+    {
+        It it = run.upper_bound(p);
+        if (it == run.begin()) { inside = false; return it; }
+        --it;
+        inside = it->second > p;
+        return it;
+    }
+
+public:
+    uint64_t freeAtOrAfter(uint64_t p)                                                   // smallest free position >= p
+    {
+        bool inside;
+        It it = covering(p, inside);
+        return inside ? it->second : p;
+    }
+    bool freeAtOrBefore(uint64_t p, uint64_t& q)                                         // largest free position <= p; false: none
+    {
+        bool inside;
+        It it = covering(p, inside);
+        if (!inside) { q = p; return true; }
+        if (it->first == 0) return false;
+        q = it->first - 1;
+        return true;
+    }
+    void hold(uint64_t lo, uint64_t hi)
+    {
+        if (lo >= hi) return;
+        It it = run.upper_bound(lo);
+        if (it != run.begin()) {
+            It before = std::prev(it);
+            if (before->second >= lo) { lo = before->first; hi = std::max(hi, before->second); it = run.erase(before); }
+        }
+        while (it != run.end() && it->first <= hi) { hi = std::max(hi, it->second); it = run.erase(it); }
+        run.emplace_hint(it, lo, hi);
+    }
+    void release(uint64_t lo, uint64_t hi)
+    {
+        if (lo >= hi) return;
+        It it = run.upper_bound(lo);
+        if (it != run.begin()) {
+            It before = std::prev(it);
+            const uint64_t end = before->second;
+            if (end > lo) {
+                if (before->first == lo) run.erase(before); else before->second = lo;
+                if (end > hi) { run.emplace(hi, end); return; }
+            }
+        }
+        while (it != run.end() && it->first < hi) {
+            const uint64_t end = it->second;
+            it = run.erase(it);
+            if (end > hi) { run.emplace_hint(it, hi, end); return; }
+        }
+    }
+};
 
 void openOrThrow(const std::string& fileName, std::ofstream& stream)                     // TryOpenFile, blocksfinder.cpp:176-183
 {
@@ -122,45 +185,47 @@ void writeSequences(const lcb_graph& g, const std::vector<lcb_block>& block, con
 void lcb_generate_output_impl(const lcb_graph& g, int64_t minBlock, const lcb_block* blocks, int64_t nBlocks, int64_t blocksFound,
                               const std::string& outDir, bool genSeq, int64_t chunks, int64_t* nTrimmed, double* coverage)
 {
-    std::vector<std::vector<bool>> covered(g.nChr());                                    // blocksfinder.h:607-611
-    for (size_t i = 0; i < covered.size(); i++) covered[i].assign(g.seq[i].size() + 1, false);
-    int64_t trimmedId = 1;
-    std::vector<lcb_block> inst(blocks, blocks + nBlocks), buffer, trimmed;
+    // Overlap trimming (blocksfinder.h:605-656): blocks are visited by falling number of copies (ties: rising id, the GroupBy order of
+    // blocksfinder.h:623), and an instance gives up the bases at its two ends that a block visited before it already holds. What the
+    // reference keeps as one flag per base (plus one past the end) is kept here as runs of held bases per chromosome - memory and time
+    // follow the number of block instances, not the genome size - with the flag array's exact outcomes:
+    //  * left end: the first base at or after the start that nobody holds, at most the end;
+    //  * right end: the reference tests the flag AT the end position, not before it: an instance whose following base is free keeps its
+    //    right end even where its last bases are held, otherwise the end moves down to the nearest free position;
+    //  * a block left with a single instance returns the whole range of that instance, bases held before it included.
+    std::vector<HeldRuns> held(g.nChr());
+    int64_t nextId = 1;
+    std::vector<lcb_block> inst(blocks, blocks + nBlocks), kept, trimmed;
     std::vector<int> copies((size_t)blocksFound + 1, 0);
     for (const auto& b : inst) copies[blockId(b)]++;
     SortByMultiplicity pred{copies};
-    std::sort(inst.begin(), inst.end(), pred);                                           // GroupBy, blocksfinder.h:623
-    for (size_t now = 0; now < inst.size();) {
-        const size_t prev = now;
-        for (; now < inst.size() && !pred(inst[prev], inst[now]); now++)
-            ;
-        buffer.clear();
-        for (size_t i = prev; i < now; i++) {                                            // blocksfinder.h:627-639
-            const size_t chr = inst[i].chr;
-            size_t start = inst[i].start, end = inst[i].end;
-            for (; covered[chr][start] && start < end; start++)
-                ;
-            for (; covered[chr][end] && end > start; end--)
-                ;
-            if ((int64_t)(end - start) >= minBlock) {
-                lcb_block t;
-                t.id = (int32_t)((inst[i].id > 0 ? 1 : -1) * trimmedId); t.chr = (uint32_t)chr; t.start = start; t.end = end;
-                buffer.push_back(t);
-                std::fill(covered[chr].begin() + start, covered[chr].begin() + end, true);
-            }
+    std::sort(inst.begin(), inst.end(), pred);                                           // the permutation of equal keys is part of the result
+    for (size_t from = 0, to; from < inst.size(); from = to) {
+        for (to = from + 1; to < inst.size() && !pred(inst[from], inst[to]); to++) {}
+        kept.clear();
+        for (size_t i = from; i < to; i++) {
+            HeldRuns& runs = held[inst[i].chr];
+            const uint64_t lo = std::min<uint64_t>(inst[i].end, runs.freeAtOrAfter(inst[i].start));
+            uint64_t hi;
+            if (!runs.freeAtOrBefore(inst[i].end, hi) || hi < lo) hi = lo;
+            if ((int64_t)(hi - lo) < minBlock) continue;
+            lcb_block t;
+            t.id = (int32_t)(inst[i].id > 0 ? nextId : -nextId); t.chr = inst[i].chr; t.start = lo; t.end = hi;
+            kept.push_back(t);
+            runs.hold(lo, hi);
         }
-        if (buffer.size() > 1) {
-            trimmedId++;
-            trimmed.insert(trimmed.end(), buffer.begin(), buffer.end());
+        if (kept.size() > 1) {
+            nextId++;
+            trimmed.insert(trimmed.end(), kept.begin(), kept.end());
         } else {
-            for (const auto& it : buffer) std::fill(covered[it.chr].begin() + it.start, covered[it.chr].begin() + it.end, false);
+            for (const auto& t : kept) held[t.chr].release(t.start, t.end);
         }
     }
     uint64_t total = 0, totalBlock = 0;                                                  // CalculateCoverage, blocksfinder.cpp:109-124
     for (uint32_t i = 0; i < g.nChr(); i++) total += g.seq[i].size();
     for (const auto& b : trimmed) totalBlock += b.end - b.start;
     if (coverage) *coverage = (double)totalBlock / (double)total;
-    if (nTrimmed) *nTrimmed = trimmedId - 1;
+    if (nTrimmed) *nTrimmed = nextId - 1;
     std::sort(trimmed.begin(), trimmed.end(), blockLess);                                // blocksfinder.h:662
     if (mkdir(outDir.c_str(), 0755) != 0 && errno != EEXIST) throw LcbError("Cannot create dir " + outDir);   // blocksfinder.cpp:15-27
     writeGff(g, trimmed, outDir + "/" + "blocks_coords.gff");

@@ -93,6 +93,63 @@ def test_output_stage_matches_reference(built, case, tmp_path):
     assert open(str(tmp_path / "o" / "blocks_coords.gff")).read() == case.golden("ref.gff")
 
 
+def _random_instances(rnd, lens, n_blocks, style):
+    """Pre-trim block instances that overlap each other the ways the trimming has to tell apart: nested, touching, sharing an end,
+    reaching position 0 or the chromosome's end, single-instance blocks on top of held ranges."""
+    rows = []
+    for bid in range(1, n_blocks + 1):
+        copies = rnd.choice([1, 2, 2, 3, 5]) if style != "singles" else rnd.choice([1, 1, 1, 2])
+        for _ in range(copies):
+            c = rnd.randrange(len(lens))
+            n = lens[c]
+            if style == "dense":                 # few anchor points: equal starts / ends, touching ranges
+                grid = max(1, n // 12)
+                a = rnd.randrange(0, 12) * grid
+                b = min(n, a + rnd.choice([1, 2, 3]) * grid + rnd.choice([0, 0, 1, -1]))
+            else:
+                a = rnd.choice([0, rnd.randrange(n), rnd.randrange(n)])
+                b = rnd.choice([n, min(n, a + rnd.randrange(1, max(2, n // 3)))])
+            if b <= a:
+                b = min(n, a + 1)
+            if b > a:
+                rows.append((bid if rnd.random() < 0.5 else -bid, c, a, b))
+    rnd.shuffle(rows)
+    return rows
+
+
+@pytest.mark.parametrize("style", ["loose", "dense", "singles"])
+def test_output_trimming_on_random_overlaps(built, case, tmp_path, style):
+    """The overlap trimming (held runs per chromosome, output.cpp) against the oracle's flag-per-base restatement of
+    blocksfinder.h:605-656 on random instance lists that overlap far more than real ones: same GFF, bytes and order, same number of
+    blocks and coverage, for several minimal block sizes."""
+    import random
+    import zlib
+    from tests.oracle_binding import ORC_BLOCK, lib
+    st = sibeliaz_amd.JunctionStorage(case.graph, [case.fasta], case.k, 2, case.a)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    lens = [len("".join(rec.split("\n")[1:])) for rec in open(case.fasta).read().split(">")[1:]]
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    L = lib()
+    rnd = random.Random(zlib.crc32((case.name + style).encode()))
+    for trial in range(40):
+        n_blocks = rnd.choice([1, 3, 10, 60, 300])
+        rows = _random_instances(rnd, lens, n_blocks, style)
+        min_block = rnd.choice([1, 1, 7, 50, max(lens) // 20 + 1])
+        blocks = np.array(rows, dtype=sibeliaz_amd.BLOCK_DTYPE)
+        finder.params = sibeliaz_amd.Params.make(case.k, case.b, min_block)
+        out = str(tmp_path / ("p%d" % trial))
+        nt, cov = finder.GenerateOutput(out, blocks=blocks, blocks_found=n_blocks)
+        ob = np.zeros(len(rows), dtype=ORC_BLOCK)
+        for f in ("id", "chr", "start", "end"):
+            ob[f] = blocks[f]
+        oout = str(tmp_path / ("o%d" % trial))
+        ocov, err = C.c_double(), C.create_string_buffer(512)
+        ont = L.orc_generate_output(orc.h, min_block, ob.ctypes.data, len(ob), n_blocks, oout.encode(), C.byref(ocov), err, 512)
+        assert ont >= 0, err.value
+        assert open(out + "/blocks_coords.gff").read() == open(oout + "/blocks_coords.gff").read(), "trial %d (%s, min block %d, %d instances)" % (trial, style, min_block, len(rows))
+        assert (nt, cov) == (ont, ocov.value)
+
+
 class OracleProcessor:
     """TEST stand-in for the device: per-seed results from the CPU oracle (never used by the product)."""
 
