@@ -54,7 +54,9 @@ def case_params(i, small=False):
     gap = rnd.choice(["0", "0", "77", "65536", "100003", "100003", "4300000000", "4300000000"])
     if gap != "0": seg["EMU_SEG_GAP"] = gap
     big = gap == "4300000000"
-    if big: seg["EMU_SEG_MAX"] = "2"               # two or three segments at most: the gapped tables are address space, the bitmap is real memory
+    # big: two or three segments at most (the gapped tables are address space, the bitmap is real memory); otherwise at most about 16 -
+    # the device tables take 32, and many strains x chromosomes with a small cap would ask for more (case 7007: the plan's loud error)
+    seg["EMU_SEG_MAX"] = "2" if big else "16"
     runs.append((rnd.choice(["seeds-init", "seeds-final"]), dict(seg, EMU_NOSTATS="1", EMU_FP_CHECK="1", EMU_LIMIT="600", EMU_NW=rnd.choice(["1", "2"]))))
     if not big: runs.append(("find", dict(seg, EMU_NOSTATS="1", EMU_ROUNDS=rnd.choice(["1", "7", "256"]), EMU_SIDE_LANES=rnd.choice(["1", "3"]), EMU_SIDE_DELAY=rnd.choice(["0", "2"]))))
     return synth, (k, b, m, a), runs, (strains, segs)
