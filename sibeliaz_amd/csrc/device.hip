@@ -494,6 +494,7 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         }
         d->T.posId = d->uploadSeg(g->posId.data(), plan);
         d->T.posPos = d->uploadSeg(g->posPos.data(), plan);
+        { const std::vector<uint32_t> win = lcb_window_table(*g, (uint32_t)p->max_branch); d->T.posWin = d->uploadSeg(win.data(), plan); }   // look-ahead windows (lcb_segments.h)
         d->T.posCh = d->uploadSeg(g->posCh.data(), plan);
         d->T.posRevCh = d->uploadSeg(g->posRevCh.data(), plan);
         if (d->seg) { d->T.occStart64 = d->upload(g->occStart.data(), g->occStart.size()); d->T.occStart32 = nullptr; }

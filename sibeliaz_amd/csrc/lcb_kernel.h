@@ -47,6 +47,12 @@
 #include "lcb_kernel_limits.h"
 
 #define LCB_EMPTY_KEY INT32_MIN
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), see lcb_vote_walk
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LCB_NO_LOADS_IN_FLIGHT() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define LCB_NO_LOADS_IN_FLIGHT() ((void)0)
+#endif
 // A pointer the compiler cannot prove to be a global one (it was merged with a null) is dereferenced with FLAT loads, which wait on
 // two counters and are slower; this says what it is. (Device compiler only: the CPU emulator of the tests sees a plain pointer.)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -102,6 +108,7 @@ struct LcbTables {
     const uint2* chrLoHi;       // [nChr]  the chromosome's positions inside its segment: g in [x, y)
     const int32_t* posId;       // [nPos]  Position::id                  (flat index = segBase[segment] + g)
     const uint32_t* posPos;     // [nPos]  Position::pos
+    const uint32_t* posWin;     // [nPos]  look-ahead window: steps forward (low 16 bits) / backward (high 16) within maxBranch bp inside the chromosome (lcb_window_table)
     const uint8_t* posCh;       // [nPos]  seq[pos + k]              (JunctionSequentialIterator::GetChar, + strand)
     const uint8_t* posRevCh;    // [nPos]  ReverseChar(seq[pos - 1]) or 'N' at pos 0   (- strand)
     const uint32_t* occStart32; // [nVertex+1] CSR over |vertex id| (one segment: fewer than 2^32 occurrences) ...
@@ -667,132 +674,172 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // with the path set in LDS always walk exactly.
 // (Tried and measured slower on the MI355X, profiles/r03: requesting the next chunk of a voter ahead of time with unconditional,
 // straight-line loads - the main wavefront is bound by instruction issue, not by the round trips the prefetch hides.)
-template <class F> struct LcbVoterT { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; F sb; };   // sb: base of the voter's segment
-struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
+// Round 6: the walk knows a voter's window before it reads anything of it. LcbTables::posWin holds, per position, the number of steps in
+// either direction that stay within maxBranch bp (a prefix, because positions ascend strictly inside a chromosome), so the reference's
+// loop test `step < lookingDepth || |pos - pos0| <= maxBranch` (blocksfinder.h:722-727) is `step <= L` with
+// L = min(steps to the chromosome end, max(depth - 1, win)), and the only other thing that ends a walk early - a used position
+// (blocksfinder.h:729-735) - is found lane-parallel over the VOTERS from the few bitmap words their windows cover. After that stage a
+// voter is (origin, direction, number of contributing steps), and the rest of the vote is a flat gather of vertex ids + hash inserts:
+//   stage A  lanes = this wavefront's voters (entry t of the touch list goes to wavefront t mod nWaves): instance fields, window word,
+//            8 bitmap words in walking order - all voters' loads in flight together, ONE round trip - then the contributing steps nv,
+//            the footprint update and the event counter, per lane;
+//   stage B  items (voter, 64-step chunk), LCB_VB of them per round: their id loads are issued back to back (the first LCB_VB voters'
+//            first chunks speculatively, together with the loads of stage A), then consumed one after the other.
+// Until round 5 a wavefront walked one voter after the other, chunk by chunk, each chunk waiting for its own loads (the compiler's
+// s_waitcnt vmcnt(0) at the head of the chunk loop also swallowed the "prefetch" of the next voter): ~1 us per chunk in every
+// variant (profiles/r04/ab_third.txt), i.e. the latency of one global round trip per 64 steps. The path-membership stop
+// (blocksfinder.h:736-741; `exact`) is evaluated per item and shortens the voter's nv for its later items.
+#ifndef LCB_VB
+#define LCB_VB 4
+#endif
+__host__ __device__ inline uint32_t lcb_brev32(uint32_t x)
+{
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);       // v_bfrev_b32
+#else                                       // (g++: the CPU emulator of the tests)
+    uint32_t r = 0;
+    for (int i = 0; i < 32; i++) if (x & (1u << i)) r |= 1u << (31 - i);
+    return r;
+#endif
+}
+#define LCB_BREV32(x) lcb_brev32(x)
+
 template <bool STATS, bool PROF = false, class ST>
-__device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank,
-                                     uint32_t waveId, uint32_t nWaves, bool exact)
+__device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t waveId, uint32_t nWaves, bool exact)
 {
     const LcbTables& T = S.T;
     typedef typename ST::Flat Flat;
-    typedef LcbVoterT<Flat> LcbVoter;
     const uint32_t vmask = S.voteCap - 1;
     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
-    const uint32_t depth = (uint32_t)S.P.depth, maxBranch = (uint32_t)S.P.maxBranch;
-    // the current chunk of 64 touch-list entries (per-lane fields) and the voters still to hand out from it
+    const uint32_t depth = (uint32_t)S.P.depth;
+    const uint32_t dm = depth ? depth - 1u : 0u;                  // steps allowed by `step < lookingDepth` alone
     const uint32_t nTouch = S.nTouch;
-    uint32_t chunkBase = 0, ordinal = 0;
-    unsigned long long pend = 0;
-    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
-    bool scanned = false;
-    const bool tickets = nWaves > 2;
-    auto nextVoter = [&](LcbVoter& v) -> bool {
-        if (tickets) {
-            // one entry of the touch list per draw; its fields are wave-uniform loads (the next voter is drawn while the current one
-            // is walked, so their latency hides behind a walk)
-            for (;;) {
-                uint32_t t = 0;
-                if (S.lane == 0) t = atomicAdd(S.vTicket, 1u);
-                t = lcb_rfl(t);
-                if (t >= nTouch) return false;
-                const uint32_t i = lcb_rfl((uint32_t)S.touch[t]);
-                const uint32_t e = useGood ? lcb_rfl((uint32_t)S.goodPos[i]) : i;      // position in the voting list (its order breaks ties)
-                if (e == ST::NONE) continue;
-                const uint32_t f = lcb_inst_fields(S, i);
-                const uint32_t fl = lcb_rl(f, LCB_F_FLAGS), fp = lcb_rl(f, LCB_F_FRONTPOS), bp = lcb_rl(f, LCB_F_BACKPOS);
-                v.e = e; v.i = i;
-                v.g0 = forward ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG);
-                v.pos0 = forward ? bp : fp;
-                v.lo = lcb_rl(f, LCB_F_LO);
-                const uint32_t hi = lcb_rl(f, LCB_F_HI);
-                v.weight = lcb_absdiff(fp, bp) + 1u;                                   // blocksfinder.h:719
-                v.positive = (fl & LCB_FLAG_POS) != 0;
-                v.dir = (forward == v.positive) ? 1 : -1;
-                v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                      // steps for which it.Valid() holds
-                v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(fl)]) : (Flat)0;
-                return true;
+    const uint32_t maxW = (uint32_t)(T.nPos >> 5);               // (the bitmap has at least nPos / 32 + 2 words)
+    for (uint32_t p0 = 0; p0 * nWaves + waveId < nTouch; p0 += 64) {
+        // (Nothing is in flight here, but the compiler cannot know - its wait-count analysis is conservative around the loops below and
+        // would otherwise wait for "possibly pending" loads between the requests of stage A, one round trip each. Said once, it is free.)
+        LCB_NO_LOADS_IN_FLIGHT();
+        // ---- stage A: one voter per lane
+        const uint32_t t = (p0 + S.lane) * nWaves + waveId;
+        bool isV = false;
+        uint32_t vI = 0, vE = 0, g0 = 0, rem = 0, weight = 0, fl = 0;
+        if (t < nTouch) {
+            vI = S.touch[t];
+            vE = useGood ? (uint32_t)S.goodPos[vI] : vI;          // position in the voting list (its order breaks ties)
+            isV = vE != ST::NONE;
+        }
+        if (isV) {
+            fl = S.iFlags[vI];
+            const uint32_t fp = S.iFrontPos[vI], bp = S.iBackPos[vI];
+            g0 = forward ? S.iBackG[vI] : S.iFrontG[vI];
+            const uint32_t lo = S.iLo[vI], hi = S.iHi[vI];
+            weight = lcb_absdiff(fp, bp) + 1u;                    // blocksfinder.h:719
+            rem = (forward == ((fl & LCB_FLAG_POS) != 0)) ? hi - 1u - g0 : g0 - lo;   // steps for which it.Valid() holds
+        }
+        const bool positive = (fl & LCB_FLAG_POS) != 0, up = forward == positive;
+        Flat sb = 0;
+        if (ST::SEG) sb = (Flat)S.segBase[lcb_fl_seg(fl)];
+        const Flat f0 = sb + g0;
+        const bool walks = isV && rem != 0;
+        uint32_t win = 0;
+        if (walks) win = T.posWin[f0];
+        // IsUsed of step d: + strand bit g, - strand bit g - 1 (none at the chromosome start). The bits of steps 1, 2, ... in walking
+        // order: flat bit fb, then fb + 1, ... (up) or fb - 1, ... (down); 8 words of it cover at least 225 steps.
+        const uint32_t delta = positive ? 0u : 1u;
+        const bool scan = walks && !tryUsed && !(!up && f0 < (Flat)(1u + delta));   // (down from flat position 0 / 1 on the - strand: no step has a bit)
+        const Flat fb = scan ? (up ? f0 + 1u - delta : f0 - 1u - delta) : (Flat)0;
+        uint32_t uw0 = 0, uw1 = 0, uw2 = 0, uw3 = 0, uw4 = 0, uw5 = 0, uw6 = 0, uw7 = 0;
+        if (scan) {
+            const uint32_t W0 = (uint32_t)(fb >> 5);
+            const uint32_t um = up ? 0xFFFFFFFFu : 0u;       // (selects by mask, not by branch: the eight addresses are straight-line code)
+#define LCB_WIDX(k) ((((W0 + (k)) < maxW ? (W0 + (k)) : maxW) & um) | ((W0 - (W0 < (k) ? W0 : (k))) & ~um))
+            uint32_t a0 = LCB_WIDX(0u), a1 = LCB_WIDX(1u), a2 = LCB_WIDX(2u), a3 = LCB_WIDX(3u), a4 = LCB_WIDX(4u), a5 = LCB_WIDX(5u), a6 = LCB_WIDX(6u), a7 = LCB_WIDX(7u);
+#undef LCB_WIDX
+            if (S.U.tab) {
+                const auto tab = LCB_GLOBAL_U32(S.U.tab);
+                const uint32_t o0 = tab[a0 >> LCB_PAGE_SHIFT], o1 = tab[a1 >> LCB_PAGE_SHIFT], o2 = tab[a2 >> LCB_PAGE_SHIFT], o3 = tab[a3 >> LCB_PAGE_SHIFT];
+                const uint32_t o4 = tab[a4 >> LCB_PAGE_SHIFT], o5 = tab[a5 >> LCB_PAGE_SHIFT], o6 = tab[a6 >> LCB_PAGE_SHIFT], o7 = tab[a7 >> LCB_PAGE_SHIFT];
+                a0 += o0; a1 += o1; a2 += o2; a3 += o3; a4 += o4; a5 += o5; a6 += o6; a7 += o7;
+            }
+            uw0 = S.U.live[a0]; uw1 = S.U.live[a1]; uw2 = S.U.live[a2]; uw3 = S.U.live[a3];
+            uw4 = S.U.live[a4]; uw5 = S.U.live[a5]; uw6 = S.U.live[a6]; uw7 = S.U.live[a7];
+        }
+        // ---- the first chunks of the first LCB_VB voters are requested now, before their windows are known
+        unsigned long long pend = __ballot(walks);
+        const unsigned long long walkM = pend;
+        if (PROF) S.pfVoters += (uint32_t)__popcll(walkM);
+        uint32_t itB[LCB_VB], itC[LCB_VB];
+        int32_t itId[LCB_VB];
+        bool itV[LCB_VB];
+        // id of step c * 64 + lane + 1 of voter b (any position of the chromosome stands in for steps beyond its end)
+        auto request = [&](uint32_t b, uint32_t c) -> int32_t {
+            const uint32_t bg = lcb_rl(g0, b), br = lcb_rl(rem, b), bf = lcb_rl(fl, b);
+            const bool bup = forward == ((bf & LCB_FLAG_POS) != 0);
+            const uint32_t d = c * 64 + S.lane + 1;
+            const uint32_t g = d <= br ? (bup ? bg + d : bg - d) : bg;
+            if (ST::SEG) { const Flat bsb = (Flat)lcb_rfl(S.segBase[lcb_fl_seg(bf)]); return (T.posId + bsb)[g]; }
+            return T.posId[g];
+        };
+#pragma unroll
+        for (int q = 0; q < LCB_VB; q++) {
+            itV[q] = pend != 0; itB[q] = 0; itC[q] = 0; itId[q] = 0;
+            if (itV[q]) { itB[q] = (uint32_t)__ffsll((long long)pend) - 1u; pend &= pend - 1; itId[q] = request(itB[q], 0); }
+        }
+        // ---- stage A, second half: contributing steps of every voter
+        uint32_t nv = 0, brk = 0;                                  // steps that vote; 1 if a breaking step (used / in the path) follows them
+        if (walks) {
+            const uint32_t wv = up ? (win & 0xFFFFu) : (win >> 16);
+            uint32_t L = wv > dm ? wv : dm;
+            if (L > rem) L = rem;
+            nv = L;
+            if (scan) {
+                const uint32_t Lu = (!positive && !up && L == rem) ? L - 1u : L;   // the step onto the chromosome's first position reads no bit on the - strand
+                const uint32_t sh = up ? ((uint32_t)fb & 31u) : 31u - ((uint32_t)fb & 31u);
+                if (!up) { uw0 = LCB_BREV32(uw0); uw1 = LCB_BREV32(uw1); uw2 = LCB_BREV32(uw2); uw3 = LCB_BREV32(uw3); uw4 = LCB_BREV32(uw4); uw5 = LCB_BREV32(uw5); uw6 = LCB_BREV32(uw6); uw7 = LCB_BREV32(uw7); }
+                const uint64_t s0 = (uint64_t)uw0 | ((uint64_t)uw1 << 32), s1 = (uint64_t)uw2 | ((uint64_t)uw3 << 32), s2 = (uint64_t)uw4 | ((uint64_t)uw5 << 32), s3 = (uint64_t)uw6 | ((uint64_t)uw7 << 32);
+                const uint64_t x0 = (s0 >> sh) | ((s1 << 1) << (63u - sh)), x1 = (s1 >> sh) | ((s2 << 1) << (63u - sh)), x2 = (s2 >> sh) | ((s3 << 1) << (63u - sh)), x3 = s3 >> sh;
+                const uint32_t have = 256u - sh;                   // steps whose bit is in x0 .. x3
+                const uint32_t n = Lu < have ? Lu : have;
+                uint32_t first = 0;                                // first used step (1-based), 0 = none
+#define LCB_SCAN64(x, base) if (!first && n > (base)) { const uint32_t c_ = n - (base) < 64u ? n - (base) : 64u; const uint64_t m_ = (x) & (c_ == 64u ? ~0ull : ((1ull << c_) - 1ull)); if (m_) first = (base) + (uint32_t)__ffsll((long long)m_); }
+                LCB_SCAN64(x0, 0u) LCB_SCAN64(x1, 64u) LCB_SCAN64(x2, 128u) LCB_SCAN64(x3, 192u)
+#undef LCB_SCAN64
+                for (uint32_t d = have + 1; !first && d <= Lu; d++)    // (windows of more than 225 steps: -b beyond 225)
+                    if (lcb_used_bit(S.U, (Flat)(up ? fb + (d - 1u) : fb - (d - 1u)))) first = d;
+                if (first) { nv = first - 1u; brk = 1u; }
             }
         }
-        for (;;) {
-            while (pend == 0) {
-                if (scanned) chunkBase += 64;
-                scanned = true;
-                if (chunkBase >= nTouch) return false;
-                const uint32_t t = chunkBase + S.lane;
-                bool is = false;
-                if (t < nTouch) {
-                    fI = S.touch[t];
-                    fE = useGood ? (uint32_t)S.goodPos[fI] : fI;          // position in the voting list (its order breaks ties)
-                    is = fE != ST::NONE;
-                    if (is) {
-                        fFl = S.iFlags[fI];
-                        const uint32_t fp = S.iFrontPos[fI], bp = S.iBackPos[fI];
-                        fG = forward ? S.iBackG[fI] : S.iFrontG[fI];
-                        fPos = forward ? bp : fp;
-                        fLo = S.iLo[fI]; fHi = S.iHi[fI];
-                        fW = lcb_absdiff(fp, bp) + 1u;                                       // blocksfinder.h:719
+        if (isV && !tryUsed) {
+            // steps 1 .. nv read used == 0 (the read-out widens by one position for the - strand's bit g - 1)
+            const uint32_t ge = up ? g0 + nv : g0 - nv;
+            const uint32_t fs = lcb_fp_slot(S, vI);
+            atomicMin(&S.fpLo[fs], ge);
+            atomicMax(&S.fpHi[fs], ge);
+        }
+        if (STATS && isV) S.cWalk += nv + brk;                      // loop iterations entered: contributing steps plus the breaking one
+        // ---- stage B: items
+        // one item: steps c * 64 + 1 ... of voter b into the vote table
+        auto consume = [&](uint32_t b, uint32_t c, int32_t id) {
+            if (PROF) S.pfChunks++;
+            const uint32_t bn = lcb_rl(nv, b), bf = lcb_rl(fl, b);
+            const uint32_t d = c * 64 + S.lane + 1;
+            bool act = d <= bn;
+            const int32_t vid = (bf & LCB_FLAG_POS) ? id : -id;
+            if (exact) {
+                const unsigned long long hitM = __ballot(act && lcb_path_contains(S, vid));
+                if (hitM) {
+                    // the walk of this voter ends at its first vertex that is in the path: the steps before it vote, it is the breaking step
+                    const uint32_t fh = (uint32_t)__ffsll((long long)hitM) - 1u;
+                    act = act && S.lane < fh;
+                    if (S.lane == b) {
+                        const uint32_t nn = c * 64 + fh;
+                        if (STATS) S.cWalk += (uint64_t)(nn + 1u) - (uint64_t)(nv + brk);
+                        nv = nn; brk = 1u;
                     }
                 }
-                pend = __ballot(is);
             }
-            const uint32_t b = (uint32_t)__ffsll((long long)pend) - 1u;
-            pend &= pend - 1;
-            const uint32_t o = ordinal++;
-            if (nWaves > 1 && (o % nWaves) != waveId) continue;
-            v.e = lcb_rl(fE, b);
-            v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
-            const uint32_t hi = lcb_rl(fHi, b);
-            v.weight = lcb_rl(fW, b);
-            const uint32_t vfl = lcb_rl(fFl, b);
-            v.positive = (vfl & LCB_FLAG_POS) != 0;
-            v.dir = (forward == v.positive) ? 1 : -1;
-            v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
-            v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(vfl)]) : (Flat)0;
-            return true;
-        }
-    };
-    // The table reads of a pass (pos, id, used word) are independent and issued together; the first pass of the NEXT
-    // voter is issued before the current one is consumed, so its latency hides behind the LDS work of this one.
-    auto issue = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
-        LcbWalk w;
-        const uint32_t d = c * 64 + S.lane + 1;
-        w.valid = d <= v.rem;                                                               // it.Valid()
-        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
-        w.pos = 0; w.id = 0; w.uw = 0;
-        if (w.valid) {
-            // (wave-uniform table base + 32-bit lane offset)
-            w.pos = (T.posPos + v.sb)[w.g];
-            w.id = (T.posId + v.sb)[w.g];
-            // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
-            const Flat ub = v.sb + (w.g - (v.positive ? 0u : 1u));
-            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, (uint32_t)(ub >> 5)) >> ((uint32_t)ub & 31u);
-        }
-        return w;
-    };
-    LcbVoter cur, nxt;
-    LcbWalk wcur, wnxt;
-    bool have = nextVoter(cur);
-    if (have) wcur = issue(cur, 0);
-    while (have) {
-        const bool haveNext = nextVoter(nxt);
-        if (haveNext) wnxt = issue(nxt, 0);
-        for (uint32_t c = 0;; c++) {
-            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
-            if (PROF) S.pfChunks++;
-            const uint32_t d = c * 64 + S.lane + 1;
-            const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
-            const int32_t vid = cur.positive ? w.id : -w.id;
-            const bool stop = cond && ((w.uw & 1u) != 0 || (exact && lcb_path_contains(S, vid)));
-            const unsigned long long failM = __ballot(!cond);
-            const unsigned long long stopM = __ballot(stop);
-            const unsigned long long endM = failM | stopM;
-            const uint32_t first = endM ? (uint32_t)(__ffsll((long long)endM) - 1) : 64u;
-            if (STATS) {
-                // loop iterations entered: contributing steps plus the breaking one (not the failed loop test)
-                const bool breaking = stopM && (uint32_t)(__ffsll((long long)stopM) - 1) == first;
-                if (S.lane < first || (S.lane == first && breaking)) S.cWalk++;
-            }
-            if (S.lane < first) {
+            const uint32_t wgt = lcb_rl(weight, b), e = lcb_rl(vE, b);
+            if (act) {
                 uint32_t h = lcb_hash(vid, S.voteShift);
                 int32_t old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
                 uint32_t probe = 0;
@@ -801,28 +848,43 @@ __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool use
                     old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
                 }
                 if (old == LCB_EMPTY_KEY) {
-                    const uint32_t t = atomicAdd(S.vNClaimed, 1u);
-                    if (t < claimCap) S.vTouched[t] = (typename ST::Idx)h; else *S.vOvf = 1u;
+                    const uint32_t tt = atomicAdd(S.vNClaimed, 1u);
+                    if (tt < claimCap) S.vTouched[tt] = (typename ST::Idx)h; else *S.vOvf = 1u;
                 }
                 if (old == LCB_EMPTY_KEY || old == vid) {
-                    atomicAdd(&S.vCount[h], cur.weight);
-                    atomicMax(&S.vLast[h], ((typename ST::VLast)cur.e << ST::LAST_SHIFT) | d);
+                    atomicAdd(&S.vCount[h], wgt);
+                    atomicMax(&S.vLast[h], ((typename ST::VLast)e << ST::LAST_SHIFT) | d);
                 } else *S.vOvf = 1u;
             }
-            if (first < 64) {
-                if (!tryUsed && S.lane == 0) {
-                    // steps 1 .. c*64+first-1 read used == 0 (one step of slack keeps the - strand's bit g-1 inside)
-                    const uint32_t st = c * 64 + first;
-                    const uint32_t ge = st > cur.rem ? (cur.dir > 0 ? cur.g0 + cur.rem : cur.lo) : (cur.dir > 0 ? cur.g0 + st : cur.g0 - st);
-                    const uint32_t fs = lcb_fp_slot(S, cur.i);
-                    atomicMin(&S.fpLo[fs], ge);
-                    atomicMax(&S.fpHi[fs], ge);
+        };
+        // the items behind the speculative ones, in voter order: chunk 1 ... of the first LCB_VB voters, every chunk of the others
+        unsigned long long rest = walkM;
+        uint32_t curB = 0, curC = 0, curN = 0, ord = 0;
+        bool curOn = false;
+        auto nextItem = [&](uint32_t& b, uint32_t& c) -> bool {
+            for (;;) {
+                if (curOn) {
+                    curN = lcb_rl(nv, curB);                    // (an exact pass may have shortened it)
+                    if (curC * 64 < curN) { b = curB; c = curC++; return true; }
+                    curOn = false;
                 }
-                break;
+                if (!rest) return false;
+                curB = (uint32_t)__ffsll((long long)rest) - 1u; rest &= rest - 1;
+                curC = ord < (uint32_t)LCB_VB ? 1u : 0u; ord++;
+                curOn = true;
             }
+        };
+        for (;;) {
+#pragma unroll
+            for (int q = 0; q < LCB_VB; q++) if (itV[q]) consume(itB[q], itC[q], itId[q]);
+#pragma unroll
+            for (int q = 0; q < LCB_VB; q++) {
+                itV[q] = nextItem(itB[q], itC[q]);
+                itId[q] = 0;
+                if (itV[q]) itId[q] = request(itB[q], itC[q]);
+            }
+            if (!itV[0]) break;
         }
-        if (PROF) S.pfVoters++;
-        have = haveNext; cur = nxt; wcur = wnxt;
     }
 }
 
@@ -912,106 +974,113 @@ __device__ inline void lcb_vote_reduce_slice(ST& S, bool forward, bool useGood, 
 
 // One pass of a vote over the voters of the touch list: walks, arg-max, clearing of the table. `hit`: the pass walked without
 // path stops and one of the vertices it touched is in the path (or the touched list is incomplete) - its result is void.
+// (One call site of the walk and one of the arg-max: the compiler inlines everything into the kernel, and until round 5 a vote's code
+// existed thirteen times per instantiation.)
 template <bool STATS, int NW, bool PROF = false, class ST>
-__device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t nList, int32_t flank, bool exact, bool& ovfAny, bool& hit)
+__device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool useGood, bool exact, bool& ovfAny, bool& hit)
 {
     const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
     LcbBest b;
-    uint32_t nTouched;
     hit = false;
-    if (NW > 1 && S.nTouch > 1) {
+    const bool multi = NW > 1 && S.nTouch > 1;                     // the helper wavefronts take part
+    const bool share = multi && S.nTouch >= LCB_VOTE_SHARE_MIN;    // ... also in the reduction and the clearing
+    if (multi) {
         // wake the helper wavefronts: every wave walks its share of the voters
         if (S.lane == 0) {
-            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (S.nTouch >= LCB_VOTE_SHARE_MIN ? 8u : 0u) | (exact ? 16u : 0u);
-            S.mail[LCB_MAIL_NLIST] = nList; S.mail[LCB_MAIL_FLANK] = (uint32_t)flank; S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
+            S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (share ? 8u : 0u) | (exact ? 16u : 0u);
+            S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
             S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
-            *S.vTicket = 0;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
-        const uint64_t tw0 = PROF ? wall_clock64() : 0;
-        lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, nList, flank, 0, NW, exact);
-        const uint64_t tw1 = PROF ? wall_clock64() : 0;
-        __syncthreads();                                           // B: all walks done
-        const uint64_t tw2 = PROF ? wall_clock64() : 0;
-        if (PROF && !LCB_PROF_PUSH) { S.pfTWalk += tw1 - tw0; S.pfTWaitB += tw2 - tw1; }
-        nTouched = lcb_rfl(*S.vNClaimed);
-        if (nTouched > claimCap) nTouched = claimCap;
-        if (STATS && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
-        if (S.nTouch >= LCB_VOTE_SHARE_MIN) {
-            lcb_vote_reduce_slice<NW>(S, forward, useGood, 0, nTouched, exact);      // contains barriers C and D
-            // final reduction over the NW partial results
-            uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0, pHit = 0;
-            if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; pHit = p[5]; }
-            hit = __ballot(pHit != 0) != 0;
-            b.cnt = lcb_wave_umax(pc);
-            bool c = pc == b.cnt && b.cnt != 0;
-            b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
-            b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
-            const unsigned long long m = __ballot(c);
-            const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
-            b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
-            b.e = lcb_rl(pe, w);
-        } else {
-            hit = !exact && lcb_vote_any_in_path(S, 0, nTouched);
-            b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
-            LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-            lcb_vote_clear(S, 0, nTouched);
-        }
-        if (PROF && !LCB_PROF_PUSH) S.pfTReduce += wall_clock64() - tw2;
-    } else {
-        const uint64_t tw0 = PROF ? wall_clock64() : 0;
-        lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, nList, flank, 0, 1, exact);
-        if (PROF && !LCB_PROF_PUSH) S.pfTWalk += wall_clock64() - tw0;
-        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-        nTouched = lcb_rfl(*S.vNClaimed);
-        if (nTouched > claimCap) nTouched = claimCap;
-        hit = !exact && lcb_vote_any_in_path(S, 0, nTouched);
-        b = lcb_vote_argmax(S, forward, useGood, 0, nTouched);
-        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
-        lcb_vote_clear(S, 0, nTouched);
     }
+    const uint64_t tw0 = PROF ? wall_clock64() : 0;
+    lcb_vote_walk<STATS, PROF>(S, forward, tryUsed, useGood, 0, multi ? (uint32_t)NW : 1u, exact);
+    const uint64_t tw1 = PROF ? wall_clock64() : 0;
+    if (multi) __syncthreads();                                    // B: all walks done
+    else LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+    const uint64_t tw2 = PROF ? wall_clock64() : 0;
+    if (PROF && !LCB_PROF_PUSH) { S.pfTWalk += tw1 - tw0; S.pfTWaitB += tw2 - tw1; }
+    uint32_t nTouched = lcb_rfl(*S.vNClaimed);
+    if (nTouched > claimCap) nTouched = claimCap;
+    if (STATS && multi && S.lane == 0) { S.cWalk += *S.mailWalk; *S.mailWalk = 0; }
+    // wave 0's slice of the touched list: all of it unless the reduction is shared
+    const uint32_t per = share ? (nTouched + NW - 1) / NW : nTouched;
+    const uint32_t s1 = per < nTouched ? per : nTouched;
+    hit = !exact && lcb_vote_any_in_path(S, 0, s1);               // a pass without path stops: is a vertex of this slice in the path?
+    b = lcb_vote_argmax(S, forward, useGood, 0, s1);
+    if (share) {
+        if (S.lane == 0) {
+            uint32_t* p = S.part;
+            p[0] = b.cnt; p[1] = b.keyHi; p[2] = b.keyLo; p[3] = (uint32_t)b.vid; p[4] = b.e; p[5] = hit ? 1u : 0u;
+        }
+        __syncthreads();                                           // C: every slice has been read, partials are visible
+        lcb_vote_clear(S, 0, s1);
+        __syncthreads();                                           // D: the table is clean before wave 0 votes again (possibly on its own)
+        // final reduction over the NW partial results
+        uint32_t pc = 0, ph = 0xFFFFFFFFu, pl = 0xFFFFFFFFu, pv = 0, pe = 0, pHit = 0;
+        if (S.lane < (uint32_t)NW) { const uint32_t* p = S.part + 8 * S.lane; pc = p[0]; ph = p[1]; pl = p[2]; pv = p[3]; pe = p[4]; pHit = p[5]; }
+        hit = __ballot(pHit != 0) != 0;
+        b.cnt = lcb_wave_umax(pc);
+        bool c = pc == b.cnt && b.cnt != 0;
+        b.keyHi = lcb_wave_umin(c ? ph : 0xFFFFFFFFu); c = c && ph == b.keyHi;
+        b.keyLo = lcb_wave_umin(c ? pl : 0xFFFFFFFFu); c = c && pl == b.keyLo;
+        const unsigned long long m = __ballot(c);
+        const uint32_t w = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+        b.vid = m ? (int32_t)lcb_rl(pv, w) : 0;
+        b.e = lcb_rl(pe, w);
+    } else {
+        LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+        lcb_vote_clear(S, 0, s1);
+    }
+    if (PROF && !LCB_PROF_PUSH) S.pfTReduce += wall_clock64() - tw2;
     ovfAny = lcb_rfl(*S.vOvf) != 0;
     if (S.lane == 0) { *S.vNClaimed = 0; *S.vOvf = 0; }
     LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
     return b;
 }
 
+// MostPopularVertex (blocksfinder.h:708-768); the second attempt of the forward extension with `used` positions allowed
+// (blocksfinder.h:782-785, forward only, Q2) is the same code run again: attempts = 2.
 template <bool STATS, bool PROF, int NW, class ST>
-__device__ inline int32_t lcb_vote(ST& S, bool forward, bool tryUsed, uint32_t& originInst)
+__device__ inline int32_t lcb_vote(ST& S, bool forward, uint32_t attempts, uint32_t& originInst)
 {
     const bool useGood = S.nGood >= 2;                             // blocksfinder.h:713
     const uint32_t nList = useGood ? S.nGood : S.nInst;
-    const int32_t flank = forward ? S.rightFlank : S.leftFlank;
-    if (STATS && S.lane == 0) S.cVote++;
-    if (PROF) S.pfVote++;
     originInst = 0;
-    if (nList == 0 || S.nTouch == 0) return 0;                     // nobody votes: nothing to walk, nothing to clear
+    // path set behind a Bloom filter: the first pass walks without path stops and is verified afterwards (lcb_vote_walk)
+    constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
     // (Tried and removed, profiles/r03: handing paths with dozens of voters from the compact to the wide variant through the overflow
     // ladder. With low thresholds 10^5-10^6 seeds of a config-3 pass leave for the one-seed-per-CU wide variant (17-47 % slower); with
     // 32 voters past 1 024 pushes config 3 gains 1 % and the k = 25 workloads, whose repeat families have a hundred voters, lose 8-28 %.)
-    // path set behind a Bloom filter: the first pass walks without path stops and is verified afterwards (lcb_vote_walk)
-    constexpr bool DEFER = LcbCfg<ST::MODE>::BW != 0;
-    const uint64_t cWalk0 = S.cWalk;
-    bool ovfAny = false, hit = false;
-    if (PROF) S.pfTouchSum += S.nTouch;
-    LcbBest b = lcb_vote_pass<STATS, NW, PROF>(S, forward, tryUsed, useGood, nList, flank, !DEFER, ovfAny, hit);
-    if (DEFER && (hit || ovfAny)) {
-        // a touched vertex is in the path (or the table overflowed, so that the touched list is incomplete - a pass with path stops
-        // may touch fewer vertices): the vote as the reference walks it. After an overflow the table may hold stale keys.
-        if (ovfAny) {
-            // (no helper is inside the table: they all wait at barrier A for the next vote)
-            for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
-            LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+    for (uint32_t attempt = 0; attempt < attempts; attempt++) {
+        const bool tryUsed = attempt != 0;
+        if (STATS && S.lane == 0) S.cVote++;
+        if (PROF) S.pfVote++;
+        if (nList == 0 || S.nTouch == 0) continue;                 // nobody votes: nothing to walk, nothing to clear
+        const uint64_t cWalk0 = S.cWalk;
+        bool ovfAny = false, hit = false;
+        if (PROF) S.pfTouchSum += S.nTouch;
+        LcbBest b;
+        for (uint32_t pass = 0;; pass++) {
+            b = lcb_vote_pass<STATS, NW, PROF>(S, forward, tryUsed, useGood, pass != 0 || !DEFER, ovfAny, hit);
+            if (pass != 0 || !DEFER || !(hit || ovfAny)) break;
+            // a touched vertex is in the path (or the table overflowed, so that the touched list is incomplete - a pass with path stops
+            // may touch fewer vertices): the vote as the reference walks it. After an overflow the table may hold stale keys.
+            if (ovfAny) {
+                // (no helper is inside the table: they all wait at barrier A for the next vote)
+                for (uint32_t h = S.lane; h < S.voteCap; h += 64) { S.vKey[h] = LCB_EMPTY_KEY; S.vCount[h] = 0; S.vLast[h] = 0; }
+                LCB_SYNC_IF(LcbCfg<ST::MODE>::IDX_LDS);
+            }
+            if (STATS) S.cWalk = cWalk0;
+            if (PROF) S.pfMaxProbe++;             // (instrumented variant: number of repeated votes)
         }
-        if (STATS) S.cWalk = cWalk0;
-        if (PROF) S.pfMaxProbe++;             // (instrumented variant: number of repeated votes)
-        b = lcb_vote_pass<STATS, NW, PROF>(S, forward, tryUsed, useGood, nList, flank, true, ovfAny, hit);
+        if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
+        if (b.cnt == 0) continue;
+        originInst = useGood ? lcb_rfl((uint32_t)S.good[b.e]) : b.e;
+        return b.vid;
     }
-    if (ovfAny) { S.status = LCB_ST_VOTE_OVF; return 0; }
-    if (b.cnt == 0) return 0;
-    originInst = useGood ? lcb_rfl((uint32_t)S.good[b.e]) : b.e;
-    return b.vid;
+    return 0;
 }
 
 // One occurrence of the pushed vertex: its record plus the three `used` words around it, so that IsUsed and (almost
@@ -1499,13 +1568,9 @@ __device__ inline bool lcb_extend(ST& S, uint32_t& bestRightSize, int64_t& bestS
     const uint64_t tv0 = PROF ? wall_clock64() : 0;
     // an asynchronous batch nobody waits for any more gives up here (the word is read past the L1: another stream writes it)
     if (S.abort && lcb_rfl(__hip_atomic_load(S.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) { S.status = LCB_ST_ABORTED; return false; }
-    int32_t next = lcb_vote<STATS, PROF, NW>(S, FORWARD, false, oi);
+    const int32_t next = lcb_vote<STATS, PROF, NW>(S, FORWARD, FORWARD ? 2u : 1u, oi);    // (forward: a second attempt over used positions, blocksfinder.h:782-785, Q2)
     LCB_MARK(S, 6, 2); LCB_MARK(S, 7, (uint32_t)next);
     if (S.status) return false;
-    if (FORWARD && next == 0) {                                      // blocksfinder.h:782-785 (forward only, Q2)
-        next = lcb_vote<STATS, PROF, NW>(S, true, true, oi);
-        if (S.status) return false;
-    }
     if (PROF) S.pfTVote += wall_clock64() - tv0;
     bool success = false;
     if (next != 0) {
@@ -1767,8 +1832,7 @@ __device__ inline void lcb_process_body(const LcbTables& T, const LcbKParams& P,
                 S.nTouch = lcb_rfl(S.mail[LCB_MAIL_NTOUCH]);
                 S.fpSplit = lcb_rfl(S.mail[LCB_MAIL_FPSPLIT]); S.fpShift = lcb_rfl(S.mail[LCB_MAIL_FPSHIFT]);
                 S.cWalk = 0;
-                lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, lcb_rfl(S.mail[LCB_MAIL_NLIST]),
-                                     (int32_t)lcb_rfl(S.mail[LCB_MAIL_FLANK]), waveId, NW, (flags & 16u) != 0);
+                lcb_vote_walk<STATS>(S, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 4u) != 0, waveId, NW, (flags & 16u) != 0);
                 if (STATS) {
                     const unsigned long long w = (unsigned long long)lcb_wave_sum((int64_t)S.cWalk);
                     if (S.lane == 0 && w) atomicAdd(S.mailWalk, w);

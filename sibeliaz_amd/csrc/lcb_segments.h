@@ -69,4 +69,37 @@ inline LcbSegPlan lcb_plan_segments(const lcb_graph& g, uint64_t cap, uint64_t g
     return p;
 }
 
+// The look-ahead window of every position (round 6): MostPopularVertex walks from a voter's end while `step < lookingDepth ||
+// |pos - pos0| <= maxBranchSize` (blocksfinder.h:722-727). Positions ascend strictly inside a chromosome, so the steps that satisfy the
+// distance bound are a prefix: win[q] = (steps backward << 16) | steps forward that stay inside q's chromosome and within maxBranch bp
+// of pos[q]. With it a voter's window length is known before anything is walked - min(steps to the chromosome end, max(depth - 1,
+// win)) - and the walk needs neither Position::pos nor a step-by-step loop test (lcb_vote_walk). A property of (graph, maxBranch);
+// host positions, uploaded like the other per-position tables.
+inline std::vector<uint32_t> lcb_window_table(const lcb_graph& g, uint32_t maxBranch)
+{
+    const uint64_t P = g.nPos();
+    std::vector<uint32_t> win((size_t)P);
+    const int64_t C = (int64_t)g.nChr();
+    const uint64_t BLK = 1u << 16;
+    const int64_t nBlk = (int64_t)((P + BLK - 1) / BLK);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t bk = 0; bk < nBlk; bk++) {
+        const uint64_t q0 = (uint64_t)bk * BLK, q1 = std::min(P, q0 + BLK);
+        int64_t c = (int64_t)(std::upper_bound(g.chrStart.begin(), g.chrStart.end(), q0) - g.chrStart.begin()) - 1;
+        for (uint64_t q = q0; q < q1; q++) {
+            while (c + 1 < C && g.chrStart[(size_t)c + 1] <= q) c++;
+            const uint64_t s = g.chrStart[(size_t)c], e = g.chrStart[(size_t)c + 1];
+            const uint64_t pq = g.posPos[q];
+            // forward: the last j in [q, e) with pos[j] <= pos[q] + maxBranch (positions differ by at least one per step)
+            const uint64_t fe = std::min(e, q + (uint64_t)maxBranch + 1);
+            const uint64_t f = (uint64_t)(std::upper_bound(g.posPos.begin() + q, g.posPos.begin() + fe, (uint32_t)std::min<uint64_t>(pq + maxBranch, 0xFFFFFFFFull)) - (g.posPos.begin() + q)) - 1;
+            // backward: the first j in [s, q] with pos[j] >= pos[q] - maxBranch
+            const uint64_t bs = q - s > (uint64_t)maxBranch ? q - maxBranch : s;
+            const uint64_t b = q - (uint64_t)(std::lower_bound(g.posPos.begin() + bs, g.posPos.begin() + q + 1, (uint32_t)(pq > maxBranch ? pq - maxBranch : 0)) - g.posPos.begin());
+            win[(size_t)q] = (uint32_t)std::min<uint64_t>(f, 0xFFFF) | ((uint32_t)std::min<uint64_t>(b, 0xFFFF) << 16);
+        }
+    }
+    return win;
+}
+
 #endif

@@ -71,7 +71,7 @@ struct Emu {
     bool seg = false;
     std::vector<uint2> chrLoHi;
     std::vector<uint32_t> occStart32;
-    DevTable<int32_t> dPosId; DevTable<uint32_t> dPosPos; DevTable<uint8_t> dPosCh, dPosRevCh;
+    DevTable<int32_t> dPosId; DevTable<uint32_t> dPosPos, dPosWin; std::vector<uint32_t> winHost; DevTable<uint8_t> dPosCh, dPosRevCh;
     std::vector<uint32_t> used;                  // used: the live bitmap (view 0) over the device's flat index, padded to whole pages, followed by the private pages of the views
     std::vector<uint32_t> viewTab;               // predicted views: page tables (word offset from a live page to the view's copy, 0 = shared)
     size_t usedWords = 0, nPages = 0;
@@ -108,6 +108,7 @@ struct Emu {
         dPosId.set(g->posId.data(), plan); dPosPos.set(g->posPos.data(), plan); dPosCh.set(g->posCh.data(), plan); dPosRevCh.set(g->posRevCh.data(), plan);
         T.chrLoHi = chrLoHi.data(); T.segBase = plan.segDev.data(); T.posId = dPosId.p; T.posPos = dPosPos.p;
         T.posCh = dPosCh.p; T.posRevCh = dPosRevCh.p;
+        winHost = lcb_window_table(*g, (uint32_t)p.max_branch); dPosWin.set(winHost.data(), plan); T.posWin = dPosWin.p;
         occStart32.assign(g->occStart.begin(), g->occStart.end());       // (one segment: fewer than 2^32 occurrences)
         T.occStart32 = seg ? nullptr : occStart32.data(); T.occStart64 = seg ? g->occStart.data() : nullptr;
         occRec.resize(g->nPos());
