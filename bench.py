@@ -75,6 +75,10 @@ WORKLOADS = {
     "primates8_4g": dict(synth="--strains 8 --chromosomes 24 --segments 5600 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "
                                "--indel 0.001 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1003",
                          k=25, b=200, m=50, a=150, desc="8 synthetic strains x 24 chromosomes (4.1 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 4, scaled]"),
+    # config 5's shape at the same scale: 16 x 20 chromosomes x ~13 Mbp = 4.1 Gbp (2 720 segments); reference hash in tests/golden/fullsize_scaled.json
+    "mice16_4g": dict(synth="--strains 16 --chromosomes 20 --segments 2720 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.005 "
+                            "--indel 0.0005 --filler-frac 0.25 --filler-min 200 --filler-max 3000 --repeat-families 20 --repeat-copies 100 --repeat-len 800 --seed 1004",
+                      k=25, b=200, m=50, a=150, desc="16 synthetic strains x 20 chromosomes (4.1 Gbp), k=25, b=200, m=50, a=150 [SURVEY.md §8d config 5, scaled]"),
     # the same two shapes at the size of a parity test (tests/test_gpu_fullsize.py; the reference needs ~20 s for each on 8 cores):
     # 8 x 24 chromosomes = 186 Mbp at 1 % divergence, 16 x 20 chromosomes = 217 Mbp at 0.5 %
     "primates8_test": dict(synth="--strains 8 --chromosomes 24 --segments 240 --seg-min 5000 --seg-max 200000 --keep 0.9 --swap 0.05 --invert 0.05 --sub 0.01 "
@@ -191,6 +195,45 @@ def our_gff(w, threads, dev_ordinal=0):
     return os.path.join(out, "blocks_coords.gff")
 
 
+def cpu_baseline_quick(workload, threads, our_gff_path, limit_s=120.0):
+    """The bounded leg of a `secondary` entry: ONE run of the unmodified reference at -t 32 on the WHOLE workload (the k = 25 test shapes take it
+    ~10 s), its GFF compared with the timed run's."""
+    host = os.cpu_count() or 1
+    t32 = min(32, host)
+    whole = ensure_workload(workload)
+    s_whole = n_seeds_of(whole, threads)
+    r = run_reference(whole, t32, "t%d_whole" % t32, limit_s)
+    if r is None or r == "timeout":
+        return None
+    return {"value": s_whole / r[0], "unit": "seeds/s", "cores": t32, "kind": "reference", "gff_md5_equal": md5(r[2]) == md5(our_gff_path),
+            "sample": "the WHOLE benchmarked workload, %s: unmodified reference sibeliaz-lcb (g++ -O3 -DNDEBUG -fopenmp) at -t %d, 1 run, 'Analyzing' to 'Generating' banner "
+                      "%.2f s (includes its serial seed enumeration), whole process %.2f s; host has %d hardware threads" % (whole["desc"], t32, r[0], r[1], host)}
+
+
+def secondary_live(names, threads, no_cpu=False):
+    """The other shapes of BASELINE.json, timed by THIS run: `bench.py --workload <name> --steps 3 --warmup 1 --secondary-leg` as a child process each
+    (its own device and tables; the parent's are closed by then), its line condensed into one entry."""
+    out = []
+    for name in names:
+        t = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "3", "--warmup", "1", "--no-cli", "--secondary-leg",
+                                "--threads", str(threads)] + (["--no-cpu-baseline"] if no_cpu else []), capture_output=True, text=True, timeout=420)
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:       # a secondary entry must never cost the line itself
+            out.append({"workload": name, "measured_in_this_run": True, "error": repr(e)})
+            continue
+        cb = line.get("cpu_baseline")
+        out.append({"what": WORKLOADS[name]["desc"], "workload": name, "measured_in_this_run": True, "value": line["value"], "unit": line["unit"],
+                    "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"], "seeds": line["config"]["seeds"],
+                    "blocks_found": line["config"]["blocks_found"],
+                    "roofline": {k: line["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "algorithmic_bytes_per_step",
+                                                                  "launches_per_step", "per_kernel", "frac_of_measured_peak")},
+                    "cpu_baseline": cb, "speedup_over_cpu_baseline": line["value"] / cb["value"] if cb else None,
+                    "sources": source_hash(), "wall_s_of_this_entry": time.time() - t})
+    return out
+
+
 def cpu_baseline(workload, threads, full, our_gff_path, budget_s=600.0):
     """SURVEY.md §8d protocol, every leg bounded: the reference on bounded samples at -t 1 / -t 32 / -t 64 / -t <all hardware threads>
     (median of 3, analyze time banner to banner; its GFF on the -t 32 sample must equal ours) and ONE run at -t 32 on the WHOLE
@@ -293,6 +336,8 @@ def main():
     ap.add_argument("--device-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: a field of lcb_device_opts (e.g. path_cap=8192)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="FIELD=VALUE", help="A/B: an engine field of lcb_hooks (e.g. max_jobs=256)")
     ap.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--no-secondary", action="store_true", help="skip the live lines of the k = 25 shapes (configs 4 / 5 at test size) that a default run appends")
+    ap.add_argument("--secondary-leg", action="store_true", help="(internal) this process times one `secondary` entry: one bounded reference leg, no entries of its own")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -365,6 +410,7 @@ def main():
         step()
     if dev is not None:
         dev.kernel_time()
+    mode_t0 = dev.mode_time() if dev is not None else None
     sync()
     t0 = time.time()
     last = None
@@ -379,6 +425,7 @@ def main():
         plan_ms += last[1]["plan_ms"]
     sync()
     elapsed = time.time() - t0
+    mode_t1 = dev.mode_time() if dev is not None else None
     if world > 1:
         tmax = torch.tensor([elapsed, kernel_ms, float(launches), kernel_busy_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -436,14 +483,31 @@ def main():
         triad = dev.hbm_triad() if dev is not None else 0.0
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same command
         # (scripts/gpu_r2_evidence.sh), committed with the profile summaries; only for the workload they were taken on
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
-        if args.workload == "ecoli62" and n_gpus == 1 and os.path.exists(pmc_file):
+        traffic, traffic_src, pmc = None, None, None
+        pmc_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r06", "r05")) if os.path.exists(f)), None)
+        if args.workload == "ecoli62" and n_gpus == 1 and pmc_file:
             pmc = json.load(open(pmc_file))
             traffic = pmc["hbm_bytes_per_launch"]
-            traffic_src = ("profiles/r05/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs) of `bench.py --steps 1 --warmup 0` on this workload, "
-                           "FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md), per process-kernel launch; counted on a build of kernel sources %s, this build is %s"
-                           % (pmc.get("kernel_source_hash"), source_hash()))
+            traffic_src = {"file": os.path.relpath(pmc_file, ROOT), "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs) of `bench.py --steps 1 --warmup 0` on this "
+                           "workload, FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md), per process-kernel launch",
+                           "source_hash_of_that_build": pmc.get("kernel_source_hash"), "source_hash_of_this_build": source_hash(),
+                           "same_sources": pmc.get("kernel_source_hash") == source_hash()}
+        # per kernel variant: launches and hipEvent-timed kernel time of the timed region (all streams); HBM bytes from the PMC passes where they are of
+        # this build's sources (the reference-semantics event counts are per seed, not per variant: the algorithmic figure stays a whole-pass one)
+        per_kernel = None
+        if mode_t0 is not None and mode_t1 is not None:
+            per_kernel = {}
+            pk_bytes = (pmc or {}).get("per_kernel_hbm_bytes_per_step") if pmc and pmc.get("kernel_source_hash") == source_hash() else None
+            for i, nm in enumerate(("compact", "wide", "big", "huge")):
+                ms_k = (mode_t1[0][i] - mode_t0[0][i]) / args.steps
+                n_k = (mode_t1[1][i] - mode_t0[1][i]) / float(args.steps)
+                if n_k == 0:
+                    continue
+                b_k = pk_bytes.get(nm) if pk_bytes else None
+                per_kernel["lcb_process_kernel<%s>" % nm] = {
+                    "calls_per_step": n_k, "ms_per_step": ms_k, "avg_launch_ms": ms_k / n_k, "share_of_kernel_ms": ms_k / max(1e-9, kernel_ms / args.steps),
+                    "hbm_bytes_per_step": b_k, "achieved_gb_s": (b_k / (ms_k / 1000.0) / 1e9) if b_k and ms_k > 0 else None,
+                    "frac": (b_k / (ms_k / 1000.0) / 1e9 / HBM_PEAK_GBS) if b_k and ms_k > 0 else None}
         line = {
             "metric": "seed vertices/sec through BlocksFinder", "value": value, "unit": "seeds/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -471,6 +535,7 @@ def main():
                          "algorithmic_bytes_per_step": abytes, "kernel_ms_per_step": kernel_busy_ms / args.steps, "bytes_per_seed": abytes / S,
                          "kernel_ms_sum_over_streams_per_step": kernel_ms / args.steps, "kernel_ms_on_side_lanes_per_step": kernel_side_ms / args.steps,
                          "event_counts_source": counts_src if not args.no_roofline else None,
+                         "per_kernel": per_kernel,
                          "peak_measured_stream_triad": triad, "frac_of_measured_peak": achieved / triad if triad > 0 else None,
                          "event_counts": ctr,
                          "note": "latency-bound integer walk: a launch is as long as its longest seed; the event counts of the named workloads are the CPU oracle's at full size "
@@ -493,16 +558,22 @@ def main():
                                   "gff_md5_equal_to_timed_run": r.returncode == 0 and md5(os.path.join(cli_out, "blocks_coords.gff")) == md5(gff)}
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload in SAMPLES:
             try:
-                cb = cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff, args.cpu_baseline_budget)
+                cb = cpu_baseline_quick(args.workload, args.threads, gff) if args.secondary_leg else cpu_baseline(args.workload, args.threads, not args.sample_cpu_baseline, gff, args.cpu_baseline_budget)
                 if cb:
                     line["cpu_baseline"] = cb
             except Exception as e:       # the reference's legs must never cost the line itself
                 line["cpu_baseline_error"] = repr(e)
-        # the other shapes of BASELINE.json on the scoreboard: lines of the same bench.py on the same build, run in the round's evidence call
-        # (scripts/r05/gpu_r5_evidence.sh) and committed with their logs - builder-run, not timed in this process
-        sec_file = os.path.join(ROOT, "profiles", "r05", "secondary.json")
-        if args.workload == "ecoli62" and os.path.exists(sec_file):
-            line["secondary"] = json.load(open(sec_file))
+        # the other shapes of BASELINE.json on the scoreboard. The k = 25 shapes (configs 4 / 5 at test size) are timed LIVE by this run, each with its own
+        # roofline and a whole-workload reference leg ("measured_in_this_run": true). Entries of the round's evidence run (other workloads: a = 868, the
+        # Gbp-scale shapes) are attached from profiles/ only if they were measured on a build of THESE sources, and say "measured_in_this_run": false.
+        if args.workload == "ecoli62" and n_gpus == 1 and not args.no_secondary and not args.secondary_leg:
+            sec = secondary_live(("primates8_test", "mice16_test"), args.threads, args.no_cpu_baseline)
+            sec_file = os.path.join(ROOT, "profiles", "r06", "secondary.json")
+            if os.path.exists(sec_file):
+                for e in json.load(open(sec_file)):
+                    if e.get("sources") == source_hash() and e.get("workload") not in ("primates8_test", "mice16_test"):
+                        sec.append(dict(e, measured_in_this_run=False))
+            line["secondary"] = sec
         print(json.dumps(line), flush=True)
     if world > 1:
         comm.close()

@@ -103,6 +103,7 @@ typedef struct {
                                    (kernel_ms is their SUM; the side lanes' kernels run beside the synchronous ones, so the sum can exceed the pass) */
     double kernel_side_ms;      /* the part of kernel_ms that ran on the side lanes' streams */
     int64_t lazy_seeds;         /* seeds in the lazy tails of the rounds: no speculative launch, their phase-start results are background jobs (lcb_hooks.lazy_span) */
+    int64_t host_dead;          /* results settled on the host without the device: no unused occurrence of the seed's vertex carries its character (lcb_hooks.sparse_rounds) */
 } lcb_stats;
 
 /* Message of the last failing call on this thread. */
@@ -111,7 +112,7 @@ const char* lcb_last_error(void);
 const char* lcb_version(void);
 /* Layout version of the structs of this header (lcb_stats, lcb_hooks, lcb_device_opts): they are allocated by the caller, so a caller
  * built against another LCB_ABI_VERSION must not call in. lcb_abi_version() returns the library's. */
-#define LCB_ABI_VERSION 5
+#define LCB_ABI_VERSION 6
 int lcb_abi_version(void);
 
 /* ---- graph: JunctionStorage::Init (junctionstorage.h:572-650), junctionapi.h:80-98, streamfastaparser.cpp:28-92 */
@@ -173,6 +174,9 @@ lcb_device* lcb_device_create_ex(const lcb_graph* g, const lcb_params* p, int de
 /* Seeds handed to the compact / wide / big / huge kernel variant since the device was created (a seed that overflows
  * one variant is counted again in the next). */
 int lcb_device_mode_seeds(lcb_device* d, int64_t counts[4]);
+/* hipEvent-timed kernel time (ms) and launches of the compact / wide / big / huge variant since the device was created, over all of its
+ * streams (measurement: bench.py's roofline.per_kernel; the background batches of the side lanes count when they retire). */
+int lcb_device_mode_time(lcb_device* d, double ms[4], int64_t launches[4]);
 void lcb_device_destroy(lcb_device* d);
 /* `used` bits (Position::used, junctionstorage.h:144) live in HBM as a bitmap over g. */
 int lcb_device_reset_used(lcb_device* d);
@@ -184,7 +188,7 @@ int lcb_device_set_used(lcb_device* d, const uint32_t* words, int64_t n_words);
 int lcb_device_set_stats_mode(lcb_device* d, int on);
 
 /* THE HOT PATH: ProcessVertex::Process (blocksfinder.h:228-310) for a batch of seeds, each against the
- * device's current `used` state, one seed per wavefront. offsets has n+1 entries; the instances of seed
+ * device's current `used` state, one seed per workgroup (wavefront 0 runs the seed, the others share its look-ahead votes). offsets has n+1 entries; the instances of seed
  * i are inst[offsets[i] .. offsets[i+1]). Returns LCB_OK, or LCB_ERR (e.g. inst_cap too small: the needed
  * capacity is then in offsets[n]). best_score and ctr may be NULL. */
 int lcb_process_seeds(lcb_device* d, const lcb_seed* seeds, int64_t n, uint64_t* offsets,
@@ -258,6 +262,11 @@ typedef struct {
     int32_t lazy_span;          /* a round spans at least this many phases: the phases beyond the (adaptive) size of its speculative launch get their
                                    phase-start results as background jobs against predicted views, planned while the commit works through the stops of the
                                    phases in front of them. Default 8; -1 = off (a round is exactly its speculative launch) */
+    int32_t sparse_rounds;      /* sparse speculative launches (round 6): seeds sorted next to each other lie next to each other in the genome
+                                   (Bundle::operator<, blocksfinder.h:195-208), so the seeds behind the first one of a collinear stretch are dead
+                                   by the time their phase starts - a round launches only the seeds of the FIRST phase of every such cluster and
+                                   spans as many phases as that takes; the others are resolved on the host when their phase starts (no unused
+                                   occurrence: empty result) or computed then. Default (0) on, -1 = off */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

@@ -67,10 +67,10 @@ def main():
                 print("%s: BLOCKS DIFFER from the first variant" % name, flush=True)
         dt, st = best
         print("%s: %.0f seeds/s, %.1f ms, kernel(sum) %.1f ms, launches %d, stops %d, jobs %d (used %d) | side batches %d jobs %d taken %d void %d failed %d | early %d | "
-              "lazy seeds %d | host ms: processor %.0f dry runs %.0f other %.0f" % (
+              "lazy seeds %d host-settled %d | host ms: processor %.0f dry runs %.0f other %.0f" % (
                   name, len(seeds) / dt, 1000 * dt, st["kernel_ms"], st["launches"], st["recompute_launches"], st["recomputed_seeds"], st["jobs_used"],
                   st["side_batches"], st["side_jobs"], st["side_taken"], st["side_void"], st["side_failed"], st.get("early_critical", 0),
-                  st.get("lazy_seeds", 0), st["process_ms"], st["plan_ms"], 1000 * dt - st["process_ms"] - st["plan_ms"]), flush=True)
+                  st.get("lazy_seeds", 0), st.get("host_dead", 0), st["process_ms"], st["plan_ms"], 1000 * dt - st["process_ms"] - st["plan_ms"]), flush=True)
     for d in devices.values():
         d.close()
 

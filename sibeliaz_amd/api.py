@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
                 ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [
                     (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "early_critical")] + [
-                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64)]
+                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64), ("host_dead", C.c_int64)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -47,7 +47,7 @@ MARK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 RESET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
-ABI_VERSION = 5        # LCB_ABI_VERSION of include/lcb.h: layout of Stats, Hooks, DeviceOpts (Hooks / DeviceOpts carry it in their first field)
+ABI_VERSION = 6        # LCB_ABI_VERSION of include/lcb.h: layout of Stats, Hooks, DeviceOpts (Hooks / DeviceOpts carry it in their first field)
 
 
 class Hooks(C.Structure):
@@ -56,14 +56,14 @@ class Hooks(C.Structure):
                 ("round_phases", C.c_int32), ("progress", C.c_int32),
                 # engine tuning (0 = default; results never depend on it)
                 ("round_fixed", C.c_int32), ("eager_phases", C.c_int32), ("max_views", C.c_int32), ("max_jobs", C.c_int32),
-                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("lazy_span", C.c_int32)]
+                ("predict_f", C.c_int32), ("exchange_always", C.c_int32), ("count_events", C.c_int32), ("sync_jobs", C.c_int32), ("lazy_span", C.c_int32), ("sparse_rounds", C.c_int32)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.abi = ABI_VERSION
 
 
-ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "lazy_span")
+ENGINE_KNOBS = ("round_phases", "round_fixed", "eager_phases", "max_views", "max_jobs", "predict_f", "exchange_always", "count_events", "sync_jobs", "lazy_span", "sparse_rounds")
 
 
 class DeviceOpts(C.Structure):
@@ -92,7 +92,7 @@ _lib = None
 EXPORTS = [
     "lcb_last_error", "lcb_version", "lcb_abi_version", "lcb_graph_load", "lcb_graph_free", "lcb_graph_n_chr", "lcb_graph_n_pos", "lcb_graph_n_vertices",
     "lcb_graph_chr_len", "lcb_graph_chr_n_pos", "lcb_graph_chr_name", "lcb_graph_chr_start", "lcb_graph_pos_id", "lcb_graph_pos_pos",
-    "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
+    "lcb_enumerate_seeds", "lcb_free", "lcb_device_create", "lcb_device_create_ex", "lcb_device_mode_seeds", "lcb_device_mode_time", "lcb_device_destroy", "lcb_device_reset_used", "lcb_device_mark_used",
     "lcb_device_set_used", "lcb_device_set_stats_mode", "lcb_device_hbm_triad", "lcb_process_seeds", "lcb_process_seeds_fp", "lcb_device_kernel_time", "lcb_committer_create",
     "lcb_committer_free", "lcb_committer_commit_phase", "lcb_committer_take_marks", "lcb_committer_n_blocks", "lcb_committer_blocks",
     "lcb_committer_blocks_found", "lcb_committer_failures", "lcb_committer_used_words", "lcb_find_blocks", "lcb_find_blocks_ex",
@@ -138,6 +138,8 @@ def load_library():
     L.lcb_device_create_ex.restype = vp
     L.lcb_device_create_ex.argtypes = [vp, C.POINTER(Params), C.c_int, C.POINTER(DeviceOpts)]
     L.lcb_device_mode_seeds.argtypes = [vp, C.POINTER(i64)]
+    if hasattr(L, "lcb_device_mode_time"):      # (an A/B library of an earlier round, LCB_LIB, lacks it)
+        L.lcb_device_mode_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.lcb_device_destroy.argtypes = [vp]
     L.lcb_device_reset_used.argtypes = [vp]
     L.lcb_device_mark_used.argtypes = [vp, vp, i64]
@@ -273,6 +275,13 @@ class Device:
         if self.L.lcb_device_mode_seeds(self.h, out):
             raise _err(self.L)
         return tuple(int(x) for x in out)
+
+    def mode_time(self):
+        """(ms, launches) of the (compact, wide, big, huge) kernel variants since creation: hipEvent-timed, all streams."""
+        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        if self.L.lcb_device_mode_time(self.h, ms, n):
+            raise _err(self.L)
+        return tuple(float(x) for x in ms), tuple(int(x) for x in n)
 
     def close(self):
         if getattr(self, "h", None):

@@ -35,7 +35,7 @@ LcbEngineConfig tuningOf(const lcb_hooks* hooks)
     if (hooks) {
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span; cfg.sparseRounds = hooks->sparse_rounds;
     }
     return cfg;
 }
@@ -111,6 +111,14 @@ int lcb_device_mode_seeds(lcb_device* d, int64_t counts[4])
     LCB_TRY
     if (!d || !counts) throw LcbError("lcb_device_mode_seeds: null argument");
     lcb_device_mode_seeds_impl(d, counts);
+    return LCB_OK;
+    LCB_CATCH(LCB_ERR)
+}
+int lcb_device_mode_time(lcb_device* d, double ms[4], int64_t launches[4])
+{
+    LCB_TRY
+    if (!d || !ms || !launches) throw LcbError("lcb_device_mode_time: null argument");
+    lcb_device_mode_time_impl(d, ms, launches);
     return LCB_OK;
     LCB_CATCH(LCB_ERR)
 }
@@ -236,7 +244,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
         cfg.allgather = hooks->allgather; cfg.allgatherUser = hooks->allgather_user;
         cfg.roundPhases = hooks->round_phases; cfg.progress = hooks->progress != 0;
         cfg.roundFixed = hooks->round_fixed != 0; cfg.eagerPhases = hooks->eager_phases; cfg.maxViews = hooks->max_views;
-        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span;
+        cfg.maxJobs = hooks->max_jobs; cfg.predictF = hooks->predict_f; cfg.exchangeAlways = hooks->exchange_always != 0; cfg.countEvents = hooks->count_events != 0; cfg.syncJobs = hooks->sync_jobs != 0; cfg.lazySpan = hooks->lazy_span; cfg.sparseRounds = hooks->sparse_rounds;
     }
     std::vector<lcb_block> v;
     if (d) lcb_find_blocks_impl(g, d, p, seeds, n_seeds, cfg, v, stats);
@@ -253,7 +261,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
             stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
             stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
-            stats->early_critical = es.earlyCritical; stats->lazy_seeds = es.lazySeeds;
+            stats->early_critical = es.earlyCritical; stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));

@@ -22,6 +22,7 @@ typedef enum : int { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
 #endif
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -234,7 +235,14 @@ void lcb_gpus_find_blocks_impl(lcb_gpus_impl* m, const lcb_seed* seeds, int64_t 
                 if (!m->broken && n > 1) {
                     m->broken = true;
                     for (auto c : m->comm) if (c) c->aborted.store(true, std::memory_order_release);
-                    for (auto c : m->comm) if (c && c->comm) { std::lock_guard<std::mutex> issuing(c->issue); (void)rccl().CommAbort(c->comm); }
+                    for (auto c : m->comm) if (c && c->comm) {
+                        // `issue` is held by a thread that is ENQUEUEING a collective - normally microseconds. An enqueue that itself blocks (RCCL's lazy
+                        // connection set-up on a communicator whose peer has already failed) would keep it for ever: after two seconds the abort goes
+                        // ahead without the lock - aborting under a blocked enqueue is what unblocks it.
+                        std::unique_lock<std::mutex> issuing(c->issue, std::defer_lock);
+                        for (int tries = 0; tries < 200 && !issuing.try_lock(); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                        (void)rccl().CommAbort(c->comm);
+                    }
                 }
             }
         });

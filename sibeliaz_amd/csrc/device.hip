@@ -278,6 +278,8 @@ struct lcb_device_impl {
     }
     int64_t launches = 0, bigRetries = 0;
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
+    double modeMs[4] = {0, 0, 0, 0};             // hipEvent-timed kernel time of each variant since creation (all streams) ...
+    int64_t modeLaunches[4] = {0, 0, 0, 0};      // ... and its launches
     int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
     int64_t overflow[4][8] = {};                 // [variant][LcbStatus]: seeds that left a variant with that status
     int compactPathGrown = 0;                    // times the compact path set was enlarged (x4 each)
@@ -425,6 +427,7 @@ struct lcb_device_impl {
         launches++;
         noteSpan(evA, evB);
         modeSeeds[w.mode] += m;
+        modeMs[w.mode] += ms; modeLaunches[w.mode]++;
         if (traceFile) {
             fprintf(traceFile, "%lld\t%u\t%u\t%s\t%.4f\n", (long long)launches, m, grid, modeName(w.mode), ms);
             if (!stats && seedTrace && hCtr)  // per-seed profile of the slowest seeds of the launch (ticks are 10 ns)
@@ -848,6 +851,11 @@ void lcb_device_kernel_time_impl(lcb_device* h, double* ms, int64_t* launches, d
 
 int64_t lcb_device_big_retries_impl(lcb_device* h) { return h->impl->bigRetries; }
 void lcb_device_mode_seeds_impl(lcb_device* h, int64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = h->impl->modeSeeds[i]; }
+void lcb_device_mode_time_impl(lcb_device* h, double ms[4], int64_t launches[4])
+{
+    // (the batches still on the lanes are accounted when they retire: a caller that wants a closed figure asks after a pass - the engine drains the lanes at its end)
+    for (int i = 0; i < 4; i++) { ms[i] = h->impl->modeMs[i]; launches[i] = h->impl->modeLaunches[i]; }
+}
 
 namespace {
 
@@ -1169,8 +1177,9 @@ void lcb_device_process_end_impl(lcb_device* h, std::vector<uint64_t>& offsets, 
 static void lcb_lane_retire(lcb_device_impl* d, SideLane& L)
 {
     float ms = 0;
-    if (L.ranW) { HIP_CHECK(hipEventSynchronize(L.w1)); HIP_CHECK(hipEventElapsedTime(&ms, L.w0, L.w1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.w0, L.w1); }
-    if (L.ranB) { HIP_CHECK(hipEventSynchronize(L.b1)); HIP_CHECK(hipEventElapsedTime(&ms, L.b0, L.b1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.b0, L.b1); }
+    // (a lane runs the wide kernel on one stream and the big kernel on the other)
+    if (L.ranW) { HIP_CHECK(hipEventSynchronize(L.w1)); HIP_CHECK(hipEventElapsedTime(&ms, L.w0, L.w1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.w0, L.w1); d->modeMs[1] += ms; d->modeLaunches[1]++; }
+    if (L.ranB) { HIP_CHECK(hipEventSynchronize(L.b1)); HIP_CHECK(hipEventElapsedTime(&ms, L.b0, L.b1)); d->kernelMs += ms; d->sideKernelMs += ms; d->launches++; d->noteSpan(L.b0, L.b1); d->modeMs[2] += ms; d->modeLaunches[2]++; }
     L.busy = L.released = L.ranW = L.ranB = false;
 }
 
@@ -1364,6 +1373,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
         stats->early_critical = es.earlyCritical;
-        stats->lazy_seeds = es.lazySeeds;
+        stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead;
     }
 }

@@ -30,6 +30,8 @@
 // With world > 1 every launch — a round's speculative launch and every job launch — is dealt round-robin to the ranks and
 // the per-seed results + footprints are all-gathered; every rank then runs the identical dry runs and commit, so all
 // ranks hold the same `used` state and block list without further traffic.
+#include <omp.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -372,18 +374,101 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // views against the live state - results that the next commit voids. The randomized emulator campaign found that configuration a
     // hundred times slower than the round launch it replaces.)
     const int lazySpan = (!useSide || maxViews <= 0 || cfg.lazySpan < 0) ? 0 : (cfg.lazySpan ? cfg.lazySpan : 8);
+
+    // ---- results the host settles itself. Path::Init (path.h:33-46) creates one instance per UNUSED occurrence of the seed's vertex that carries
+    // the seed's character; with none, Process() finds no vertex to go to in either direction and returns nothing (blocksfinder.h:781-786) - and
+    // it has read no bit as 0, so that result holds against every later state too (bits only go 0 -> 1). The device's screening kernel decides the
+    // same thing for the seeds of a launch; here the host decides it for a seed at the moment its result is needed - against the committer's own
+    // bitmap, which IS the live state - so that no launch, no job and no stop is spent on it. P: predicted marks on top of the live state (dry runs).
+    const bool hostScreen = cfg.sparseRounds >= 0 && !cfg.countEvents;           // (a counting pass walks through the motions on the device)
+    auto usedAt = [&](uint64_t q, const RangeSet* P) -> bool { return ((com.used[(size_t)(q >> 5)] >> (q & 31)) & 1u) != 0 || (P && P->hits(q, q)); };
+    auto hostDead = [&](const lcb_seed& sd, const RangeSet* P) -> bool {
+        const uint32_t av = (uint32_t)(sd.vid < 0 ? -sd.vid : sd.vid);
+        for (uint64_t j = g->occStart[av]; j < g->occStart[av + 1]; j++) {
+            const uint64_t q = g->occG[j];
+            const bool positive = g->posId[q] == sd.vid;                         // JunctionIterator::IsPositiveStrand
+            if ((int32_t)(signed char)(positive ? g->posCh[q] : g->posRevCh[q]) != sd.ch) continue;
+            // JunctionSequentialIterator::IsUsed (junctionstorage.h:270-283): + strand bit idx, - strand bit idx-1 (none at the chromosome start)
+            const bool isUsed = positive ? usedAt(q, P) : (q > g->chrStart[g->occChr[j]] ? usedAt(q - 1, P) : false);
+            if (!isUsed) return false;
+        }
+        return true;
+    };
+    // Sparse speculative launches. The seeds are sorted by (count, chromosomes of the occurrences, resolve position) - Bundle::operator<,
+    // blocksfinder.h:195-208; the resolve position is the smallest position of a + strand occurrence, on chromosome resolve_chr -, so the seeds
+    // of one collinear stretch follow each other a few bp apart ON THEIR RESOLVE CHROMOSOME (stretches that resolve to different chromosomes
+    // interleave in the list): a CLUSTER is a run of seeds of one resolve chromosome whose positions ascend in steps of at most clusterGap. The
+    // first live seed of a cluster finds the block; every other seed of the cluster lies on that block's path. Those that share its phase see the phase-start state
+    // like it and compute the block again (the reference does the same, blocksfinder.h:345-370); those of LATER phases are dead when their
+    // phase starts. A launch of a whole round computes the block once per seed of the cluster all the same - thousands of times where the
+    // blocks are long (k = 25 shapes: 12 phases per block) -, the adaptive round size answers by shrinking to one phase, and the blocks are
+    // found one after the other, one block-sized seed per launch. A sparse round launches the seeds of the FIRST phase of every cluster only
+    // and spans as many phases as it takes to collect roundPhases x 256 of them (at most sparseSpan phases): the first phases of many blocks
+    // are in flight at once. The other seeds are lazy (no result): dead ones are settled by the host when their phase starts, a live one
+    // (the guess was wrong: its cluster holds more than one block) is computed then, like the seeds of a lazy tail. Exactness is untouched.
+    const bool sparse = hostScreen && lazySpan > 0;
+    const int sparseSpan = 1024;
+    // (the guess costs time, never exactness: a gap too small launches the seeds of a block's later phases for nothing, one too large leaves the first
+    // phase of the next block to a stop of the commit - what a lazy tail does)
+    const uint64_t clusterGap = getenv("LCB_CLUSTER_GAP") ? (uint64_t)atoll(getenv("LCB_CLUSTER_GAP")) : 16 * (uint64_t)std::max<int64_t>(p->max_branch, 1);   // (environment: experiments)
+    struct ClusterEnd { uint64_t round = 0, pos = 0; int64_t phase = 0; };   // per resolve chromosome: the newest cluster of this round (its last position, the phase it began in)
+    std::vector<ClusterEnd> clusterOf(std::max<size_t>(1, (size_t)g->nChr()));
+    uint64_t roundStamp = 0;
+    const int screenThreads = std::max(1, std::min(omp_get_max_threads(), 32));
+    std::vector<uint8_t> isEager, deadE;           // per seed of a sparse round: part of its launch / its phase-start result is the empty one (settled by the host)
+    std::vector<lcb_seed> eagerSeeds;
+    Results packed;
     for (int64_t pos = 0; pos < nSeeds;) {
-        const int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)std::max(roundPhases, std::min(lazySpan, maxRound)) * phase);
-        const int64_t nEager = std::min<int64_t>(nRound, (int64_t)roundPhases * phase);     // seeds [nEager, nRound) are lazy
+        int64_t nRound = std::min<int64_t>(nSeeds - pos, (int64_t)std::max(roundPhases, std::min(lazySpan, maxRound)) * phase);
+        int64_t nEager = std::min<int64_t>(nRound, (int64_t)roundPhases * phase);     // seeds [nEager, nRound) are lazy (a sparse round: nEager = number of launched seeds, isEager says which)
+        if (sparse) {
+            // the launched seeds: phase by phase, the seeds whose cluster began in that phase (the first cluster of the round begins with it: what
+            // the round before has left of it is dead by now, or alive and wanted)
+            const int64_t budget = (int64_t)roundPhases * phase, spanMax = std::min<int64_t>(nSeeds - pos, (int64_t)sparseSpan * phase);
+            isEager.assign((size_t)spanMax, 0);
+            int64_t nSel = 0, end = 0;
+            roundStamp++;
+            for (int64_t ph = 0; ph < spanMax; ph += phase) {
+                const int64_t n = std::min<int64_t>(phase, spanMax - ph);
+                int64_t sel = 0;
+                for (int64_t i = ph; i < ph + n; i++) {
+                    const lcb_seed& a = seeds[pos + i];
+                    ClusterEnd& c = clusterOf[(size_t)a.resolve_chr < clusterOf.size() ? (size_t)a.resolve_chr : 0];
+                    if (c.round != roundStamp || a.resolve_pos < c.pos || a.resolve_pos - c.pos > clusterGap) { c.round = roundStamp; c.phase = ph; }   // a new cluster
+                    c.pos = a.resolve_pos;
+                    if (c.phase == ph) { isEager[(size_t)i] = 1; sel++; }
+                }
+                if (ph > 0 && nSel + sel > budget && ph >= (int64_t)lazySpan * phase) break;  // the budget is spent: the round ends in front of this phase
+                nSel += sel; end = ph + n;
+            }
+            nRound = end; nEager = nSel;
+            isEager.resize((size_t)nRound);
+            eagerSeeds.clear();
+            for (int64_t i = 0; i < nRound; i++) if (isEager[(size_t)i]) eagerSeeds.push_back(seeds[pos + i]);
+        }
+        auto eager = [&](int64_t i) -> bool { return sparse ? isEager[(size_t)i] != 0 : i < nEager; };
         int64_t eagerRecomputed = 0;
         st.rounds++;
         flush();                                    // processor state == live state at the start of phase `pos`
         epochMarks.assign(1, RangeSet());
         // ---- speculative launch of the whole round (dealt to the ranks; on one rank with the ordered commit of the round's clean
         // prefix chained behind its kernels where the processor can do that)
-        processSharded(seeds + pos, nullptr, nEager, round, (uint64_t)pos);
+        if (!sparse) processSharded(seeds + pos, nullptr, nEager, round, (uint64_t)pos);
+        else {
+            processSharded(eagerSeeds.data(), nullptr, nEager, packed, (uint64_t)pos);
+            // the launched seeds ascend, so their instances and footprints are in round order already: only the offsets spread out
+            round.inst.swap(packed.inst); round.fp.swap(packed.fp);
+            round.off.assign((size_t)nRound + 1, 0); round.fpOff.assign((size_t)nRound + 1, 0);
+            int64_t k = 0;
+            for (int64_t i = 0; i < nRound; i++) {
+                round.off[(size_t)i] = packed.off[(size_t)k]; round.fpOff[(size_t)i] = packed.fpOff[(size_t)k];
+                if (isEager[(size_t)i]) k++;
+            }
+            round.off[(size_t)nRound] = packed.off[(size_t)k]; round.fpOff[(size_t)nRound] = packed.fpOff[(size_t)k];
+            st.lazySeeds += nRound - nEager;
+        }
         const auto tSetup = std::chrono::steady_clock::now();
-        if (nEager < nRound) {                      // the lazy seeds: no result, nothing known
+        if (!sparse && nEager < nRound) {           // the lazy seeds: no result, nothing known
             round.off.resize((size_t)nRound + 1, round.off[(size_t)nEager]); round.fpOff.resize((size_t)nRound + 1, round.fpOff[(size_t)nEager]);
             if (cfg.countEvents) round.ctr.resize((size_t)nRound, lcb_counters{});
             st.lazySeeds += nRound - nEager;
@@ -392,14 +477,28 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
         eIdx.assign((size_t)nRound, -1); fIdx.assign((size_t)nRound, -1);
         e0Checked.assign((size_t)nRound, 0);
         liveIdx.clear();
-        for (int64_t i = 0; i < nEager; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
-        for (int64_t i = nEager; i < nRound; i++) liveIdx.push_back((int32_t)i);
+        if (!sparse) {
+            for (int64_t i = 0; i < nEager; i++) if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i);
+            for (int64_t i = nEager; i < nRound; i++) liveIdx.push_back((int32_t)i);
+        } else {
+            // the lazy seeds that are dead NOW are dead for good: what the screening kernel does for the seeds of a launch, on all host threads
+            deadE.assign((size_t)nRound, 0);
+#pragma omp parallel for num_threads(screenThreads) schedule(dynamic, 1024)
+            for (int64_t i = 0; i < nRound; i++) if (!isEager[(size_t)i] && hostDead(seeds[pos + i], nullptr)) deadE[(size_t)i] = 1;
+            for (int64_t i = 0; i < nRound; i++) {
+                if (isEager[(size_t)i]) { if (round.off[i + 1] != round.off[i] || round.fpOff[i + 1] != round.fpOff[i]) liveIdx.push_back((int32_t)i); }
+                else if (!deadE[(size_t)i]) liveIdx.push_back((int32_t)i);
+                else st.hostDead++;
+            }
+        }
+        if (hostScreen && !sparse) deadE.assign((size_t)nRound, 0);
         if (useSide) { sideJobs.clear(); sideSent.clear(); batches.clear(); laneOrder.clear(); sideScan = 0; sideE.assign((size_t)nRound, -1); sideF.assign((size_t)nRound, -1); }
         st.sectionMs[LCB_SEC_SETUP] += msSince(tSetup);
 
         // the newest E result of seed i: instances / footprint / provenance
         auto eInst = [&](int64_t i, const lcb_instance*& r, uint64_t& cnt) {
-            if (eIdx[(size_t)i] >= 0) { const Cand& c = cands[(size_t)eIdx[(size_t)i]]; r = c.inst.data(); cnt = c.inst.size(); }
+            if (hostScreen && deadE[(size_t)i]) { r = nullptr; cnt = 0; }
+            else if (eIdx[(size_t)i] >= 0) { const Cand& c = cands[(size_t)eIdx[(size_t)i]]; r = c.inst.data(); cnt = c.inst.size(); }
             else { r = round.inst.data() + round.off[i]; cnt = round.off[i + 1] - round.off[i]; }
         };
         // Conditions (1) and (2) of the header for a result computed at launch `epoch` against view `view`, judged against
@@ -420,9 +519,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             return true;
         };
         auto eValidNow = [&](int64_t i) -> bool {
-            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; return validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
-            if (i >= nEager) return false;          // a lazy seed: nothing has been computed for it yet
-            return validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
+            if (hostScreen && deadE[(size_t)i]) return true;
+            bool ok = false;                        // (a lazy seed without a job result: nothing has been computed for it yet)
+            if (eIdx[(size_t)i] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)i]]; ok = validNow(c.epoch, c.view, c.checkedTo, &c.viewOk, c.fp.data(), c.fp.size()); }
+            else if (eager(i)) ok = validNow(0, -1, e0Checked[(size_t)i], nullptr, round.fp.data() + round.fpOff[i], (size_t)(round.fpOff[i + 1] - round.fpOff[i]));
+            // no exact result at hand: if no unused occurrence is left the seed needs none (called at the phase start: the state it is judged by)
+            if (!ok && hostScreen && hostDead(seeds[pos + i], nullptr)) { deadE[(size_t)i] = 1; st.hostDead++; return true; }
+            return ok;
         };
 
         // Every predicted mark of the job's view is true by now - or, inside a dry run, still predicted (simP).
@@ -627,10 +730,12 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
             };
             if (useEarly && midPhase) { earlySeeds.assign(1, seeds[pos + stopAt]); beginEarly(); }
             const int64_t lim = std::min<int64_t>(nRound, ph0 + (int64_t)(eagerPhases + 1) * phase);
+            int64_t screenLeft = 16384;              // seeds this dry run may screen on the host (its time is the stop's time)
             std::vector<lcb_instance> guess;
             size_t lv = liveFrom((midPhase ? stopAt : ph0));          // cursor into liveIdx (seeds that are not in it need nothing, commit nothing)
             for (int64_t ph = ph0; ph < lim; ph += phase) {
                 if (jobs.size() >= maxJobs) break;      // enough speculation for one launch (the first job is always there)
+                if (hostScreen && screenLeft <= 0 && !jobs.empty()) break;
                 const int64_t n = std::min<int64_t>(phase, nRound - ph);
                 const bool first = ph == ph0;
                 while (lv < liveIdx.size() && liveIdx[lv] < (first && midPhase ? stopAt : ph)) lv++;
@@ -642,9 +747,13 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     for (size_t q = lv; q < lvEnd; q++) {
                         const int64_t j = liveIdx[q];
                         bool ok;
-                        if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
-                        else if (j >= nEager) ok = false;
+                        if (hostScreen && deadE[(size_t)j]) ok = true;
+                        else if (eIdx[(size_t)j] >= 0) { Cand& c = cands[(size_t)eIdx[(size_t)j]]; ok = simValid(c.epoch, c.view, c.checkedTo, c.fp.data(), c.fp.size()); }
+                        else if (!eager(j)) ok = false;
                         else ok = simValid(0, -1, e0Checked[(size_t)j], round.fp.data() + round.fpOff[j], (size_t)(round.fpOff[j + 1] - round.fpOff[j]));
+                        // dead against the live state plus the commits this dry run predicts before its phase: it will need no job (the host
+                        // settles it when its phase starts, if the predictions come true; a dead seed of the stop's own phase is settled already)
+                        if (!ok && hostScreen && screenLeft > 0 && !(first && !midPhase)) { screenLeft--; if (hostDead(seeds[pos + j], simP.empty() ? nullptr : &simP)) ok = true; }
                         if (!ok && !onItsWay(j, false)) {
                             if (!any) { currentView(); any = true; }
                             jobs.push_back(Job{j, false, (uint32_t)nViews, curSet});
@@ -672,6 +781,8 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                         if (have && c.inst.size() > 1) simAdd(c.inst.data(), c.inst.size());
                     }
                     if (!have) {
+                        // (a seed that is dead once the commits predicted before it have happened re-processes to nothing: the host settles that too)
+                        if (hostScreen && screenLeft > 0 && !(first && midPhase && j == stopAt)) { screenLeft--; if (hostDead(seeds[pos + j], simP.empty() ? nullptr : &simP)) continue; }
                         if (!onItsWay(j, true)) {
                             currentView();
                             jobs.push_back(Job{j, true, (uint32_t)nViews, curSet});
@@ -775,7 +886,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                 for (size_t k = 1; k <= nSync - nCrit; k++) { tmp.off.push_back(i0 + tmp2.off[k]); tmp.fpOff.push_back(f0 + tmp2.fpOff[k]); }
             }
             st.recomputeLaunches++; st.recomputedSeeds += (int64_t)jobs.size();
-            for (auto& jb : jobs) if (jb.seed < nEager) eagerRecomputed++;
+            for (auto& jb : jobs) if (eager(jb.seed)) eagerRecomputed++;
             if (midPhase) st.conflictLaunches++;
             if (debug) std::cerr << "engine: stop at seed " << (pos + stopAt) << (midPhase ? " (F)" : " (E)") << " -> " << jobs.size() << " jobs, " << nViews << " views" << (lane >= 0 ? ", all but the first on side lane " + std::to_string(lane) : std::string()) << "\n";
             epochMarks.emplace_back();              // marks from here on belong to the new epoch
@@ -857,6 +968,9 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
                     com.finalize(r, cnt); takeMarks(); if (eIdx[(size_t)i] >= 0) st.jobsUsed++; continue;
                 }
                 st.failures++;                                                           // blocksfinder.h:406
+                // re-processed against the live state (blocksfinder.h:407): nothing, if no unused occurrence is left - the usual fate of the seeds
+                // that share a phase with the first seed of their block
+                if (hostScreen && hostDead(seeds[pos + i], nullptr)) { st.hostDead++; continue; }
                 for (;;) {
                     if (fIdx[(size_t)i] >= 0) {
                         Cand& c = cands[(size_t)fIdx[(size_t)i]];

@@ -206,7 +206,7 @@ lcb_graph* lcb_graph_load_impl(const char* junctionFile, const std::vector<std::
         // The reference's limit is per chromosome (uint32_t idx / pos, junctionstorage.h:120-151; README.md:25-26), not on the input:
         // positions are (segment, 32-bit offset) pairs on the device (lcb_segments.h), the host tables are 64-bit
         for (size_t c = 0; c < C; c++)
-            if (g->chrStart[c + 1] - g->chrStart[c] >= LCB_SEG_POSITIONS) throw LcbError("a chromosome with 2^32 or more junctions is not supported");
+            if (g->chrStart[c + 1] - g->chrStart[c] >= LCB_SEG_POSITIONS) throw LcbError("a chromosome with 2^32 - 2^20 or more junctions is not supported (the reference's own limit is 2^32 bp, hence fewer than 2^32 junctions, per chromosome)");
         g->posId.resize(P); g->posPos.resize(P);
         bool unordered = false;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 4)

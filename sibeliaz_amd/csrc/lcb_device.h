@@ -42,6 +42,7 @@ void lcb_device_side_release_impl(lcb_device* d, int lane);
 double lcb_device_hbm_triad_impl(lcb_device* d, uint64_t bytes, int reps);
 int lcb_device_concurrency_impl(lcb_device* d);          // seeds in flight in the compact variant
 void lcb_device_mode_seeds_impl(lcb_device* d, int64_t out[4]);
+void lcb_device_mode_time_impl(lcb_device* d, double ms[4], int64_t launches[4]);
 // since the last call: sum of the hipEvent-timed kernel durations over all streams, launches, union of the kernels' intervals (the time
 // the GPU was busy with them: side-lane kernels overlap the synchronous ones), and the part of the sum that ran on the side lanes
 void lcb_device_kernel_time_impl(lcb_device* d, double* ms, int64_t* launches, double* busyMs = nullptr, double* sideMs = nullptr);

@@ -191,6 +191,7 @@ struct LcbEngineConfig {
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
     int lazySpan = 0;         // a round spans at least this many phases: those beyond the adaptive launch size get their phase-start results as jobs (0 = 8, -1 = off)
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
+    int sparseRounds = 0;     // sparse speculative launches + host-resolved dead seeds (lcb_hooks.sparse_rounds): 0 = default (on), -1 = off
 };
 
 enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch (lists of the seeds that read or commit anything)
@@ -209,6 +210,7 @@ struct LcbEngineStats {
     int64_t overPredicted = 0;    // job results dropped because their view held a mark that did not come true
     int64_t earlyCritical = 0;    // stops whose own jobs ran while the rest was planned
     int64_t lazySeeds = 0;        // seeds of the lazy tails of the rounds (no speculative launch: their phase-start results are jobs)
+    int64_t hostDead = 0;         // results the host settled without the device: no unused occurrence of the seed's vertex with its character (empty Path::Init)
     int64_t sideBatches = 0, sideJobs = 0;      // asynchronous job batches and their jobs (recomputeLaunches / recomputedSeeds count them too)
     int64_t sideTaken = 0;        // ... results taken when the commit reached their seed (view came true)
     int64_t sideVoid = 0;         // ... jobs dropped because a mark of their view did not come true, or superseded by a newer plan

@@ -352,12 +352,19 @@ struct LcbStateT {
 };
 
 // footprint slot of pool entry i (see LcbStateT::fpSplit)
+// (-DLCB_TEST_FP_SLOT_DIV=n, emulator tests only: a pool with 1/n of its footprint slots, so that small inputs reach the shared slots)
+#ifndef LCB_TEST_FP_SLOT_DIV
+#define LCB_TEST_FP_SLOT_DIV 1u
+#endif
 template <class ST>
 __device__ __forceinline__ uint32_t lcb_fp_slot(const ST& S, uint32_t i)
 {
     if (i < S.fpSplit) return i;
     const uint32_t f = i + S.fpShift;
-    return f < S.instCap ? f : i;      // no room for a slot of its own: it shares the old one (a superset: still exact)
+    // no room for a slot of its own: it shares the old one - one hull over both instances, a superset: still exact, provided both lie in
+    // the slot's segment (a slot is 32-bit offsets plus ONE segment; lcb_push ends the seed with LCB_ST_INST_OVF otherwise and the next
+    // variant, whose pool is larger, gives the instance a slot of its own)
+    return f < S.instCap / LCB_TEST_FP_SLOT_DIV ? f : i;
 }
 
 // segment of footprint slot fs (SEG kernels)
@@ -674,6 +681,171 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // with the path set in LDS always walk exactly.
 // (Tried and measured slower on the MI355X, profiles/r03: requesting the next chunk of a voter ahead of time with unconditional,
 // straight-line loads - the main wavefront is bound by instruction issue, not by the round trips the prefetch hides.)
+// ---- The round-5 walk - one voter after the other, chunk by chunk, voters drawn from LDS tickets. Which kernel variant walks which way is a
+// bit mask over the variants (bit m set: variant m takes the window-table walk below); decided by same-box A/B on the MI355X (profiles/r06).
+#ifndef LCB_WALK_V2_MODES
+#define LCB_WALK_V2_MODES 0x1u
+#endif
+#define LCB_WALK_V2_OF(ST) (((LCB_WALK_V2_MODES) >> ST::MODE) & 1u)
+template <class F> struct LcbVoterT { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; F sb; };   // sb: base of the voter's segment
+struct LcbWalk { uint32_t g, pos; int32_t id; uint32_t uw; bool valid; };
+template <bool STATS, bool PROF = false, class ST>
+__device__ inline void lcb_vote_walk_v1(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t waveId, uint32_t nWaves, bool exact)
+{
+    const LcbTables& T = S.T;
+    typedef typename ST::Flat Flat;
+    typedef LcbVoterT<Flat> LcbVoter;
+    const uint32_t vmask = S.voteCap - 1;
+    const uint32_t claimCap = S.voteCap - (S.voteCap >> 2);
+    const uint32_t depth = (uint32_t)S.P.depth, maxBranch = (uint32_t)S.P.maxBranch;
+    // the current chunk of 64 touch-list entries (per-lane fields) and the voters still to hand out from it
+    const uint32_t nTouch = S.nTouch;
+    uint32_t chunkBase = 0, ordinal = 0;
+    unsigned long long pend = 0;
+    uint32_t fE = 0, fI = 0, fG = 0, fPos = 0, fLo = 0, fHi = 0, fW = 0, fFl = 0;
+    bool scanned = false;
+    const bool tickets = nWaves > 2;
+    auto nextVoter = [&](LcbVoter& v) -> bool {
+        if (tickets) {
+            // one entry of the touch list per draw; its fields are wave-uniform loads (the next voter is drawn while the current one
+            // is walked, so their latency hides behind a walk)
+            for (;;) {
+                uint32_t t = 0;
+                if (S.lane == 0) t = atomicAdd(S.vTicket, 1u);
+                t = lcb_rfl(t);
+                if (t >= nTouch) return false;
+                const uint32_t i = lcb_rfl((uint32_t)S.touch[t]);
+                const uint32_t e = useGood ? lcb_rfl((uint32_t)S.goodPos[i]) : i;      // position in the voting list (its order breaks ties)
+                if (e == ST::NONE) continue;
+                const uint32_t f = lcb_inst_fields(S, i);
+                const uint32_t fl = lcb_rl(f, LCB_F_FLAGS), fp = lcb_rl(f, LCB_F_FRONTPOS), bp = lcb_rl(f, LCB_F_BACKPOS);
+                v.e = e; v.i = i;
+                v.g0 = forward ? lcb_rl(f, LCB_F_BACKG) : lcb_rl(f, LCB_F_FRONTG);
+                v.pos0 = forward ? bp : fp;
+                v.lo = lcb_rl(f, LCB_F_LO);
+                const uint32_t hi = lcb_rl(f, LCB_F_HI);
+                v.weight = lcb_absdiff(fp, bp) + 1u;                                   // blocksfinder.h:719
+                v.positive = (fl & LCB_FLAG_POS) != 0;
+                v.dir = (forward == v.positive) ? 1 : -1;
+                v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                      // steps for which it.Valid() holds
+                v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(fl)]) : (Flat)0;
+                return true;
+            }
+        }
+        for (;;) {
+            while (pend == 0) {
+                if (scanned) chunkBase += 64;
+                scanned = true;
+                if (chunkBase >= nTouch) return false;
+                const uint32_t t = chunkBase + S.lane;
+                bool is = false;
+                if (t < nTouch) {
+                    fI = S.touch[t];
+                    fE = useGood ? (uint32_t)S.goodPos[fI] : fI;          // position in the voting list (its order breaks ties)
+                    is = fE != ST::NONE;
+                    if (is) {
+                        fFl = S.iFlags[fI];
+                        const uint32_t fp = S.iFrontPos[fI], bp = S.iBackPos[fI];
+                        fG = forward ? S.iBackG[fI] : S.iFrontG[fI];
+                        fPos = forward ? bp : fp;
+                        fLo = S.iLo[fI]; fHi = S.iHi[fI];
+                        fW = lcb_absdiff(fp, bp) + 1u;                                       // blocksfinder.h:719
+                    }
+                }
+                pend = __ballot(is);
+            }
+            const uint32_t b = (uint32_t)__ffsll((long long)pend) - 1u;
+            pend &= pend - 1;
+            const uint32_t o = ordinal++;
+            if (nWaves > 1 && (o % nWaves) != waveId) continue;
+            v.e = lcb_rl(fE, b);
+            v.i = lcb_rl(fI, b); v.g0 = lcb_rl(fG, b); v.pos0 = lcb_rl(fPos, b); v.lo = lcb_rl(fLo, b);
+            const uint32_t hi = lcb_rl(fHi, b);
+            v.weight = lcb_rl(fW, b);
+            const uint32_t vfl = lcb_rl(fFl, b);
+            v.positive = (vfl & LCB_FLAG_POS) != 0;
+            v.dir = (forward == v.positive) ? 1 : -1;
+            v.rem = v.dir > 0 ? hi - 1u - v.g0 : v.g0 - v.lo;                               // steps for which it.Valid() holds
+            v.sb = ST::SEG ? (Flat)lcb_rfl(S.segBase[lcb_fl_seg(vfl)]) : (Flat)0;
+            return true;
+        }
+    };
+    // The table reads of a pass (pos, id, used word) are independent and issued together; the first pass of the NEXT
+    // voter is issued before the current one is consumed, so its latency hides behind the LDS work of this one.
+    auto issue = [&](const LcbVoter& v, uint32_t c) -> LcbWalk {
+        LcbWalk w;
+        const uint32_t d = c * 64 + S.lane + 1;
+        w.valid = d <= v.rem;                                                               // it.Valid()
+        w.g = v.dir > 0 ? v.g0 + d : v.g0 - d;
+        w.pos = 0; w.id = 0; w.uw = 0;
+        if (w.valid) {
+            // (wave-uniform table base + 32-bit lane offset)
+            w.pos = (T.posPos + v.sb)[w.g];
+            w.id = (T.posId + v.sb)[w.g];
+            // IsUsed: + strand bit g, - strand bit g-1 (none at the chromosome start)
+            const Flat ub = v.sb + (w.g - (v.positive ? 0u : 1u));
+            if (!tryUsed && (v.positive || w.g > v.lo)) w.uw = lcb_uword(S.U, (uint32_t)(ub >> 5)) >> ((uint32_t)ub & 31u);
+        }
+        return w;
+    };
+    LcbVoter cur, nxt;
+    LcbWalk wcur, wnxt;
+    bool have = nextVoter(cur);
+    if (have) wcur = issue(cur, 0);
+    while (have) {
+        const bool haveNext = nextVoter(nxt);
+        if (haveNext) wnxt = issue(nxt, 0);
+        for (uint32_t c = 0;; c++) {
+            const LcbWalk w = c == 0 ? wcur : issue(cur, c);
+            if (PROF) S.pfChunks++;
+            const uint32_t d = c * 64 + S.lane + 1;
+            const bool cond = w.valid && (d < depth || lcb_absdiff(w.pos, cur.pos0) <= maxBranch);
+            const int32_t vid = cur.positive ? w.id : -w.id;
+            const bool stop = cond && ((w.uw & 1u) != 0 || (exact && lcb_path_contains(S, vid)));
+            const unsigned long long failM = __ballot(!cond);
+            const unsigned long long stopM = __ballot(stop);
+            const unsigned long long endM = failM | stopM;
+            const uint32_t first = endM ? (uint32_t)(__ffsll((long long)endM) - 1) : 64u;
+            if (STATS) {
+                // loop iterations entered: contributing steps plus the breaking one (not the failed loop test)
+                const bool breaking = stopM && (uint32_t)(__ffsll((long long)stopM) - 1) == first;
+                if (S.lane < first || (S.lane == first && breaking)) S.cWalk++;
+            }
+            if (S.lane < first) {
+                uint32_t h = lcb_hash(vid, S.voteShift);
+                int32_t old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
+                uint32_t probe = 0;
+                while (old != LCB_EMPTY_KEY && old != vid && probe < S.voteCap) {
+                    h = (h + 1) & vmask; probe++;
+                    old = atomicCAS(&S.vKey[h], LCB_EMPTY_KEY, vid);
+                }
+                if (old == LCB_EMPTY_KEY) {
+                    const uint32_t t = atomicAdd(S.vNClaimed, 1u);
+                    if (t < claimCap) S.vTouched[t] = (typename ST::Idx)h; else *S.vOvf = 1u;
+                }
+                if (old == LCB_EMPTY_KEY || old == vid) {
+                    atomicAdd(&S.vCount[h], cur.weight);
+                    atomicMax(&S.vLast[h], ((typename ST::VLast)cur.e << ST::LAST_SHIFT) | d);
+                } else *S.vOvf = 1u;
+            }
+            if (first < 64) {
+                if (!tryUsed && S.lane == 0) {
+                    // steps 1 .. c*64+first-1 read used == 0 (one step of slack keeps the - strand's bit g-1 inside)
+                    const uint32_t st = c * 64 + first;
+                    const uint32_t ge = st > cur.rem ? (cur.dir > 0 ? cur.g0 + cur.rem : cur.lo) : (cur.dir > 0 ? cur.g0 + st : cur.g0 - st);
+                    const uint32_t fs = lcb_fp_slot(S, cur.i);
+                    atomicMin(&S.fpLo[fs], ge);
+                    atomicMax(&S.fpHi[fs], ge);
+                }
+                break;
+            }
+        }
+        if (PROF) S.pfVoters++;
+        have = haveNext; cur = nxt; wcur = wnxt;
+    }
+}
+
+
 // Round 6: the walk knows a voter's window before it reads anything of it. LcbTables::posWin holds, per position, the number of steps in
 // either direction that stay within maxBranch bp (a prefix, because positions ascend strictly inside a chromosome), so the reference's
 // loop test `step < lookingDepth || |pos - pos0| <= maxBranch` (blocksfinder.h:722-727) is `step <= L` with
@@ -707,6 +879,7 @@ __host__ __device__ inline uint32_t lcb_brev32(uint32_t x)
 template <bool STATS, bool PROF = false, class ST>
 __device__ inline void lcb_vote_walk(ST& S, bool forward, bool tryUsed, bool useGood, uint32_t waveId, uint32_t nWaves, bool exact)
 {
+    if (!LCB_WALK_V2_OF(ST)) { lcb_vote_walk_v1<STATS, PROF>(S, forward, tryUsed, useGood, waveId, nWaves, exact); return; }
     const LcbTables& T = S.T;
     typedef typename ST::Flat Flat;
     const uint32_t vmask = S.voteCap - 1;
@@ -990,6 +1163,7 @@ __device__ inline LcbBest lcb_vote_pass(ST& S, bool forward, bool tryUsed, bool 
             S.mail[LCB_MAIL_FLAGS] = (forward ? 1u : 0u) | (tryUsed ? 2u : 0u) | (useGood ? 4u : 0u) | (share ? 8u : 0u) | (exact ? 16u : 0u);
             S.mail[LCB_MAIL_NTOUCH] = S.nTouch;
             S.mail[LCB_MAIL_FPSPLIT] = S.fpSplit; S.mail[LCB_MAIL_FPSHIFT] = S.fpShift;
+            if (!LCB_WALK_V2_OF(ST)) *S.vTicket = 0;
             S.mail[LCB_MAIL_CMD] = LCB_CMD_VOTE;
         }
         __syncthreads();                                           // A
@@ -1357,6 +1531,18 @@ __device__ inline bool lcb_push(ST& S, const LcbEdgeT<typename ST::OccIdx>& E, b
             if (HOIST) { atomicMin(&S.fpLo[fs], g); atomicMax(&S.fpHi[fs], g); }      // (no result: nothing waits for the workspace)
             else { if (g < S.fpLo[fs]) S.fpLo[fs] = g; if (g > S.fpHi[fs]) S.fpHi[fs] = g; }
             becameGood = before < (int64_t)S.P.minBlock && (HOIST ? (int64_t)lenAfter : lcb_real_length(S, cand)) >= (int64_t)S.P.minBlock;
+        }
+        if (ST::SEG) {
+            // a new instance that has to share the footprint slot of an older pool entry (no slot of its own left) must lie in that slot's
+            // segment: the slot's hull is (segment, 32-bit offsets), and a hull of another segment would not cover this instance's reads
+            bool clash = false;
+            const unsigned long long im = __ballot(ins);
+            if (ins) {
+                const uint32_t i = S.nInst + (uint32_t)__popcll(im & ((1ull << S.lane) - 1));
+                const uint32_t fs = lcb_fp_slot(S, i);
+                clash = fs < S.nFp && lcb_fp_get_seg(S, fs) != lcb_cw_seg(chr);
+            }
+            if (__ballot(clash)) { S.status = LCB_ST_INST_OVF; return true; }
         }
         const unsigned long long insM = __ballot(ins);
         const unsigned long long extM = __ballot(ext);

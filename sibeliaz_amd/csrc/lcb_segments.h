@@ -47,13 +47,15 @@ inline LcbSegPlan lcb_plan_segments(const lcb_graph& g, uint64_t cap, uint64_t g
     const size_t C = g.nChr();
     if (!cap || cap > LCB_SEG_POSITIONS) cap = LCB_SEG_POSITIONS;
     if (C >= (1u << LCB_SEG_SHIFT)) throw LcbError("more than 2^24 chromosomes are not supported by the device tables");
+    // (test hook: a gap leaves the last bitmap word of a segment and the first one of the next to themselves - lcb_device_set_used copies whole words per segment)
+    if (gap && gap < 64) throw LcbError("lcb_device_opts.seg_gap: a gap between the segments of the device tables has at least 64 positions");
     p.gap = gap;
     p.chrWord.resize(C); p.chrLo.resize(C); p.chrHi.resize(C); p.chrDev.resize(C);
     p.segStart.assign(1, 0);
     uint64_t segBegin = 0;
     for (size_t c = 0; c < C; c++) {
         const uint64_t a = g.chrStart[c], b = g.chrStart[c + 1];
-        if (b - a >= LCB_SEG_POSITIONS) throw LcbError("a chromosome with 2^32 or more junctions is not supported");
+        if (b - a >= LCB_SEG_POSITIONS) throw LcbError("a chromosome with 2^32 - 2^20 or more junctions is not supported (the reference's own limit is 2^32 bp, hence fewer than 2^32 junctions, per chromosome)");
         if (b - segBegin > cap && a > segBegin) { p.segStart.push_back(a); segBegin = a; }
         const uint32_t s = (uint32_t)p.segStart.size() - 1;
         if (s >= LCB_MAX_SEG) throw LcbError("more than 32 segments of 2^32 junction occurrences (2^37 in total) are not supported by the device tables");

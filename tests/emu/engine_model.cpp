@@ -238,6 +238,7 @@ int main(int argc, char** argv)
         if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
         cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
         if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN", 0) ? envInt("LCB_LAZY_SPAN", 0) : -1;
+        if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS")) > 0 ? 1 : -1;
         std::vector<lcb_block> blocks;
         LcbEngineStats es;
         const auto t0 = std::chrono::steady_clock::now();
@@ -258,9 +259,9 @@ int main(int argc, char** argv)
             if (L.jobs) { nJobs++; jobSeeds += L.n; } else nRound++;
             critical += L.maxPush; total += L.sumPush;
         }
-        fprintf(stderr, "model: %zu seeds, %zu blocks, failures %lld, rounds %lld, job launches %lld (%lld jobs, %lld used), conflict launches %lld, over-predicted %lld, %.1f s\n",
+        fprintf(stderr, "model: %zu seeds, %zu blocks, failures %lld, rounds %lld, job launches %lld (%lld jobs, %lld used), conflict launches %lld, over-predicted %lld, lazy seeds %lld, settled by the host %lld, %.1f s\n",
                 seeds.size(), blocks.size(), (long long)es.failures, (long long)es.rounds, (long long)es.recomputeLaunches, (long long)es.recomputedSeeds, (long long)es.jobsUsed,
-                (long long)es.conflictLaunches, (long long)es.overPredicted, sec);
+                (long long)es.conflictLaunches, (long long)es.overPredicted, (long long)es.lazySeeds, (long long)es.hostDead, sec);
         if (es.earlyCritical) fprintf(stderr, "model: early critical launches %lld of %lld stops\n", (long long)es.earlyCritical, (long long)es.recomputeLaunches);
         fprintf(stderr, "model: host ms: engine %.0f = processor %.0f + dry runs %.0f + commit / validation / other %.0f\n", es.wallMs, es.processMs, es.planMs, es.wallMs - es.processMs - es.planMs);
         fprintf(stderr, "model:   of the rest: round setup %.0f, validation %.0f, commit %.0f, marks to the processor %.0f | of the dry runs: marks to the processor %.0f, simulation %.0f; views built %lld\n", es.sectionMs[LCB_SEC_SETUP],

@@ -34,6 +34,8 @@ CASES = [
     ("config5_mice16_scaled", "mice16_scaled", 150),
     # ... and config 4's shape at 4.1 Gbp (P = 0.8 G occurrences: ~30 GB in the reference, most of the build container's memory)
     ("config4_primates8_4g_scaled", "primates8_4g", 150),
+    # ... and config 5's shape at 4.1 Gbp (round 6)
+    ("config5_mice16_4g_scaled", "mice16_4g", 150),
 ]
 
 

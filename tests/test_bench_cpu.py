@@ -28,6 +28,10 @@ class _FakeDevice:
     def mode_seeds(self):
         return [0, 0, 0, 0]
 
+    def mode_time(self):
+        self.calls = getattr(self, "calls", 0) + 1
+        return (4.0 * self.calls, 6.0 * self.calls, 0.0, 0.0), (2 * self.calls, self.calls, 0, 0)
+
     def close(self):
         pass
 
@@ -70,6 +74,12 @@ def test_bench_line_fields(fake_gpu, monkeypatch, capsys):
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "seeds/s" and line["config"]["workload"].startswith("10 synthetic strains")
     assert set(line["config"]["side"]) == {"batches", "jobs", "taken", "void", "failed"}
     assert line["roofline"]["kernel_ms_per_step"] == pytest.approx(12.5) and line["roofline"]["launches_per_step"] == 3
+    # per kernel variant: the difference of the device's cumulative (ms, launches) over the timed region, per step; variants that did not run are left out
+    pk = line["roofline"]["per_kernel"]
+    assert set(pk) == {"lcb_process_kernel<compact>", "lcb_process_kernel<wide>"}
+    assert pk["lcb_process_kernel<compact>"]["calls_per_step"] == 1 and pk["lcb_process_kernel<compact>"]["ms_per_step"] == pytest.approx(2.0)
+    assert pk["lcb_process_kernel<wide>"]["avg_launch_ms"] == pytest.approx(6.0) and pk["lcb_process_kernel<wide>"]["hbm_bytes_per_step"] is None
+    assert "secondary" not in line                      # (only the headline workload carries the other shapes)
     # with the roofline: the counting pass (a workload without committed counts), the triad, the traffic note
     line = _run_main(bench, monkeypatch, capsys, ["--workload", "ecoli10_tiny", "--steps", "1", "--warmup", "0", "--no-cli", "--no-cpu-baseline"])
     assert set(line["roofline"]["event_counts"]) == set(__import__("sibeliaz_amd").api.COUNTER_NAMES) and line["roofline"]["peak_measured_stream_triad"] == 4700.0
@@ -142,3 +152,29 @@ def test_ab_driver_runs_every_variant_once_loaded(fake_gpu, monkeypatch, capsys)
     out = capsys.readouterr().out.strip().splitlines()
     assert out[0].startswith("ecoli10_tiny:") and [ln.split(":")[0] for ln in out[1:]] == ["base", "nolazy", "lanes2"]
     assert "DIFFER" not in "".join(out)
+
+
+def test_secondary_entries_are_timed_by_child_runs_and_condensed(fake_gpu, monkeypatch):
+    """The k = 25 lines a default run appends: one child `bench.py --secondary-leg` per shape, its line condensed; a child that fails costs an entry, not the line."""
+    bench = fake_gpu
+    child = {"value": 1.0e6, "unit": "seeds/s", "ms_per_step": 3500.0, "steps": 3, "warmup": 1, "config": {"seeds": 3500465, "blocks_found": 700},
+             "roofline": {"bound": "hbm", "achieved": 9.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0011, "kernel_ms_per_step": 3300.0, "algorithmic_bytes_per_step": 3.2e10,
+                          "launches_per_step": 1000.0, "per_kernel": {}, "frac_of_measured_peak": 0.002},
+             "cpu_baseline": {"value": 4.0e5, "unit": "seeds/s", "cores": 32, "kind": "reference", "gff_md5_equal": True, "sample": "whole"}}
+    seen = []
+
+    class R:
+        def __init__(self, out):
+            self.stdout = out
+
+    def fake_run(cmd, **kw):
+        seen.append(cmd)
+        if "mice16_test" in cmd:
+            return R("no line here\n")
+        return R("noise\n" + json.dumps(child) + "\n")
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    sec = bench.secondary_live(("primates8_test", "mice16_test"), 4)
+    assert all("--secondary-leg" in c and "--no-cli" in c for c in seen) and len(seen) == 2
+    assert sec[0]["measured_in_this_run"] is True and sec[0]["speedup_over_cpu_baseline"] == pytest.approx(2.5) and sec[0]["roofline"]["frac"] == 0.0011
+    assert sec[0]["sources"] == bench.source_hash() and sec[0]["cpu_baseline"]["gff_md5_equal"] is True
+    assert sec[1]["workload"] == "mice16_test" and "error" in sec[1]

@@ -34,13 +34,13 @@ def test_ctypes_structs_have_the_layout_of_the_header(built, tmp_path):
     from sibeliaz_amd import api
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lcb.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lcb_stats), sizeof(lcb_hooks), '
-                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, lazy_seeds), offsetof(lcb_hooks, lazy_span), '
+                   'sizeof(lcb_device_opts), sizeof(lcb_seed), sizeof(lcb_block), sizeof(lcb_instance), offsetof(lcb_stats, host_dead), offsetof(lcb_hooks, sparse_rounds), '
                    'offsetof(lcb_device_opts, seg_gap)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     want = [C.sizeof(api.Stats), C.sizeof(api.Hooks), C.sizeof(api.DeviceOpts), sibeliaz_amd.SEED_DTYPE.itemsize, sibeliaz_amd.BLOCK_DTYPE.itemsize,
-            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.lazy_seeds.offset, api.Hooks.lazy_span.offset, api.DeviceOpts.seg_gap.offset]
+            sibeliaz_amd.INSTANCE_DTYPE.itemsize, api.Stats.host_dead.offset, api.Hooks.sparse_rounds.offset, api.DeviceOpts.seg_gap.offset]
     assert got == want
     header = open(os.path.join(ROOT, "include", "lcb.h")).read()
     assert int(re.search(r"#define LCB_ABI_VERSION (\d+)", header).group(1)) == api.ABI_VERSION == sibeliaz_amd.load_library().lcb_abi_version()
@@ -269,6 +269,11 @@ def emu_built():
                                             ("inv_k25", "medium", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "777", "EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_FP_CHECK": "1"}),
                                             ("inv_k25", "big", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "100000", "EMU_NW": "16", "EMU_NOSTATS": "1", "EMU_LIMIT": "200", "EMU_SCHED": "rr", "EMU_FP_CHECK": "1"}),
                                             ("twogenomes", "huge", {"EMU_SEG_CAP": "1000", "EMU_LIMIT": "800"}),
+                                            # footprint slots shared across segments (the EMU_SHARE build has a sixteenth of the slots): an instance of the backward
+                                            # extension that would have to share a slot of ANOTHER segment ends the seed with an overflow status and the next variant
+                                            # re-runs it (the shared hull kept the old segment and did not cover the new instance's reads)
+                                            ("twogenomes", "seeds-init", {"EMU_SEG_CAP": "1000", "EMU_SHARE": "1", "EMU_LIMIT": "900", "EMU_FP_CHECK": "1"}),
+                                            ("tandem4", "seeds-init", {"EMU_SEG_CAP": "1500", "EMU_SHARE": "1", "EMU_LIMIT": "700", "EMU_FP_CHECK": "1", "EMU_NOSTATS": "1"}),
                                             ("nruns_abund", "find", {"EMU_SEG_CAP": "1500", "EMU_SEG_GAP": "1000", "EMU_ROUNDS": "64"}),
                                             ("twogenomes", "find", {"EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "70000", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_NW": "2"}),
                                             ("tandem4", "find", {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "123457", "EMU_NOSTATS": "1", "EMU_SHARE": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "1", "EMU_SIDE_LATE": "1", "LCB_LAZY_SPAN": "8"})])
