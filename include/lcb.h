@@ -262,11 +262,12 @@ typedef struct {
     int32_t lazy_span;          /* a round spans at least this many phases: the phases beyond the (adaptive) size of its speculative launch get their
                                    phase-start results as background jobs against predicted views, planned while the commit works through the stops of the
                                    phases in front of them. Default 8; -1 = off (a round is exactly its speculative launch) */
-    int32_t sparse_rounds;      /* sparse speculative launches (round 6): seeds sorted next to each other lie next to each other in the genome
-                                   (Bundle::operator<, blocksfinder.h:195-208), so the seeds behind the first one of a collinear stretch are dead
-                                   by the time their phase starts - a round launches only the seeds of the FIRST phase of every such cluster and
-                                   spans as many phases as that takes; the others are resolved on the host when their phase starts (no unused
-                                   occurrence: empty result) or computed then. Default (0) on, -1 = off */
+    int32_t sparse_rounds;      /* round 6. 0 (default): the host settles the results it can settle itself - a seed none of whose occurrences is unused with its
+                                   character has an empty result against every later state too (lcb_stats.host_dead) - instead of asking the device. 1: also
+                                   sparse speculative launches: seeds sorted next to each other lie next to each other in the genome (Bundle::operator<,
+                                   blocksfinder.h:195-208), so a round launches only the seeds of the FIRST phase of every such cluster and spans as many
+                                   phases as that takes; the others are settled on the host when their phase starts, or computed then (measured: slower on
+                                   every test shape, neutral at Gbp scale - an experiment, not a default). -1: neither */
 } lcb_hooks;
 int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, const lcb_seed* seeds, int64_t n_seeds,
                        const lcb_hooks* hooks, lcb_block** blocks, int64_t* n_blocks, lcb_stats* stats);

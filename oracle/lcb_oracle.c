@@ -137,10 +137,23 @@ static int it_valid(const orc_graph* g, SeqIt it)                               
 {
     return it.idx >= 0 && it.idx < g->nPos[it_chr(it)];
 }
+/* Diagnostics for tests/emu/engine_model (pricing of resumable seeds; not part of the reference): a `used` byte with bit 1 set besides
+ * bit 0 is WATCHED - still used, as far as the algorithm is concerned -, and between orc_watch_begin() and orc_watch_end() the
+ * number of pushes made before the first read of a watched byte is recorded (pushes of the replay, BF:271-284, do not count:
+ * the device restarts at a checkpoint instead). Per thread. */
+static __thread int tl_watchOn = 0, tl_inReplay = 0;
+static __thread int64_t tl_pushes = 0, tl_watchFirst = -1;
+void orc_watch_begin(void) { tl_watchOn = 1; tl_pushes = 0; tl_watchFirst = -1; tl_inReplay = 0; }
+int64_t orc_watch_end(int64_t* pushes) { tl_watchOn = 0; if (pushes) *pushes = tl_pushes; return tl_watchFirst; }
+static int used_byte(uint8_t u)
+{
+    if ((u & 2) && tl_watchOn && tl_watchFirst < 0) tl_watchFirst = tl_pushes;
+    return u;
+}
 static int it_used(const orc_graph* g, SeqIt it)                                   /* JS:270 */
 {
-    if (it_positive(it)) return g->position[it_chr(it)][it.idx].used;
-    if (it.idx > 0) return g->position[it_chr(it)][it.idx - 1].used;
+    if (it_positive(it)) return used_byte(g->position[it_chr(it)][it.idx].used);
+    if (it.idx > 0) return used_byte(g->position[it_chr(it)][it.idx - 1].used);
     return 0;
 }
 static void it_mark_used(orc_graph* g, SeqIt it)                                   /* JS:285 */
@@ -775,6 +788,7 @@ static int path_point_push_back(Path* p, const Edge* e)                         
     p->nRight++;
     p->rightBodyFlank = startVertexDistance + e->length;                            /* Point::EndDistance, PH:204 */
     if (p->ctr) p->ctr->n_push++;
+    if (!tl_inReplay) tl_pushes++;
     return 1;
 }
 
@@ -791,6 +805,7 @@ static int path_point_push_front(Path* p, const Edge* e)                        
     p->nLeft++;
     p->leftBodyFlank = startVertexDistance;
     if (p->ctr) p->ctr->n_push++;
+    if (!tl_inReplay) tl_pushes++;
     return 1;
 }
 
@@ -978,7 +993,9 @@ static void process(Finder* f, int64_t vid, char initChar, int64_t* bestScoreOut
         for (int64_t i = 0; i < nEdge; i++) bestEdge[i] = p->rightBody[i].edge;
         path_clear(p);
         path_init(p, vid, initChar);
+        tl_inReplay = 1;
         for (int64_t i = 0; i < nEdge; i++) path_point_push_back(p, &bestEdge[i]);
+        tl_inReplay = 0;
         free(bestEdge);
         if (p->fpOn && p->fpMode == 2) { p->fpSplit = p->nPool; p->fpShift = p->nFp - p->nPool; }
     }

@@ -71,6 +71,9 @@ const char* orc_chr_name(const orc_graph* g, int64_t chr);
 void orc_chr_positions(const orc_graph* g, int64_t chr, int32_t* id, uint32_t* pos);
 /* `used` flags of position_[chr] (one byte per entry); writable, for differential tests */
 uint8_t* orc_chr_used(orc_graph* g, int64_t chr);
+/* diagnostics (tests/emu/engine_model): pushes made before the first read of a watched `used` byte (value 3), per thread; -1 = none was read */
+void orc_watch_begin(void);
+int64_t orc_watch_end(int64_t* pushes);
 void orc_reset_used(orc_graph* g);
 
 /* Seed enumeration + sort, blocksfinder.h:461-503,517. Returns S. */

@@ -7,7 +7,7 @@ import numpy as np
 
 path = sys.argv[1]
 op = gzip.open if path.endswith(".gz") else open
-launch, seeds = {}, collections.defaultdict(list)
+launch, seeds, grid = {}, collections.defaultdict(list), {}
 for line in op(path, "rt"):
     f = line.rstrip("\n").split("\t")
     if f[0] == "#seed":
@@ -16,7 +16,7 @@ for line in op(path, "rt"):
         d["vid"] = int(f[3])
         seeds[int(f[1])].append(d)
     else:
-        launch[int(f[0])] = (int(f[1]), f[3], float(f[4]))
+        launch[int(f[0])] = (int(f[1]), f[3], float(f[4])); grid[int(f[0])] = int(f[2])
 ms = np.array([v[2] for v in launch.values()])
 n = np.array([v[0] for v in launch.values()])
 mode = np.array([v[1] for v in launch.values()])
@@ -43,27 +43,28 @@ if allp:
     for d in big:
         print("   slow seed vid=%d st=%d ticks=%.1f us push=%d vote=%d inst=%d  -> %.1f us/push" % (d["vid"], d["st"], d["ticks"] / 100.0, d["push"], d["vote"], d["inst"], d["ticks"] / 100.0 / max(1, d["push"])))
 
-# ---- per-launch critical path: how much of each launch is its longest seed vs the work spread over the slots
+# ---- per-launch critical path: how much of each launch is its longest seed vs the work of all its seeds spread over the workgroups of its grid
 if allp:
     rows = []
     for lid, (nn, md, t) in launch.items():
         sd = seeds.get(lid, [])
-        if not sd:
-            rows.append((nn, t, 0.0, 0.0, md)); continue
-        tks = np.array([d["ticks"] for d in sd]) / 1e5          # ms
-        wgs = collections.defaultdict(float)
-        for d in sd:
-            wgs[d.get("wg", 0)] += d["ticks"] / 1e5
-        rows.append((nn, t, tks.max(), max(wgs.values()), md))
-    rows = np.array([(r[0], r[1], r[2], r[3]) for r in rows])
-    tot = rows[:, 1].sum()
-    print("critical path: sum of launch ms %.1f | sum of longest-seed ms %.1f (%.0f%%) | sum of busiest-workgroup ms %.1f (%.0f%%)" % (
-        tot, rows[:, 2].sum(), 100 * rows[:, 2].sum() / tot, rows[:, 3].sum(), 100 * rows[:, 3].sum() / tot))
-    for lo, hi in ((1, 1), (2, 16), (17, 256), (257, 4096), (4097, 1 << 30)):
-        sel = (rows[:, 0] >= lo) & (rows[:, 0] <= hi)
-        if sel.any():
-            print("  launches with %6d..%-10d seeds: %5d launches %8.1f ms  longest-seed %8.1f ms  busiest-wg %8.1f ms  mean ms %.3f" % (
-                lo, hi, sel.sum(), rows[sel, 1].sum(), rows[sel, 2].sum(), rows[sel, 3].sum(), rows[sel, 1].mean()))
+        tks = np.array([d["ticks"] for d in sd]) / 1e5 if sd else np.zeros(1)          # ms
+        rows.append((nn, t, tks.max(), tks.sum() / max(1, grid.get(lid, 1)), len(sd), md))
+    R = np.array([r[:5] for r in rows]); M = np.array([r[5] for r in rows])
+    tot = R[:, 1].sum()
+    print("critical path: sum of launch ms %.1f | sum of longest-seed ms %.1f (%.0f%%) | sum of (work of the traced seeds / workgroups of the grid) ms %.1f (%.0f%%)" % (
+        tot, R[:, 2].sum(), 100 * R[:, 2].sum() / tot, R[:, 3].sum(), 100 * R[:, 3].sum() / tot))
+    for md in ("compact", "wide", "big"):
+        for lo, hi in ((1, 1), (2, 16), (17, 512), (513, 4096), (4097, 1 << 30)):
+            sel = (M == md) & (R[:, 0] >= lo) & (R[:, 0] <= hi)
+            if sel.any():
+                print("  %-7s launches of %6d..%-10d seeds: %5d launches %9.1f ms | longest seed %9.1f ms | work / grid %9.1f ms | traced (> 20 us) seeds per launch %.0f, mean launch %.3f ms" % (
+                    md, lo, hi, sel.sum(), R[sel, 1].sum(), R[sel, 2].sum(), R[sel, 3].sum(), R[sel, 4].mean(), R[sel, 1].mean()))
+    pu = np.array([d["push"] for d in allp]); tk = np.array([d["ticks"] for d in allp]) / 100.0
+    for lo, hi in ((0, 10), (10, 100), (100, 1000), (1000, 10000), (10000, 1 << 40)):
+        s = (pu >= lo) & (pu < hi)
+        if s.any():
+            print("  seeds with %6d..%-8d pushes: %8d seeds, %9.2f wave-seconds, us/push %.2f" % (lo, hi, s.sum(), tk[s].sum() / 1e6, tk[s].sum() / max(1, pu[s].sum())))
     ppu = np.array([d["ticks"] / 100.0 / d["push"] for d in allp if d["push"] >= 50])
     ins = np.array([d["inst"] for d in allp if d["push"] >= 50])
     for lo, hi in ((0, 8), (8, 32), (32, 64), (64, 128), (128, 256), (256, 100000)):

@@ -253,8 +253,11 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // batch is dealt like a launch - job k of it runs on a lane of rank k % world - and results travel through exchangeSide below.
     const bool multi = world > 1 || (cfg.exchangeAlways && cfg.allgather);
     const bool useSide = !cfg.syncJobs && !cfg.countEvents && proc.sideLanes() > 0;
-    // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs (one rank)
-    const bool useEarly = useSide && !multi;
+    // ... and the results a stop cannot go on without are computed while the host still plans the rest of the stop's jobs. With several
+    // ranks (round 6) EVERY rank computes them itself instead of being dealt a share: they run against the live state, which is the same on
+    // all ranks, and the kernels are deterministic - so every rank holds the same results without a collective, and a stop's own F (one
+    // seed: nothing to divide) no longer costs two all-gathers.
+    const bool useEarly = useSide;
     std::vector<lcb_seed> earlySeeds;
     struct SideJob { int64_t seed; bool isF; int32_t set, epoch; int lane; int64_t k; uint8_t state; };   // lane: index into `batches`; k: job of the batch; state: 0 in flight, 1 taken, 2 dropped
     struct SideBatch { int lane; int pending; };    // the processor's lane on THIS rank (-1: this rank has no job of the batch), jobs in flight (on all ranks)
@@ -406,7 +409,7 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     // and spans as many phases as it takes to collect roundPhases x 256 of them (at most sparseSpan phases): the first phases of many blocks
     // are in flight at once. The other seeds are lazy (no result): dead ones are settled by the host when their phase starts, a live one
     // (the guess was wrong: its cluster holds more than one block) is computed then, like the seeds of a lazy tail. Exactness is untouched.
-    const bool sparse = hostScreen && lazySpan > 0;
+    const bool sparse = hostScreen && lazySpan > 0 && cfg.sparseRounds > 0;    // (measured on the MI355X, profiles/r06: off by default)
     const int sparseSpan = 1024;
     // (the guess costs time, never exactness: a gap too small launches the seeds of a block's later phases for nothing, one too large leaves the first
     // phase of the next block to a stop of the commit - what a lazy tail does)

@@ -191,7 +191,7 @@ struct LcbEngineConfig {
     bool exchangeAlways = false;   // world == 1 still goes through pack / all-gather / unpack (tests of the exchange path)
     int lazySpan = 0;         // a round spans at least this many phases: those beyond the adaptive launch size get their phase-start results as jobs (0 = 8, -1 = off)
     bool syncJobs = false;    // never use the processor's side lanes: every job of a stop's plan runs in one synchronous launch (the round-2 engine)
-    int sparseRounds = 0;     // sparse speculative launches + host-resolved dead seeds (lcb_hooks.sparse_rounds): 0 = default (on), -1 = off
+    int sparseRounds = 0;     // lcb_hooks.sparse_rounds: 0 = host-settled dead seeds (default), 1 = also sparse speculative launches, -1 = neither
 };
 
 enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch (lists of the seeds that read or commit anything)

@@ -83,7 +83,14 @@ template <int MODE> struct LcbCfg;
 // Idx: a pool index / a vote-table slot (16 bits where the capacities are compile-time constants of a few thousand; 32 bits in the huge
 // variant, whose capacities grow with the path - the reference's vectors are unbounded, path.h:683-685); VLast: (ordinal of the last
 // contributing instance in the voting list, step) of a vote-table entry - 16 + 16 bits, or 32 + 32.
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+// (-DLCB_COMPACT_IC / -DLCB_COMPACT_VC: experiment builds of the compact variant with smaller pools - more workgroups per CU, lcb_device_opts.compact_slots)
+#ifndef LCB_COMPACT_IC
+#define LCB_COMPACT_IC 256
+#endif
+#ifndef LCB_COMPACT_VC
+#define LCB_COMPACT_VC 1024
+#endif
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = LCB_COMPACT_IC, VC = LCB_COMPACT_VC, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; typedef uint32_t Idx; typedef unsigned long long VLast; };

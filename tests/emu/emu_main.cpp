@@ -533,7 +533,7 @@ int main(int argc, char** argv)
                 if (getenv("LCB_PREDICT_F")) cfg.predictF = std::max(1, envInt("LCB_PREDICT_F"));
                 if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES") ? envInt("LCB_EAGER_PHASES") : -1;
                 if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN") ? envInt("LCB_LAZY_SPAN") : -1;
-                if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS")) > 0 ? 1 : -1;
+                if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS"));   // -1 / 0 / 1 (lcb_hooks.sparse_rounds)
                 cfg.countEvents = !getenv("EMU_NOSTATS");   // stats-mode kernels: the engine sums the events of exactly the reference's Process() calls (host commit only)
                 LcbEngineStats es;
                 lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocks, &es);
@@ -597,7 +597,7 @@ int main(int argc, char** argv)
                         EmuRankLink link{&ex, r};
                         LcbEngineConfig cfg; cfg.roundPhases = R; cfg.rank = r; cfg.world = world;
                         if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = atoi(getenv("LCB_LAZY_SPAN")) ? atoi(getenv("LCB_LAZY_SPAN")) : -1;
-                        if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS")) > 0 ? 1 : -1;
+                        if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS"));   // -1 / 0 / 1 (lcb_hooks.sparse_rounds)
                         cfg.allgather = emuAllgather; cfg.allgatherUser = &link;
                         lcb_engine_run(g, &p, seeds.data(), (int64_t)seeds.size(), proc, cfg, blocksOf[(size_t)r], &statsOf[(size_t)r]);
                     } catch (std::exception& e) { errOf[(size_t)r] = e.what(); }

@@ -43,7 +43,16 @@ struct OracleProc : LcbProcessor {
     std::vector<Launch> launches;
     int stride = 1;
     // the last result of every (vertex, character): how many recomputations reproduce it, and how long they were
-    std::unordered_map<uint64_t, std::pair<std::vector<lcb_instance>, int64_t>> last;
+    struct LastRec { std::vector<lcb_instance> first; int64_t second = 0; std::vector<lcb_fp> fp; size_t markLen = 0; };
+    std::unordered_map<uint64_t, LastRec> last;
+    // Pricing of resumable seeds (round 6): the marks committed since a seed's previous computation that lie inside its previous footprint are what voided
+    // that result; the new computation is identical to the old one up to its first read of one of those positions (the oracle counts the pushes made until
+    // then: orc_watch_*), so a checkpoint taken before that read would be a valid restart. resume*: sums over all recomputations.
+    std::vector<std::pair<uint64_t, uint64_t>> markLog;          // every range ever marked, in order
+    int64_t resumeN = 0, resumeNoMarks = 0, resumeWhole = 0, resumePushes = 0, resumePrefix = 0, resumePushesHit = 0;
+    int64_t criticalResume = 0;                                  // sum over the synchronous launches of their longest seed with the resumable prefix taken off
+    const bool resumeClock = getenv("MODEL_RESUME") != nullptr;  // the virtual clock runs with resumption (durations without the resumable prefix)
+    const int64_t ckEvery = 32;                                  // LCB_CK_EVERY: a checkpoint every 32 pushes
     int64_t recomputed = 0, identical = 0, identicalPushes = 0, recomputedPushes = 0, launchesLongestIdentical = 0;
     int64_t criticalNew = 0;       // critical path if no launch had to wait for a seed that merely reproduces its previous result
     // Virtual clock in pushes (a synchronous launch lasts as long as its longest seed; enough workgroups for every seed of a launch) and
@@ -119,6 +128,7 @@ struct OracleProc : LcbProcessor {
         std::vector<std::vector<lcb_instance>> ri((size_t)n);
         std::vector<std::vector<lcb_fp>> rf((size_t)n);
         std::vector<int64_t> pushes((size_t)n, 0), pool((size_t)n, 0);
+        std::vector<int64_t> own((size_t)n, 0), firstHit((size_t)n, -2);      // pushes without the replay's; pushes before the first read of a voiding mark (-1: none read, -2: no mark inside the old footprint)
         const int64_t chunk = 16;
         const int64_t nChunks = (n + chunk - 1) / chunk;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
@@ -136,9 +146,51 @@ struct OracleProc : LcbProcessor {
                     for (auto& mk : vmarks) if (mk.firstView > applied && mk.firstView <= v) setRange(o, mk.lo, mk.hi, &undo);
                     applied = v;
                 }
+                // the marks that voided the seed's previous result: committed since (markLog) or predicted by this job's view, inside the previous footprint
+                std::vector<uint8_t*> tagged;
+                bool prev = false;
+                {
+                    const uint64_t key = ((uint64_t)(uint32_t)seeds[i].vid << 8) | (uint8_t)seeds[i].ch;
+                    auto it = last.find(key);
+                    if (it != last.end() && !it->second.fp.empty()) {
+                        prev = true;
+                        std::vector<std::pair<uint64_t, uint64_t>> iv;                  // the old footprint as disjoint ascending intervals [lo, hi]
+                        for (const lcb_fp& f : it->second.fp) iv.emplace_back(f.lo, f.hi);
+                        std::sort(iv.begin(), iv.end());
+                        size_t w = 0;
+                        for (size_t r = 1; r < iv.size(); r++) { if (iv[r].first <= iv[w].second + 1) iv[w].second = std::max(iv[w].second, iv[r].second); else iv[++w] = iv[r]; }
+                        iv.resize(w + 1);
+                        auto tag = [&](uint64_t mlo, uint64_t mhi) {                    // [mlo, mhi)
+                            if (mlo >= mhi) return;
+                            size_t a = (size_t)(std::upper_bound(iv.begin(), iv.end(), std::make_pair(mlo, (uint64_t)~0ull)) - iv.begin());
+                            if (a > 0 && iv[a - 1].second >= mlo) a--;
+                            const std::vector<uint64_t>& cs = g->chrStart;
+                            for (; a < iv.size() && iv[a].first < mhi; a++) {
+                                const uint64_t lo = std::max(mlo, iv[a].first), hi = std::min(mhi, iv[a].second + 1);
+                                if (lo >= hi) continue;
+                                size_t cI2 = (size_t)(std::upper_bound(cs.begin(), cs.end(), lo) - cs.begin()) - 1;
+                                for (uint64_t q = lo; q < hi; q++) {
+                                    while (q >= cs[cI2 + 1]) cI2++;
+                                    uint8_t* u = orc_chr_used(o, (int64_t)cI2) + (q - cs[cI2]) * (uint64_t)stride;
+                                    if (*u == 1) { *u = 3; tagged.push_back(u); }
+                                }
+                            }
+                        };
+                        for (size_t r = it->second.markLen; r < markLog.size(); r++) tag(markLog[r].first, markLog[r].second);
+                        for (auto& mk : vmarks) if (mk.firstView <= v && mk.firstView > 0) tag(mk.lo, mk.hi);
+                    }
+                }
+                orc_watch_begin();
                 orc_counters c; memset(&c, 0, sizeof(c));
                 int64_t score = 0, nfp = 0;
                 const int64_t k = orc_worker_process(ow[(size_t)t], seeds[i].vid, seeds[i].ch, buf.data(), (int64_t)buf.size(), &score, &c, fbuf.data(), (int64_t)fbuf.size(), &nfp);
+                {
+                    int64_t ownPushes = 0;
+                    const int64_t fh = orc_watch_end(&ownPushes);
+                    own[(size_t)i] = ownPushes;
+                    firstHit[(size_t)i] = !prev ? -3 : (tagged.empty() ? -2 : fh);     // -3: no previous result
+                    for (uint8_t* u : tagged) *u = 1;
+                }
                 if (k > (int64_t)buf.size() || nfp > (int64_t)fbuf.size()) { fprintf(stderr, "model: result too large\n"); exit(2); }
                 ri[(size_t)i].resize((size_t)k);
                 for (int64_t e = 0; e < k; e++) ri[(size_t)i][(size_t)e] = lcb_instance{buf[e].chr, buf[e].front_idx, buf[e].back_idx, buf[e].positive ? 1u : 0u};
@@ -166,6 +218,19 @@ struct OracleProc : LcbProcessor {
             else if (pl > 256) L.nWideOvf++;
         }
         off[(size_t)n] = inst.size(); fpOff[(size_t)n] = fp.size();
+        // the resumable prefix of every recomputation (in pushes of the model's clock, which include the replay's)
+        std::vector<int64_t> eff(pushes);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t fh = firstHit[(size_t)i];
+            if (fh == -3) continue;
+            resumeN++; resumePushes += own[(size_t)i];
+            if (fh == -2) { resumeNoMarks++; continue; }            // voided by something else than a mark in its footprint (a prediction that did not come true)
+            resumePushesHit += own[(size_t)i];
+            int64_t prefix = fh < 0 ? own[(size_t)i] : (fh / ckEvery) * ckEvery;
+            if (fh < 0) resumeWhole++;
+            resumePrefix += prefix;
+            if (own[(size_t)i] > 0) eff[(size_t)i] = pushes[(size_t)i] - prefix * pushes[(size_t)i] / own[(size_t)i];
+        }
         {
             int64_t longest = -1, longestNew = 0; bool longestIdentical = false;
             for (int64_t i = 0; i < n; i++) {
@@ -179,13 +244,15 @@ struct OracleProc : LcbProcessor {
                 }
                 if (pushes[(size_t)i] > longest) { longest = pushes[(size_t)i]; longestIdentical = same; }
                 if (!same && pushes[(size_t)i] > longestNew) longestNew = pushes[(size_t)i];
-                last[key] = std::make_pair(ri[(size_t)i], pushes[(size_t)i]);
+                LastRec& rec = last[key];
+                rec.first = ri[(size_t)i]; rec.second = pushes[(size_t)i]; rec.fp = rf[(size_t)i]; rec.markLen = markLog.size();
             }
             if (longestIdentical) launchesLongestIdentical++;
             criticalNew += longestNew;
         }
-        lastPushes = pushes;
+        lastPushes = resumeClock ? eff : pushes;
         if (inSide) { sidePushes += L.sumPush; return; }       // a background batch: not a launch the commit waits for
+        { int64_t mx = 0; for (int64_t i = 0; i < n; i++) mx = std::max(mx, eff[(size_t)i]); criticalResume += mx; if (resumeClock) L.maxPush = mx; }
         now += L.maxPush;
         launches.push_back(L);
         if (getenv("LCB_ENGINE_DEBUG_JOBS")) for (int64_t i = 0; i < n; i++) fprintf(stderr, "   done %lld pushes %lld inst %zu pool %lld\n", (long long)i, (long long)pushes[(size_t)i], ri[(size_t)i].size(), (long long)pool[(size_t)i]);
@@ -195,6 +262,7 @@ struct OracleProc : LcbProcessor {
     }
     void mark(const uint64_t* r, int64_t n) override
     {
+        for (int64_t i = 0; i < n; i++) markLog.emplace_back(r[2 * i], r[2 * i + 1]);
         for (orc_graph* o : og) for (int64_t i = 0; i < n; i++) setRange(o, r[2 * i], r[2 * i + 1], nullptr);
     }
     void reset() override { for (orc_graph* o : og) orc_reset_used(o); }
@@ -238,7 +306,7 @@ int main(int argc, char** argv)
         if (getenv("LCB_EAGER_PHASES")) cfg.eagerPhases = envInt("LCB_EAGER_PHASES", 0) ? envInt("LCB_EAGER_PHASES", 0) : -1;
         cfg.roundFixed = envInt("LCB_ROUND_FIXED", 0) != 0;
         if (getenv("LCB_LAZY_SPAN")) cfg.lazySpan = envInt("LCB_LAZY_SPAN", 0) ? envInt("LCB_LAZY_SPAN", 0) : -1;
-        if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS")) > 0 ? 1 : -1;
+        if (getenv("LCB_SPARSE_ROUNDS")) cfg.sparseRounds = atoi(getenv("LCB_SPARSE_ROUNDS"));   // -1 / 0 / 1 (lcb_hooks.sparse_rounds)
         std::vector<lcb_block> blocks;
         LcbEngineStats es;
         const auto t0 = std::chrono::steady_clock::now();
@@ -287,6 +355,12 @@ int main(int argc, char** argv)
                 (long long)proc.now, proc.lanes.size(), (long long)es.sideBatches, (long long)es.sideJobs, (long long)es.sideTaken, (long long)es.sideVoid, (long long)proc.sidePushes, (long long)proc.sideWaited);
         fprintf(stderr, "model: recomputations %lld (%lld pushes), of which reproduced the previous result of the seed: %lld (%lld pushes); launches whose longest seed was such a reproduction: %lld; critical path without the reproductions: %lld pushes\n",
                 (long long)proc.recomputed, (long long)proc.recomputedPushes, (long long)proc.identical, (long long)proc.identicalPushes, (long long)proc.launchesLongestIdentical, (long long)proc.criticalNew);
+        fprintf(stderr, "model: resumable seeds (checkpoint every %lld pushes, pushes without the replay's): %lld recomputations of seeds with a previous footprint, %lld pushes; %lld of them (%lld pushes) had a mark inside "
+                "their previous footprint - %lld of those never read one (the whole result stands), identical prefix %lld pushes = %.1f %% of their pushes, %.1f %% of all recomputation pushes; %lld had none (a prediction that did not come true)\n",
+                (long long)proc.ckEvery, (long long)proc.resumeN, (long long)proc.resumePushes, (long long)(proc.resumeN - proc.resumeNoMarks), (long long)proc.resumePushesHit, (long long)proc.resumeWhole,
+                (long long)proc.resumePrefix, 100.0 * proc.resumePrefix / std::max<int64_t>(1, proc.resumePushesHit), 100.0 * proc.resumePrefix / std::max<int64_t>(1, proc.resumePushes), (long long)proc.resumeNoMarks);
+        fprintf(stderr, "model: critical path of the synchronous launches %lld pushes; with every recomputation resumed at its last clean checkpoint %lld pushes%s\n", (long long)critical, (long long)proc.criticalResume,
+                proc.resumeClock ? " (MODEL_RESUME: the virtual clock above runs with resumption)" : "");
         if (getenv("MODEL_DUMP")) {
             FILE* f = fopen(getenv("MODEL_DUMP"), "w");
             for (auto& bl : blocks) fprintf(f, "%d\t%llu\t%llu\t%llu\n", bl.id, (unsigned long long)bl.chr, (unsigned long long)bl.start, (unsigned long long)bl.end);

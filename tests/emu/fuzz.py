@@ -59,6 +59,11 @@ def case_params(i, small=False):
     seg["EMU_SEG_MAX"] = "2" if big else "16"
     runs.append((rnd.choice(["seeds-init", "seeds-final"]), dict(seg, EMU_NOSTATS="1", EMU_FP_CHECK="1", EMU_LIMIT="600", EMU_NW=rnd.choice(["1", "2"]))))
     if not big: runs.append(("find", dict(seg, EMU_NOSTATS="1", EMU_ROUNDS=rnd.choice(["1", "7", "256"]), EMU_SIDE_LANES=rnd.choice(["1", "3"]), EMU_SIDE_DELAY=rnd.choice(["0", "2"]))))
+    # round 6 (drawn last of all): the engine runs with sparse speculative launches / without host-settled seeds in half of the cases (default: host-settled seeds only)
+    sr = rnd.choice(["1", "1", "-1", None, None, None])
+    if sr is not None:
+        for mode, env in runs:
+            if mode == "find": env["LCB_SPARSE_ROUNDS"] = sr
     return synth, (k, b, m, a), runs, (strains, segs)
 
 

@@ -67,6 +67,8 @@ def test_two_rank_gloo_matches_reference(built, tmp_path, name, rounds):
                                             ("inv_k25", 2, {"EMU_SIDE_LANES": "3", "EMU_SIDE_DELAY": "1000", "EMU_ROUNDS": "64"}),
                                             # eight ranks (results do not depend on 1 / 2 / 4 / 8 ranks), with and without background batches
                                             ("inv_k25", 8, {}), ("nruns_abund", 8, {"EMU_SIDE_LANES": "2", "EMU_SIDE_DELAY": "1", "LCB_LAZY_SPAN": "8"}),
+                                            # sparse speculative launches / no host-settled seeds (lcb_hooks.sparse_rounds 1 / -1): every rank settles the same seeds
+                                            ("nruns_abund", 3, {"EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "1"}), ("tandem4", 2, {"EMU_SIDE_LANES": "2", "EMU_ROUNDS": "8", "LCB_SPARSE_ROUNDS": "-1"}),
                                             # ... and with positions as (segment, offset) pairs (the SEG kernels; test_host_cpu.py)
                                             ("tandem4", 4, {"EMU_SEG_CAP": "3000", "EMU_SEG_GAP": "99991", "EMU_SIDE_LANES": "2"})])
 def test_multi_rank_engine_with_real_footprints(built, tmp_path, name, ranks, env):

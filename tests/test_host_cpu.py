@@ -256,6 +256,13 @@ def emu_built():
                                             ("smallb", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "8", "EMU_SIDE_LANES": "2", "LCB_MAX_JOBS": "4", "LCB_LAZY_SPAN": "8"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_EXPECT_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2", "EMU_SIDE_CAP": "20", "EMU_SIDE_LATE": "1"}),
                                             ("nruns_abund", "find", {"EMU_NOSTATS": "1", "EMU_NO_EARLY": "1", "EMU_ROUNDS": "64", "EMU_SIDE_LANES": "2"}),
+                                            # round 6: results the host settles itself (dead seeds; default) / also sparse speculative launches (lcb_hooks.sparse_rounds = 1:
+                                            # only the first phase of every cluster of seeds is launched, rounds of up to 1 024 phases) / neither
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "1"}),
+                                            ("tandem4", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "EMU_SIDE_LATE": "1", "LCB_LAZY_SPAN": "2", "LCB_SPARSE_ROUNDS": "1", "LCB_CLUSTER_GAP": "50"}),
+                                            ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_DELAY": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "1", "LCB_CLUSTER_GAP": "1000000"}),
+                                            ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "-1"}),
+                                            ("twogenomes", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "LCB_SPARSE_ROUNDS": "-1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"}),
