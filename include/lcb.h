@@ -85,7 +85,7 @@ typedef struct {
     int64_t recomputed_seeds;   /* ... jobs in those launches */
     int64_t conflict_launches;  /* job launches whose stop was a conflicting seed waiting for its re-processed result (blocksfinder.h:406-411) */
     int64_t conflict_seeds;     /* jobs that re-process a (predicted) conflict against the (predicted) live state */
-    int64_t exchanges;          /* all-gathers (multi-rank) */
+    int64_t exchanges;          /* variable-size exchanges between the ranks (multi-rank): a launch's results, published background results, agreements */
     int64_t jobs_used;          /* job results that passed the exact validation and were committed from */
     int64_t views_built;        /* predicted `used` views materialised on the device */
     int64_t over_predicted;     /* validations that failed because a predicted mark did not come true */
@@ -103,6 +103,7 @@ typedef struct {
                                    (kernel_ms is their SUM; the side lanes' kernels run beside the synchronous ones, so the sum can exceed the pass) */
     double kernel_side_ms;      /* the part of kernel_ms that ran on the side lanes' streams */
     int64_t lazy_seeds;         /* seeds in the lazy tails of the rounds: no speculative launch, their phase-start results are background jobs (lcb_hooks.lazy_span) */
+    int64_t collectives;        /* all-gathers issued for the exchanges: one where every rank's buffer is small, else two */
     int64_t host_dead;          /* results settled on the host without the device: no unused occurrence of the seed's vertex carries its character (lcb_hooks.sparse_rounds) */
 } lcb_stats;
 
@@ -140,7 +141,7 @@ lcb_device* lcb_device_create(const lcb_graph* g, const lcb_params* p, int devic
  * the caller: `abi` must hold the LCB_ABI_VERSION of the header it was compiled against (a mismatch is rejected, not misread). */
 typedef struct {
     uint32_t abi;            /* = LCB_ABI_VERSION */
-    uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 5 per CU */
+    uint32_t compact_slots;  /* workgroups (= seeds in flight) of the compact kernel variant; default 5 per CU (8 with the small pools, compact_pools) */
     uint32_t wide_slots;     /* ... of the wide variant; default 1 per CU */
     uint32_t big_slots;      /* ... of the big variant (index in LDS, instance fields in HBM); default 1 per CU */
     uint32_t huge_slots;     /* ... of the huge variant (all per-path state in HBM); default 1 per 4 CUs */
@@ -166,7 +167,9 @@ typedef struct {
     uint32_t side_big_cap;   /* most jobs of one background batch that run in the big variant (seeds known to need it: one workgroup per CU for tens of
                                 milliseconds each); the others get no result there - the commit computes them when it needs them. Default: the big-variant slots of a
                                 lane (one wave); 0xFFFFFFFF = no cap */
-    uint32_t reserved0;
+    uint32_t compact_pools;  /* pools of the compact variant: 1 = 256 instances / 1 024 vote slots (5 workgroups per CU), 2 = 128 / 512 (8 per CU: more seeds in
+                                flight where paths have few instances); 0 = chosen by the input (small pools if a vertex has at most 20 occurrences on
+                                average; back to the large ones if more than 3 % of the live seeds overflow them) */
     uint64_t seg_gap;        /* unused positions between two segments of the device tables (0 = none): with 2^32 the flat indices of a
                                 small input exceed 32 bits, i.e. every 64-bit address computation of the kernels is exercised */
 } lcb_device_opts;

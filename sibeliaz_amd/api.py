@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("conflict_seeds", C.c_int64), ("exchanges", C.c_int64), ("jobs_used", C.c_int64), ("views_built", C.c_int64),
                 ("over_predicted", C.c_int64), ("process_ms", C.c_double), ("plan_ms", C.c_double)] + [("ev_" + n, C.c_uint64) for n in COUNTER_NAMES] + [
                     (n, C.c_int64) for n in ("side_batches", "side_jobs", "side_taken", "side_void", "side_failed", "early_critical")] + [
-                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64), ("host_dead", C.c_int64)]
+                    ("kernel_busy_ms", C.c_double), ("kernel_side_ms", C.c_double), ("lazy_seeds", C.c_int64), ("collectives", C.c_int64), ("host_dead", C.c_int64)]
 
 
 ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -71,7 +71,7 @@ class DeviceOpts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("abi", "compact_slots", "wide_slots", "big_slots", "huge_slots", "path_cap", "wide_path_cap", "max_views", "batch",
                                           "wide_threshold", "start_mode", "screen_min", "path_cap_max", "arena", "side_lanes")] + [
                     # test hooks of the (segment, offset) positions: small segments on small inputs, flat indices beyond 2^32 (lcb.h)
-                    ("seg_cap", C.c_uint64), ("side_big_cap", C.c_uint32), ("reserved0", C.c_uint32), ("seg_gap", C.c_uint64)]
+                    ("seg_cap", C.c_uint64), ("side_big_cap", C.c_uint32), ("compact_pools", C.c_uint32), ("seg_gap", C.c_uint64)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

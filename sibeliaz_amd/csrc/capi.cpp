@@ -261,7 +261,7 @@ int lcb_find_blocks_ex(const lcb_graph* g, lcb_device* d, const lcb_params* p, c
             stats->jobs_used = es.jobsUsed; stats->views_built = es.viewsBuilt; stats->over_predicted = es.overPredicted;
             stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
             stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
-            stats->early_critical = es.earlyCritical; stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead;
+            stats->early_critical = es.earlyCritical; stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead; stats->collectives = es.collectives;
         }
     }
     *blocks = (lcb_block*)malloc((v.size() ? v.size() : 1) * sizeof(lcb_block));

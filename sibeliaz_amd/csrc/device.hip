@@ -278,6 +278,13 @@ struct lcb_device_impl {
     }
     int64_t launches = 0, bigRetries = 0;
     int64_t modeSeeds[4] = {0, 0, 0, 0};         // seeds handed to each kernel variant since creation
+    // the compact variant's pools (lcb_device_opts.compact_pools): small = LcbCfg<4> (128 instances / 512 vote slots, 8 workgroups per CU) instead of
+    // LcbCfg<0> (256 / 1 024, 5 per CU); chosen by the input, and given up for good if too many live seeds overflow the small pools
+    bool compactSmall = false, compactAuto = false;
+    uint32_t compactLargeSlots = 0;              // ws[0].nSlots with the large pools
+    int64_t compactDone = 0, compactPoolOvf = 0; // seeds that ended in the compact variant with a result / by overflowing its instance pool or vote table
+    int compactFellBack = 0;
+    uint32_t compactIC() const { return compactSmall ? LcbCfg<4>::IC : LcbCfg<0>::IC; }
     double modeMs[4] = {0, 0, 0, 0};             // hipEvent-timed kernel time of each variant since creation (all streams) ...
     int64_t modeLaunches[4] = {0, 0, 0, 0};      // ... and its launches
     int64_t screened = 0, screenedDead = 0, viewPagesBuilt = 0;
@@ -362,7 +369,7 @@ struct lcb_device_impl {
             hipLaunchKernelGGL(lcb_screen_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, T, hSeeds, m, hOut, dLive, dCursor + 1);
             HIP_CHECK(hipGetLastError());
         }
-#define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))
+#define LCB_NW(MODE) (MODE == 3 ? LCB_NW_HUGE : (MODE == 2 ? LCB_NW_BIG : (MODE == 1 ? LCB_NW_WIDE : LCB_NW_COMPACT)))     /* (0 and 4: the compact variant) */
 #define LCB_LAUNCH(MODE, ST, PF, SG) hipLaunchKernelGGL((lcb_process_kernel<MODE, ST, LCB_NW(MODE), PF, SG>), dim3(grid), dim3(64 * LCB_NW(MODE)), 0, stream, \
                                                   T, KP, hSeeds, m, W, hOut, hArena, arenaCap, wantFp ? hFp : nullptr, fpCap)
 #define LCB_LAUNCH_SEG(MODE, ST, PF) do { if (seg) LCB_LAUNCH(MODE, ST, PF, true); else LCB_LAUNCH(MODE, ST, PF, false); } while (0)
@@ -370,6 +377,7 @@ struct lcb_device_impl {
         if (w.mode == 3) LCB_LAUNCH_MODE(3);
         else if (w.mode == 2) LCB_LAUNCH_MODE(2);
         else if (w.mode == 1) LCB_LAUNCH_MODE(1);
+        else if (compactSmall) LCB_LAUNCH_MODE(4);
         else LCB_LAUNCH_MODE(0);
 #undef LCB_LAUNCH_MODE
 #undef LCB_LAUNCH_SEG
@@ -464,7 +472,15 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         d->plan = lcb_plan_segments(*g, o.seg_cap, o.seg_gap);
         d->seg = d->plan.nSeg() > 1 || o.seg_cap != 0;
         // defaults: compact 5 workgroups per CU (LDS-bound; 4 with the segment tables of the SEG kernels), wide 1 per CU, big 1 per CU
-        if (!o.compact_slots) o.compact_slots = (d->seg ? 4 : 5) * nCu;
+        // the compact variant's pools: small ones where a vertex has few occurrences (paths of few instances: k = 25 inputs of 8-16 genomes, 6-12
+        // occurrences per vertex; the 62-strain shape has 26 at 1/40 of its size and more at full size, and its paths outgrow 128 instances)
+        if (o.compact_pools > 2) throw LcbError("lcb_device_opts.compact_pools: 0 (by the input), 1 (256 instances / 1 024 vote slots) or 2 (128 / 512)");
+        d->compactAuto = o.compact_pools == 0;
+        uint64_t nOccupied = 0;                      // vertices with an occurrence the abundance filter kept
+        for (size_t v = 0; v + 1 < g->occStart.size(); v++) nOccupied += g->occStart[v + 1] > g->occStart[v];
+        d->compactSmall = o.compact_pools == 2 || (o.compact_pools == 0 && nOccupied > 0 && g->nPos() <= 20 * nOccupied);
+        d->compactLargeSlots = o.compact_slots ? o.compact_slots : (d->seg ? 4 : 5) * nCu;
+        if (!o.compact_slots) o.compact_slots = d->compactSmall ? 8 * nCu : d->compactLargeSlots;     // (8: four wavefronts per SIMD by registers, two per workgroup)
         if (!o.wide_slots) o.wide_slots = nCu;
         if (!o.big_slots) o.big_slots = nCu;
         if (!o.huge_slots) o.huge_slots = nCu / 4 ? nCu / 4 : 1;
@@ -635,6 +651,8 @@ void lcb_device_destroy_impl(lcb_device* h)
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->views.poolPages);
             fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
+            fprintf(stderr, "   compact pools: %s (%u workgroups), %lld live seeds ended there, %lld outgrew its pools%s\n", d->compactSmall ? "128 instances / 512 vote slots" : "256 instances / 1 024 vote slots", d->ws[0].nSlots,
+                    (long long)d->compactDone, (long long)d->compactPoolOvf, d->compactFellBack ? " - the small pools were given up" : "");
             fprintf(stderr, "   result arena: %llu instances (enlarged %d times)\n", d->arenaCap, d->arenaGrown);
             fprintf(stderr, "   seeds that joined a call's big launch instead of a wide launch in front of it: %lld\n", (long long)d->joinedBig);
             for (int m = 0; m < 4; m++)
@@ -946,6 +964,7 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
         const LcbSeedOut& o = d->hOut[i];
         const int64_t s = list[at + i];
         if (o.status == LCB_ST_OK) {
+            if (mode == 0 && o.nFp) d->compactDone++;
             if (mode >= 2 && (!(A.allBig && A.start[(size_t)s] < 2) || o.poolInst > LcbCfg<1>::IC)) A.neededBig++;
             A.cnt[(size_t)s] = o.nInst;
             A.flatOff[(size_t)s] = A.flat.size();
@@ -983,6 +1002,7 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
             A.arenaOvf++;
         } else {
             if (o.status < 8) d->overflow[mode][o.status]++;
+            if (mode == 0 && (o.status == LCB_ST_INST_OVF || o.status == LCB_ST_VOTE_OVF)) d->compactPoolOvf++;
             A.tried[(size_t)s] |= (uint8_t)(1u << mode);
             // The next variant. The ladder is compact -> wide -> big -> huge by capacity of instances and vote table, but the
             // PATH capacity is the other way round between the first two: the wide variant keeps its path set in LDS (4096
@@ -991,8 +1011,8 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
             // instances than half the compact pool (the repeat-rich seeds of config 3: thousands of instances AND > 4096
             // pushes; they would crawl through the compact variant only to overflow its pool) - the rest goes on to big.
             int nextMode = mode < 3 ? mode + 1 : 3;
-            if (mode == 1 && o.status == LCB_ST_PATH_OVF && !(A.tried[(size_t)s] & 1u) && o.poolInst * 2 <= LcbCfg<0>::IC) nextMode = 0;
-            else if (mode == 0 && o.status == LCB_ST_PATH_OVF && d->ws[0].pathCap < d->o.path_cap_max && o.poolInst * 2 <= LcbCfg<0>::IC) {
+            if (mode == 1 && o.status == LCB_ST_PATH_OVF && !(A.tried[(size_t)s] & 1u) && o.poolInst * 2 <= d->compactIC()) nextMode = 0;
+            else if (mode == 0 && o.status == LCB_ST_PATH_OVF && d->ws[0].pathCap < d->o.path_cap_max && o.poolInst * 2 <= d->compactIC()) {
                 // a long path of few instances: the compact slots get a larger path set (runToCompletion) and the seed runs there again
                 A.growCompactPath = true;
                 A.tried[(size_t)s] &= (uint8_t)~1u;
@@ -1027,6 +1047,11 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             const bool screen = !d->stats && m >= d->o.screen_min;
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
+        }
+        if (mode == 0 && d->compactSmall && d->compactAuto && d->compactDone + d->compactPoolOvf >= 4096 && d->compactPoolOvf * 32 > d->compactDone + d->compactPoolOvf) {
+            // more than 3 % of the live seeds outgrow the small pools (and run again in the wide variant, one workgroup per CU): the large pools from here on
+            d->compactSmall = false; d->compactFellBack++;
+            d->ws[0].nSlots = std::min(d->ws[0].nSlots, d->compactLargeSlots);
         }
         if (A.growCompactPath) {
             // The compact path set starts small on purpose (the sets of all slots together stay cache-resident: 1280 x 128 KB)
@@ -1373,6 +1398,6 @@ void lcb_find_blocks_impl(const lcb_graph* g, lcb_device* dev, const lcb_params*
         stats->process_ms = es.processMs; stats->plan_ms = es.planMs; stats->events = es.events;
         stats->side_batches = es.sideBatches; stats->side_jobs = es.sideJobs; stats->side_taken = es.sideTaken; stats->side_void = es.sideVoid; stats->side_failed = es.sideFailed;
         stats->early_critical = es.earlyCritical;
-        stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead;
+        stats->lazy_seeds = es.lazySeeds; stats->host_dead = es.hostDead; stats->collectives = es.collectives;
     }
 }

@@ -292,25 +292,44 @@ void lcb_engine_run(const lcb_graph* g, const lcb_params* p, const lcb_seed* see
     uint64_t launchOrdinal = 0;
     std::vector<lcb_seed> shareSeeds;
     std::vector<uint32_t> shareView;
-    // All-gather of one variable-size buffer per rank (sizes first, then the payload padded to the largest): recvBuf holds world
-    // strides of `stride` bytes. The size exchange carries an error flag and a tag of the call, so that a rank that failed - or ranks
-    // that disagree about the collective they are in - stop ALL ranks with an error instead of leaving the others blocked.
+    // All-gather of one variable-size buffer per rank: recvBuf holds world strides of `stride` bytes afterwards. ONE collective when every
+    // rank's buffer is small (round 6): each rank sends a fixed-size record - a 32-byte head (size, error flag, ordinal and tag of the call)
+    // followed by the first LCB_GATHER_INLINE bytes of its buffer - and only if some rank's buffer is larger does a second collective carry the
+    // buffers padded to the largest (until round 5: always two, sizes first). The results of a stop's jobs, the published results of background
+    // jobs and the one-byte agreements are almost always small; a round's speculative launch is not. The head carries an error flag and a tag
+    // of the call, so that a rank that failed - or ranks that disagree about the collective they are in - stop ALL ranks with an error instead
+    // of leaving the others blocked.
+    constexpr uint64_t LCB_GATHER_INLINE = 8192 - 32;
+    std::vector<unsigned char> gatherSend, gatherRecv;
     auto gatherV = [&](uint64_t failed, const std::string& what, uint64_t tag, uint64_t& stride, std::vector<uint64_t>* sizes) {
-        uint64_t head[4] = {sendBuf.size(), failed, launchOrdinal, tag};
-        std::vector<uint64_t> heads((size_t)world * 4);
-        if (cfg.allgather(cfg.allgatherUser, head, sizeof(head), heads.data())) throw LcbError("all-gather failed");
+        const uint64_t head[4] = {sendBuf.size(), failed, launchOrdinal, tag};
+        const uint64_t rec = 32 + LCB_GATHER_INLINE;
+        gatherSend.assign((size_t)rec, 0);
+        memcpy(gatherSend.data(), head, 32);
+        if (!sendBuf.empty()) memcpy(gatherSend.data() + 32, sendBuf.data(), (size_t)std::min<uint64_t>(sendBuf.size(), LCB_GATHER_INLINE));
+        gatherRecv.resize((size_t)(rec * world));
+        if (cfg.allgather(cfg.allgatherUser, gatherSend.data(), rec, gatherRecv.data())) throw LcbError("all-gather failed");
+        st.collectives++;
         uint64_t maxBytes = 0;
         if (sizes) sizes->assign((size_t)world, 0);
         for (int r = 0; r < world; r++) {
-            if (heads[4 * r + 1]) throw LcbError(r == rank ? "rank " + std::to_string(r) + " failed: " + what : "rank " + std::to_string(r) + " failed; stopping all ranks");
-            if (heads[4 * r + 2] != head[2] || heads[4 * r + 3] != head[3])
+            uint64_t h[4];
+            memcpy(h, gatherRecv.data() + (size_t)(rec * r), 32);
+            if (h[1]) throw LcbError(r == rank ? "rank " + std::to_string(r) + " failed: " + what : "rank " + std::to_string(r) + " failed; stopping all ranks");
+            if (h[2] != head[2] || h[3] != head[3])
                 throw LcbError("ranks disagree about the launch they are in (are the engine and device options identical on every rank?)");
-            maxBytes = std::max(maxBytes, heads[4 * r]);
-            if (sizes) (*sizes)[(size_t)r] = heads[4 * r];
+            maxBytes = std::max(maxBytes, h[0]);
+            if (sizes) (*sizes)[(size_t)r] = h[0];
         }
-        sendBuf.resize((size_t)maxBytes);
-        recvBuf.resize((size_t)maxBytes * world);
-        if (maxBytes && cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
+        if (maxBytes <= LCB_GATHER_INLINE) {
+            recvBuf.resize((size_t)maxBytes * world);
+            for (int r = 0; r < world && maxBytes; r++) memcpy(recvBuf.data() + (size_t)(maxBytes * r), gatherRecv.data() + (size_t)(rec * r) + 32, (size_t)maxBytes);
+        } else {
+            sendBuf.resize((size_t)maxBytes);
+            recvBuf.resize((size_t)maxBytes * world);
+            if (cfg.allgather(cfg.allgatherUser, sendBuf.data(), maxBytes, recvBuf.data())) throw LcbError("all-gather failed");
+            st.collectives++;
+        }
         st.exchanges++;
         stride = maxBytes;
     };

@@ -203,7 +203,8 @@ enum { LCB_SEC_SETUP = 0,      // per round: bookkeeping after the round launch 
 
 struct LcbEngineStats {
     int64_t seeds = 0, blocksFound = 0, failures = 0, rounds = 0, recomputeLaunches = 0, recomputedSeeds = 0, conflictLaunches = 0,
-            conflictSeeds = 0, exchanges = 0;
+            conflictSeeds = 0, exchanges = 0,
+            collectives = 0;      // all-gathers issued for them (one per exchange whose buffers are all small, else two)
     // predictive job launches: recomputeLaunches/recomputedSeeds count them and their jobs; of those jobs,
     int64_t jobsUsed = 0;         // ... results that were committed from (exactly validated)
     int64_t viewsBuilt = 0;       // predicted `used` views materialised

@@ -83,16 +83,13 @@ template <int MODE> struct LcbCfg;
 // Idx: a pool index / a vote-table slot (16 bits where the capacities are compile-time constants of a few thousand; 32 bits in the huge
 // variant, whose capacities grow with the path - the reference's vectors are unbounded, path.h:683-685); VLast: (ordinal of the last
 // contributing instance in the voting list, step) of a vote-table entry - 16 + 16 bits, or 32 + 32.
-// (-DLCB_COMPACT_IC / -DLCB_COMPACT_VC: experiment builds of the compact variant with smaller pools - more workgroups per CU, lcb_device_opts.compact_slots)
-#ifndef LCB_COMPACT_IC
-#define LCB_COMPACT_IC 256
-#endif
-#ifndef LCB_COMPACT_VC
-#define LCB_COMPACT_VC 1024
-#endif
-template <> struct LcbCfg<0> { static constexpr uint32_t IC = LCB_COMPACT_IC, VC = LCB_COMPACT_VC, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+template <> struct LcbCfg<0> { static constexpr uint32_t IC = 256, VC = 1024, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<1> { static constexpr uint32_t IC = 1024, VC = 2048, BW = 0, PC = 8192; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<2> { static constexpr uint32_t IC = 4096, VC = 4096, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
+// 4 = the compact variant with half the pools (128 instances / 512 vote slots: 17 KB of LDS instead of 32 KB - 8 workgroups per CU, bound by
+// registers, instead of 5): where the vertices have few occurrences (k = 25 inputs of 8-16 genomes: paths of ~16 instances) the round launches
+// of a Gbp-scale input are bound by the number of seeds in flight (profiles/r06). For the host it is variant 0 (lcb_device_opts.compact_pools).
+template <> struct LcbCfg<4> { static constexpr uint32_t IC = 128, VC = 512, BW = 256, PC = 0; static constexpr bool INST_LDS = true, IDX_LDS = true; typedef uint16_t Idx; typedef uint32_t VLast; };
 template <> struct LcbCfg<3> { static constexpr uint32_t IC = 1, VC = 1, BW = 2048, PC = 0; static constexpr bool INST_LDS = false, IDX_LDS = false; typedef uint32_t Idx; typedef unsigned long long VLast; };
 
 enum LcbStatus : uint32_t {
@@ -691,7 +688,7 @@ __device__ inline void lcb_path_init(ST& S, int32_t vid, int32_t ch)
 // ---- The round-5 walk - one voter after the other, chunk by chunk, voters drawn from LDS tickets. Which kernel variant walks which way is a
 // bit mask over the variants (bit m set: variant m takes the window-table walk below); decided by same-box A/B on the MI355X (profiles/r06).
 #ifndef LCB_WALK_V2_MODES
-#define LCB_WALK_V2_MODES 0x1u
+#define LCB_WALK_V2_MODES 0x11u
 #endif
 #define LCB_WALK_V2_OF(ST) (((LCB_WALK_V2_MODES) >> ST::MODE) & 1u)
 template <class F> struct LcbVoterT { uint32_t e, i, g0, pos0, lo, rem, weight; int32_t dir; bool positive; F sb; };   // sb: base of the voter's segment

@@ -195,6 +195,13 @@ struct Emu {
                                        else emu_run_block(0, NW_, [&]() { lcb_process_body<M, ST, NW_, PF, SG>(T, KP, sp, n, W, op, ar, arc, fa, fac); }); } while (0)
 #define EMU_RUN(M, ST, NW_, PF) do { if (seg) EMU_RUN_S(M, ST, NW_, PF, true); else EMU_RUN_S(M, ST, NW_, PF, false); } while (0)
         // non-stats = the shipped code path (checkpointed replay, dead-seed early-out); the instrumented variant supplies push counts
+        // EMU_COMPACT_SMALL: the compact variant with the small pools (LcbCfg<4>: 128 instances / 512 vote slots; lcb_device_opts.compact_pools)
+        const bool small = mode == 0 && getenv("EMU_COMPACT_SMALL") != nullptr;
+        if (small && noStats && nw == 1) EMU_RUN(4, false, 1, true);
+        else if (small && noStats && nw == 2) EMU_RUN(4, false, 2, true);
+        else if (small && !noStats && nw == 1) EMU_RUN(4, true, 1, false);
+        else if (small && !noStats && nw == 4) EMU_RUN(4, true, 4, false);
+        else
         if (noStats && mode == 0 && nw == 1) EMU_RUN(0, false, 1, true);
         else if (noStats && mode == 0 && nw == 2) EMU_RUN(0, false, 2, true);
         else if (noStats && mode == 1 && nw == 1) EMU_RUN(1, false, 1, true);
@@ -610,9 +617,9 @@ int main(int argc, char** argv)
                 if (nb != (int64_t)blocks.size() || st.blocks_found != es.blocksFound || st.failures != es.failures) diffs++;
                 for (int64_t i = 0; i < nb && i < (int64_t)blocks.size(); i++)
                     if (ob[i].id != blocks[i].id || ob[i].chr != blocks[i].chr || ob[i].start != blocks[i].start || ob[i].end != blocks[i].end) diffs++;
-                fprintf(stderr, "find-ranks rank %d/%d: blocks %zu/%lld failures %lld/%lld rounds %lld job launches %lld (%lld jobs, %lld used) views %lld exchanges %lld | side lanes: %lld batches, %lld jobs, %lld taken, %lld void, %lld failed | diffs %d\n", r, world,
+                fprintf(stderr, "find-ranks rank %d/%d: blocks %zu/%lld failures %lld/%lld rounds %lld job launches %lld (%lld jobs, %lld used) views %lld exchanges %lld (collectives %lld) | side lanes: %lld batches, %lld jobs, %lld taken, %lld void, %lld failed | diffs %d\n", r, world,
                         blocks.size(), (long long)nb, (long long)es.failures, (long long)st.failures, (long long)es.rounds, (long long)es.recomputeLaunches,
-                        (long long)es.recomputedSeeds, (long long)es.jobsUsed, (long long)es.viewsBuilt, (long long)es.exchanges, (long long)es.sideBatches, (long long)es.sideJobs,
+                        (long long)es.recomputedSeeds, (long long)es.jobsUsed, (long long)es.viewsBuilt, (long long)es.exchanges, (long long)es.collectives, (long long)es.sideBatches, (long long)es.sideJobs,
                         (long long)es.sideTaken, (long long)es.sideVoid, (long long)es.sideFailed, diffs);
                 if (es.exchanges == 0) { fprintf(stderr, "FAIL: no exchange happened\n"); bad++; }
                 if (getenv("EMU_SIDE_LANES") && es.recomputeLaunches > 2 && es.sideBatches == 0) { fprintf(stderr, "FAIL: side lanes asked for but no batch ran in the background\n"); bad++; }

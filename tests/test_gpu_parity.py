@@ -170,6 +170,41 @@ def test_find_blocks_matches_reference(built, case, tmp_path):
     assert blocks.tobytes() == blocks2.tobytes()
 
 
+@pytest.mark.parametrize("pools", [1, 2])
+def test_compact_pools_parity(built, case, pools):
+    """The compact variant with either of its pool sizes (lcb_device_opts.compact_pools: 1 = 256 instances / 1 024 vote slots, 2 = 128 / 512 with 8
+    workgroups per CU; 0 lets the input choose): every seed started there in both `used` states (the seeds that outgrow the pools go up the ladder),
+    then the whole FindBlocks + GFF against the reference."""
+    st, p, dev = _setup(case, compact_pools=pools, start_mode=1)
+    orc = Oracle(case.graph, [case.fasta], case.k, case.a)
+    seeds = st.seeds(4)
+    _compare_all(case, st, dev, orc, seeds, "compact pools %d, unused state" % pools)
+    assert dev.mode_seeds()[0] >= len(seeds)
+    orc.find_blocks(case.k, case.b, case.m)
+    dev.set_used(orc.used_bitmap(st.chr_start()))
+    _compare_all(case, st, dev, orc, seeds, "compact pools %d, final state" % pools)
+    dev.close()
+    st, p, dev = _setup(case, compact_pools=pools, wide_threshold=1)       # (every launch of two seeds or more begins in the compact variant)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+
+
+@pytest.mark.parametrize("sparse", [-1, 0, 1])
+def test_host_settled_seeds_and_sparse_rounds_on_gpu(built, case, sparse):
+    """lcb_hooks.sparse_rounds: -1 = every result from the device, 0 (default) = the host settles the seeds without an unused occurrence, 1 = also sparse
+    speculative launches (only the first phase of every cluster of seeds). Blocks, failure_ and blocksFound_ are the reference's in all three."""
+    st, p, dev = _setup(case)
+    finder = sibeliaz_amd.BlocksFinder(st, case.k)
+    blocks = finder.FindBlocks(case.m, case.b, device=dev, threads=4, sparse_rounds=sparse)
+    got = "".join("%d\t%d\t%d\t%d\n" % (b["id"], b["chr"], b["start"], b["end"]) for b in blocks)
+    assert got == case.golden("pretrim.tsv")
+    summary = dict(ln.split("\t") for ln in case.golden("summary.txt").splitlines())
+    assert finder.stats["failures"] == int(summary["failure"]) and finder.stats["blocks_found"] == int(summary["blocksFound"])
+    assert sparse >= 0 or finder.stats["host_dead"] == 0
+
+
 @pytest.mark.parametrize("fixed,phases", [(1, 1), (1, 7), (0, 64)])
 def test_round_engine_variants_on_gpu(built, case, fixed, phases):
     """Round size must not change the result: one phase per launch (the reference's schedule), a fixed speculative round of

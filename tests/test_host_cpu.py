@@ -263,6 +263,13 @@ def emu_built():
                                             ("inv_k25", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "1", "EMU_SIDE_DELAY": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "1", "LCB_CLUSTER_GAP": "1000000"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8", "LCB_SPARSE_ROUNDS": "-1"}),
                                             ("twogenomes", "find", {"EMU_ROUNDS": "8", "EMU_NOSTATS": "1", "LCB_SPARSE_ROUNDS": "-1"}),
+                                            # the compact variant with the small pools (128 instances / 512 vote slots; lcb_device_opts.compact_pools = 2): per-seed results
+                                            # with the footprint check, the overflow into the wide variant (tandem4's pools outgrow 128), the whole engine, with segments
+                                            ("inv_k25", "seeds-init", {"EMU_COMPACT_SMALL": "1", "EMU_NW": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "600", "EMU_FP_CHECK": "1"}),
+                                            ("tandem4", "seeds-final", {"EMU_COMPACT_SMALL": "1", "EMU_LIMIT": "500"}),
+                                            ("nruns_abund", "find", {"EMU_COMPACT_SMALL": "1", "EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_NW": "2", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8"}),
+                                            ("twogenomes", "find", {"EMU_COMPACT_SMALL": "1", "EMU_ROUNDS": "8"}),
+                                            ("inv_k25", "seeds-init", {"EMU_COMPACT_SMALL": "1", "EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "4300000000", "EMU_SEG_MAX": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "300", "EMU_FP_CHECK": "1"}),
                                             # predictive engine: no F prediction / tiny job cap / view starvation, fixed whole-input round
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "LCB_PREDICT_F": "1", "LCB_MAX_JOBS": "8"}),
                                             ("nruns_abund", "find", {"EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_VIEWS": "3", "LCB_ROUND_FIXED": "1", "LCB_MAX_JOBS": "64"}),
