@@ -514,7 +514,7 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": w["desc"], "lcb_synth": w["synth"], "seeds": S, "junction_occurrences": storage.n_positions(),
                        "vertices": storage.GetVerticesNumber(), "phase_size": 256,
-                       "parallelism": "one seed per workgroup: compact variant (2 wavefronts, 5 workgroups per CU) for launches of many seeds, wide variant (16 wavefronts "
+                       "parallelism": "one seed per workgroup: compact variant (2 wavefronts; 5 workgroups per CU, or 8 with the small pools an input of few occurrences per vertex gets) for launches of many seeds, wide variant (16 wavefronts "
                                       "sharing the votes) for launches of few, big variant for seeds with thousands of instances; speculative rounds of up to 256 phases with lazy tails and dry-run job launches against predicted used views, exact footprint "
                                       "validation, ordered commit on the host; %d GPU(s)%s" % (n_gpus, ", every launch dealt to the ranks, ncclAllGather of results" if n_gpus > 1 else ", a stop's speculative jobs on side lanes"),
                        "blocks_found": int(st["blocks_found"]), "commit_conflicts": int(st["failures"]), "rounds": int(st["rounds"]),
@@ -524,6 +524,7 @@ def main():
                        "side": {k: int(st["side_" + k]) for k in ("batches", "jobs", "taken", "void", "failed")},
                        "early_critical_launches": int(st.get("early_critical", 0)),
                        "lazy_seeds": int(st.get("lazy_seeds", 0)),
+                       "host_settled_seeds": int(st.get("host_dead", 0)), "collectives": int(st.get("collectives", 0)),
                        "seeds_per_kernel_variant": dict(zip(("compact", "wide", "big", "huge"), dev.mode_seeds())) if gpus is None else None,
                        "host_ms_per_step": {"in_processor_incl_kernels": process_ms / args.steps, "dry_runs": plan_ms / args.steps,
                                             "commit_validation_other": ms_per_step - (process_ms + plan_ms) / args.steps},

@@ -168,8 +168,8 @@ typedef struct {
                                 milliseconds each); the others get no result there - the commit computes them when it needs them. Default: the big-variant slots of a
                                 lane (one wave); 0xFFFFFFFF = no cap */
     uint32_t compact_pools;  /* pools of the compact variant: 1 = 256 instances / 1 024 vote slots (5 workgroups per CU), 2 = 128 / 512 (8 per CU: more seeds in
-                                flight where paths have few instances); 0 = chosen by the input (small pools if a vertex has at most 20 occurrences on
-                                average; back to the large ones if more than 3 % of the live seeds overflow them) */
+                                flight where paths have few instances); 0 = chosen by the input (small pools if the typical occurrence belongs to a vertex
+                                with at most 20 occurrences; back to the large ones if more than an eighth of the live seeds outgrow them) */
     uint64_t seg_gap;        /* unused positions between two segments of the device tables (0 = none): with 2^32 the flat indices of a
                                 small input exceed 32 bits, i.e. every 64-bit address computation of the kernels is exercised */
 } lcb_device_opts;

@@ -476,9 +476,11 @@ lcb_device* lcb_device_create_impl(const lcb_graph* g, const lcb_params* p, int 
         // occurrences per vertex; the 62-strain shape has 26 at 1/40 of its size and more at full size, and its paths outgrow 128 instances)
         if (o.compact_pools > 2) throw LcbError("lcb_device_opts.compact_pools: 0 (by the input), 1 (256 instances / 1 024 vote slots) or 2 (128 / 512)");
         d->compactAuto = o.compact_pools == 0;
-        uint64_t nOccupied = 0;                      // vertices with an occurrence the abundance filter kept
-        for (size_t v = 0; v + 1 < g->occStart.size(); v++) nOccupied += g->occStart[v + 1] > g->occStart[v];
-        d->compactSmall = o.compact_pools == 2 || (o.compact_pools == 0 && nOccupied > 0 && g->nPos() <= 20 * nOccupied);
+        // (the occurrence-weighted mean of the occurrences per vertex: "the typical occurrence belongs to a vertex with that many" - 6-14 for the k = 25 shapes of 8 / 16
+        // genomes, 35+ for the 62-strain shape, 25 for the 10-strain one, whose many strain-private vertices would hide that in a plain mean)
+        long double occSq = 0;
+        for (size_t v = 0; v + 1 < g->occStart.size(); v++) { const long double nv = (long double)(g->occStart[v + 1] - g->occStart[v]); occSq += nv * nv; }
+        d->compactSmall = o.compact_pools == 2 || (o.compact_pools == 0 && g->nPos() > 0 && occSq <= 20.0L * (long double)g->nPos());
         d->compactLargeSlots = o.compact_slots ? o.compact_slots : (d->seg ? 4 : 5) * nCu;
         if (!o.compact_slots) o.compact_slots = d->compactSmall ? 8 * nCu : d->compactLargeSlots;     // (8: four wavefronts per SIMD by registers, two per workgroup)
         if (!o.wide_slots) o.wide_slots = nCu;
@@ -1048,8 +1050,9 @@ void runToCompletion(lcb_device_impl* d, ProcAcc& A)
             d->launch(ws, m, screen);
             hugeOverflow = gatherBatch(d, A, list, at, m, screen, mode) || hugeOverflow;
         }
-        if (mode == 0 && d->compactSmall && d->compactAuto && d->compactDone + d->compactPoolOvf >= 4096 && d->compactPoolOvf * 32 > d->compactDone + d->compactPoolOvf) {
-            // more than 3 % of the live seeds outgrow the small pools (and run again in the wide variant, one workgroup per CU): the large pools from here on
+        if (mode == 0 && d->compactSmall && d->compactAuto && d->compactDone + d->compactPoolOvf >= 65536 && d->compactPoolOvf * 8 > d->compactDone + d->compactPoolOvf) {
+            // a safeguard behind the choice by the input: more than an eighth of the live seeds outgrow the small pools (and run again in the wide variant, one
+            // workgroup per CU): the large pools from here on. (The head of the seed order - the vertices with the most occurrences - outgrows either pool.)
             d->compactSmall = false; d->compactFellBack++;
             d->ws[0].nSlots = std::min(d->ws[0].nSlots, d->compactLargeSlots);
         }
