@@ -64,6 +64,9 @@ def case_params(i, small=False):
     if sr is not None:
         for mode, env in runs:
             if mode == "find": env["LCB_SPARSE_ROUNDS"] = sr
+    # ... and a third of the cases run the compact variant with its small pools (128 instances / 512 vote slots; lcb_device_opts.compact_pools): every run of the case
+    if rnd.random() < 1.0 / 3:
+        for mode, env in runs: env["EMU_COMPACT_SMALL"] = "1"
     return synth, (k, b, m, a), runs, (strains, segs)
 
 
