@@ -283,6 +283,7 @@ struct lcb_device_impl {
     bool compactSmall = false, compactAuto = false;
     uint32_t compactLargeSlots = 0;              // ws[0].nSlots with the large pools
     int64_t compactDone = 0, compactPoolOvf = 0; // seeds that ended in the compact variant with a result / by overflowing its instance pool or vote table
+    int64_t longPathHints = 0;                   // results of the compact variant whose instances span more junctions than the wide variant's path set holds vertices
     int compactFellBack = 0;
     uint32_t compactIC() const { return compactSmall ? LcbCfg<4>::IC : LcbCfg<0>::IC; }
     double modeMs[4] = {0, 0, 0, 0};             // hipEvent-timed kernel time of each variant since creation (all streams) ...
@@ -653,6 +654,7 @@ void lcb_device_destroy_impl(lcb_device* h)
                     (long long)d->modeSeeds[1], (long long)d->modeSeeds[2], (long long)d->modeSeeds[3], (long long)d->screened, (long long)d->screenedDead);
             fprintf(stderr, "   private view pages built: %lld (4 KB each; pool %u pages)\n", (long long)d->viewPagesBuilt, d->views.poolPages);
             fprintf(stderr, "   compact path set: %u vertices per slot (enlarged %d times)\n", d->ws[0].pathCap, d->compactPathGrown);
+            fprintf(stderr, "   results remembered as too long for the wide variant's path set: %lld\n", (long long)d->longPathHints);
             fprintf(stderr, "   compact pools: %s (%u workgroups), %lld live seeds ended there, %lld outgrew its pools%s\n", d->compactSmall ? "128 instances / 512 vote slots" : "256 instances / 1 024 vote slots", d->ws[0].nSlots,
                     (long long)d->compactDone, (long long)d->compactPoolOvf, d->compactFellBack ? " - the small pools were given up" : "");
             fprintf(stderr, "   result arena: %llu instances (enlarged %d times)\n", d->arenaCap, d->arenaGrown);
@@ -967,6 +969,15 @@ bool gatherBatch(lcb_device_impl* d, ProcAcc& A, const std::vector<int64_t>& lis
         const int64_t s = list[at + i];
         if (o.status == LCB_ST_OK) {
             if (mode == 0 && o.nFp) d->compactDone++;
+            // A block whose instances span thousands of junctions was found by a path of as many vertices: when this seed is computed again - as a stop's own job
+            // or in a background batch, launches that begin in the wide variant - it would fill the wide variant's LDS path set (4 096 vertices) first and start
+            // over elsewhere. It is remembered like an overflow: the next attempt begins in the compact variant (a lane: in the big one).
+            if (mode == 0 && o.nInst && !d->o.start_mode) {
+                // (the first instance stands for all: the instances of a block span about the same number of junctions, and this loop runs for every result)
+                const uint4 r0 = d->hArena[o.arenaOff];
+                const uint32_t span = r0.y > r0.z ? r0.y - r0.z : r0.z - r0.y;
+                if ((uint64_t)span * 8 >= (uint64_t)d->ws[1].pathCap * 3) { setHint(d, A.seeds[s], 0); d->longPathHints++; }
+            }
             if (mode >= 2 && (!(A.allBig && A.start[(size_t)s] < 2) || o.poolInst > LcbCfg<1>::IC)) A.neededBig++;
             A.cnt[(size_t)s] = o.nInst;
             A.flatOff[(size_t)s] = A.flat.size();
@@ -1264,8 +1275,9 @@ int lcb_device_side_begin_impl(lcb_device* h, const lcb_seed* seeds, const uint3
             if ((d->hintBits[hb >> 6] >> (hb & 63)) & 1ull) { auto it = d->modeHint.find(key); if (it != d->modeHint.end()) mode = it->second; }
         }
         if (mode >= 3) L.hOut[i].status = LCB_ST_ABORTED;           // the huge variant does not run here: no result
-        else if (mode == 2 && d->o.side_big_cap != 0xFFFFFFFFu && nB >= d->o.side_big_cap) L.hOut[i].status = LCB_ST_ABORTED;   // more heavy speculation than the lane's cap: no result (the plan's order is the order of need)
-        else if (mode == 2) listB[nB++] = (uint32_t)i;
+        // (hint 0: a path too long for the wide variant's LDS path set - a lane has no compact kernel, so it runs in the big one)
+        else if ((mode == 2 || mode == 0) && d->o.side_big_cap != 0xFFFFFFFFu && nB >= d->o.side_big_cap) L.hOut[i].status = LCB_ST_ABORTED;   // more heavy speculation than the lane's cap: no result (the plan's order is the order of need)
+        else if (mode == 2 || mode == 0) listB[nB++] = (uint32_t)i;
         else listW[nW++] = (uint32_t)i;
     }
     memset(L.hCtl, 0, 64);
