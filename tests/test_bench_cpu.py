@@ -3,6 +3,7 @@ time-bounded, and a failing leg never costs the line. The device is replaced by 
 the harness, not a measurement (the measurement is the driver's run on the MI355X)."""
 import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -178,3 +179,29 @@ def test_secondary_entries_are_timed_by_child_runs_and_condensed(fake_gpu, monke
     assert sec[0]["measured_in_this_run"] is True and sec[0]["speedup_over_cpu_baseline"] == pytest.approx(2.5) and sec[0]["roofline"]["frac"] == 0.0011
     assert sec[0]["sources"] == bench.source_hash() and sec[0]["cpu_baseline"]["gff_md5_equal"] is True
     assert sec[1]["workload"] == "mice16_test" and "error" in sec[1]
+
+
+def test_pmc_summary_condenses_the_counter_passes_per_kernel_variant(tmp_path):
+    """scripts/r06/pmc_summary.py: the FETCH / WRITE / SQ passes of the evidence script become per-variant HBM bytes (FETCH doubled + WRITE, KB units) and SQ shares in
+    profiles/r06/pmc_traffic.json - what bench.py quotes as roofline.traffic and roofline.per_kernel[...].hbm_bytes_per_step. Both compact instantiations count as `compact`."""
+    import csv
+    out = tmp_path / "ev"
+    kernels = [("void lcb_process_kernel<0, false, 2, false, false>(LcbTables, int)", 100.0), ("void lcb_process_kernel<4, false, 2, false, false>(LcbTables, int)", 50.0),
+               ("void lcb_process_kernel<1, false, 16, false, false>(LcbTables, int)", 10.0), ("lcb_screen_kernel(LcbTables)", 5.0)]
+    for d, names in (("pmc_fetch", {"FETCH_SIZE": 1.0}), ("pmc_write", {"WRITE_SIZE": 0.5}),
+                     ("pmc_sq", {"SQ_WAVE_CYCLES": 10.0, "SQ_INSTS_VALU": 2.0, "SQ_INSTS_SALU": 1.5, "SQ_INSTS_LDS": 0.5, "SQ_ACTIVE_INST_ANY": 4.0, "SQ_WAIT_INST_ANY": 1.0, "SQ_WAIT_ANY": 5.0})):
+        os.makedirs(out / d / "x")
+        with open(out / d / "x" / "p_counter_collection.csv", "w") as f:
+            w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writeheader()
+            for k, v in kernels:
+                for n, scale in names.items():
+                    w.writerow({"Kernel_Name": k, "Counter_Name": n, "Counter_Value": v * scale})
+    (out / "kernel_source_hash.txt").write_text("abc\n")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "r06", "pmc_summary.py"), str(out)], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    js = json.load(open(out / "pmc_traffic.json"))
+    assert js["kernel_source_hash"] == "abc" and js["launches"] == 3
+    assert js["per_kernel_hbm_bytes_per_step"] == {"compact": (2 * 150.0 + 75.0) * 1024, "wide": (2 * 10.0 + 5.0) * 1024}
+    assert js["hbm_bytes_per_pass"] == pytest.approx((2 * 160.0 + 80.0) * 1024) and js["per_kernel_dispatches"] == {"compact": 2, "wide": 1}
+    assert js["per_kernel_sq"]["compact"]["derived"]["active_share_of_wave_cycles"] == pytest.approx(0.4)
+    assert json.load(open(tmp_path / "profiles" / "r06" / "pmc_traffic.json")) == js
