@@ -187,7 +187,14 @@ struct Emu {
         const uint32_t n = (uint32_t)c.ks.size();
         if (!n) return;
         const char* nwEnv = getenv("EMU_NW");
-        const int nw = nwEnv ? atoi(nwEnv) : 1;
+        int nw = nwEnv ? atoi(nwEnv) : 1;
+        {   // a seed that overflowed a smaller variant is re-run in THIS mode (runRetry) with the EMU_NW of the case: where this mode has no instantiation with that many
+            // wavefronts it runs with one (the fuzz campaign reached this with the small-pool compact variant, two wavefronts, and an overflow into the wide variant)
+            const bool ns = getenv("EMU_NOSTATS") != nullptr;
+            const bool have = ns ? ((mode == 0 && (nw == 1 || nw == 2)) || (mode == 1 && (nw == 1 || nw == 16)) || (mode == 2 && (nw == 1 || nw == 8 || nw == 16)) || (mode == 3 && (nw == 1 || nw == 8)))
+                                 : ((mode == 0 && (nw == 1 || nw == 4)) || (mode == 1 && (nw == 1 || nw == 8 || nw == 16)) || (mode == 2 && (nw == 1 || nw == 4)) || (mode == 3 && (nw == 1 || nw == 4)));
+            if (!have && isRetry) nw = 1;
+        }
         LcbSeedOut* op = c.out.data(); uint4* ar = c.arena.data(); LcbFpOut* fa = c.fpArena.data();
         const size_t arc = c.arena.size(), fac = c.fpArena.size();
         const bool noStats = getenv("EMU_NOSTATS") != nullptr;     // the shipped instantiation (checkpointed replay, no event counters)
@@ -273,13 +280,14 @@ struct Emu {
     // Like the product's retry chain (device.hip): seeds that overflow the LDS capacities of this mode are run again in the next
     // larger mode (small -> medium -> big), against the same `used` views.
     std::unique_ptr<Emu> next;
+    bool isRetry = false;          // this emulator runs the seeds that overflowed a smaller variant
     void runRetry(const std::vector<LcbKSeed>& seeds)
     {
         run(seeds);
         std::vector<size_t> again;
         for (size_t i = 0; i < out.size(); i++) if (out[i].status >= LCB_ST_INST_OVF && out[i].status <= LCB_ST_BEST_OVF) again.push_back(i);
         if (again.empty() || mode >= 3) return;
-        if (!next) next.reset(new Emu(g, p, mode + 1));
+        if (!next) { next.reset(new Emu(g, p, mode + 1)); next->isRetry = true; }
         next->used = used; next->T.used = next->used.data(); next->nViewsAlloc = nViewsAlloc;
         next->viewTab = viewTab; next->T.viewTab = next->viewTab.data();
         std::vector<LcbKSeed> sub;

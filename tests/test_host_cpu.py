@@ -267,6 +267,7 @@ def emu_built():
                                             # with the footprint check, the overflow into the wide variant (tandem4's pools outgrow 128), the whole engine, with segments
                                             ("inv_k25", "seeds-init", {"EMU_COMPACT_SMALL": "1", "EMU_NW": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "600", "EMU_FP_CHECK": "1"}),
                                             ("tandem4", "seeds-final", {"EMU_COMPACT_SMALL": "1", "EMU_LIMIT": "500"}),
+                                            ("tandem4", "seeds-init", {"EMU_COMPACT_SMALL": "1", "EMU_NW": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "500", "EMU_FP_CHECK": "1"}),   # (two wavefronts; the seeds that outgrow the pools re-run in the wide variant)
                                             ("nruns_abund", "find", {"EMU_COMPACT_SMALL": "1", "EMU_ROUNDS": "64", "EMU_NOSTATS": "1", "EMU_NW": "2", "EMU_SIDE_LANES": "2", "LCB_LAZY_SPAN": "8"}),
                                             ("twogenomes", "find", {"EMU_COMPACT_SMALL": "1", "EMU_ROUNDS": "8"}),
                                             ("inv_k25", "seeds-init", {"EMU_COMPACT_SMALL": "1", "EMU_SEG_CAP": "2000", "EMU_SEG_GAP": "4300000000", "EMU_SEG_MAX": "2", "EMU_NOSTATS": "1", "EMU_LIMIT": "300", "EMU_FP_CHECK": "1"}),
